@@ -1,0 +1,241 @@
+/*
+ * libpropainter_hip — C-ABI of the MI355X (gfx950) ProPainter inference kernels.
+ *
+ * The reference (sczhou/ProPainter) is pure Python: its native arithmetic lives in torch /
+ * torchvision wheels.  Each entry point below replaces the native op(s) named in its comment
+ * (file:line relative to the reference root).  Conventions:
+ *   - every symbol is extern "C"; plain C types; tensors are raw device pointers + explicit sizes;
+ *   - the caller owns every buffer (including index tables and workspaces); kernels never allocate,
+ *     free or retain pointers; weights are read-only;
+ *   - all work is enqueued asynchronously on the `stream` argument (a hipStream_t passed as void*);
+ *     no implicit synchronisation;
+ *   - return 0 on success, a negative PP_ERR_* code for argument errors, a positive value = raw
+ *     hipError_t; the message is retrievable with pp_last_error_string() (thread-local);
+ *   - activation layout inside the engine is NHWC ("pixel-major"): element (n,y,x,c) of a tensor lives
+ *     at ((n*H + y)*W + x)*cstride + choff + c, so concatenations are expressed as channel windows of
+ *     a wider buffer instead of copies;
+ *   - dtype codes: PP_F32 = 0, PP_F16 = 1.  Accumulation is always fp32.
+ */
+#ifndef PROPAINTER_HIP_H
+#define PROPAINTER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PP_F32 0
+#define PP_F16 1
+
+#define PP_ERR_ARG (-1)        /* bad shape / null pointer / unsupported size        */
+#define PP_ERR_DTYPE (-2)      /* unsupported dtype code                              */
+#define PP_ERR_ALIGN (-3)      /* pointer or channel count violates alignment rule    */
+#define PP_ERR_WORKSPACE (-4)  /* caller-provided table / workspace too small         */
+
+/* activation codes for fused epilogues */
+#define PP_ACT_NONE 0
+#define PP_ACT_RELU 1
+#define PP_ACT_LRELU 2   /* slope = act_param */
+#define PP_ACT_SIGMOID 3
+#define PP_ACT_TANH 4
+#define PP_ACT_GELU 5    /* exact erf GELU (torch.nn.GELU default) */
+
+int pp_version(void);
+const char* pp_last_error_string(void);
+/* sizeof() of the argument structs as compiled, for bindings to verify their layouts */
+int pp_sizeof_conv_args(void);
+int pp_sizeof_attn_args(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution / linear / batched GEMM on MFMA  (replaces every nn.Conv2d, nn.Conv3d,
+ * nn.Linear and torch.matmul on the path: RAFT/extractor.py:168-192, RAFT/update.py:89-136,
+ * model/recurrent_flow_completion.py:206-256, model/propainter.py:198-216,266-273,
+ * model/modules/sparse_transformer.py:17,39,43,68-69,123-130; and, with `dcn_offmask` set, the
+ * sampling + GEMM of torchvision.ops.deform_conv2d at model/propainter.py:67-69 and
+ * model/recurrent_flow_completion.py:42-44).
+ *
+ * GEMM view: M = N*OH*OW output pixels, K = (taps x concatenated source channels), per group.
+ * K is walked in chunks of 8 channels described by a device table (pp_conv_build_ktable) so that
+ * arbitrary tap lists (dilation, phase-decomposed transposed convs) and channel concatenations of
+ * up to PP_CONV_MAX_SRC sources are one kernel.  Weights are pre-packed [groups][cout_pad][K].
+ * ---------------------------------------------------------------------------------------------- */
+#define PP_CONV_MAX_SRC 4
+
+typedef struct {
+  const void* ptr;  /* NHWC base of this source                          */
+  int32_t cstride;  /* elements per pixel                                */
+  int32_t choff;    /* first channel used (for group 0)                  */
+  int32_t cgroup;   /* channel advance per group (0 when groups == 1)    */
+  int32_t pad_;
+} pp_conv_src_t;
+
+typedef struct {
+  int32_t dtype;                 /* PP_F32 / PP_F16: sources, weights, residual, dcn_offmask   */
+  int32_t N, H, W;               /* input extent shared by all sources                         */
+  int32_t OH, OW;                /* output extent                                              */
+  int32_t stride_h, stride_w;
+  int32_t pad_h, pad_w;          /* input coordinate = out*stride - pad + tap offset           */
+  int32_t pad_mode;              /* 0 = zeros, 1 = replicate (clamp)                           */
+  int32_t groups;                /* grid.z; also used as the batch count of a batched GEMM     */
+  int32_t cout_g;                /* real output channels per group                             */
+  int32_t cout_pad;              /* rows per group in the packed weights (multiple of 16)      */
+  int32_t kchunks;               /* K/8 per group, multiple of 4                               */
+  int32_t nsrc;
+  pp_conv_src_t src[PP_CONV_MAX_SRC];
+  const int32_t* ktable;         /* device, kchunks x int4 {dy, dx, src | g<<8 | tap<<16, choff}; src 255 = zero chunk */
+  const void* weight;            /* device, packed [groups][cout_pad][kchunks*8], dtype        */
+  int64_t weight_gstride;        /* elements between groups in `weight` (cout_pad*K normally)  */
+  const float* bias;             /* device fp32 [groups*cout_g] or NULL                        */
+  int32_t act;                   /* PP_ACT_* applied to (acc*out_scale + bias)                 */
+  float act_param;
+  float out_scale;
+  const void* residual;          /* optional NHWC tensor added after `act` (dtype = dtype)     */
+  int32_t res_cstride, res_choff;
+  int32_t act2;                  /* PP_ACT_NONE or PP_ACT_RELU applied after the residual add  */
+  int32_t out_dtype;             /* PP_F32 / PP_F16                                            */
+  void* out;                     /* NHWC [N,OH,OW,...]                                          */
+  int32_t out_cstride, out_choff;
+  int32_t out_cgroup;            /* channel advance per group in `out` (cout_g normally)       */
+  int64_t src_gstride;           /* batched GEMM: element advance of src[0].ptr per group      */
+  int64_t out_gstride;           /* batched GEMM: element advance of `out` per group           */
+  /* deformable sampling (modulated, 16 offset groups, 3x3): NHWC [N,H,W,dcn_cstride] holding
+   * 288 offset channels (dy,dx interleaved per (group,tap)) followed by 144 modulation masks. */
+  const void* dcn_offmask;
+  int32_t dcn_cstride;
+  int32_t dcn_mask_off;          /* channel index of the first modulation mask (288)           */
+} pp_conv_args_t;
+
+/* Host helper: fill `out` (kchunks_padded x 4 int32) for `ntaps` taps (dy[i], dx[i] are input
+ * offsets added to out*stride - pad) over `nsrc` sources of src_channels[i] channels each (each a
+ * multiple of 8).  `dcn_groups` > 0 additionally records the offset-group / tap id of every chunk.
+ * Returns the padded chunk count (multiple of 4) or a negative error; call with out == NULL to size. */
+int pp_conv_build_ktable(int ntaps, const int32_t* dy, const int32_t* dx, int nsrc,
+                         const int32_t* src_channels, int dcn_groups, int32_t* out, int out_capacity);
+
+int pp_conv2d(const pp_conv_args_t* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Flow-guided sampling (replaces F.grid_sample as used by model/modules/flow_loss_utils.py:6-45,
+ * model/propainter.py:19-31,104-190)
+ * ---------------------------------------------------------------------------------------------- */
+/* out[n,y,x,c] = sample(x[n,:,:,c], (x + flow[n,y,x,0], y + flow[n,y,x,1])), zeros padding,
+ * align_corners=True; mode 0 = bilinear, 1 = nearest (round-half-even).  x/out NHWC with channel
+ * windows; flow NHWC [N,H,W,2] (fl_cstride >= 2). C must be a multiple of 8 unless C <= 4. */
+int pp_flow_warp(const void* x, int x_cstride, int x_choff, const void* flow, int fl_cstride, int fl_choff,
+                 void* out, int out_cstride, int out_choff, int N, int H, int W, int C, int mode,
+                 int dtype, void* stream);
+
+/* valid[n,y,x] = |fw + warp(bw, fw)|^2 < 0.01 (|fw|^2 + |warp(bw)|^2) + 0.5  (model/propainter.py:22-31);
+ * flows NHWC [N,H,W,2]; valid written as dtype into out[n,y,x,out_choff] (1.0 / 0.0). */
+int pp_fb_check(const void* flow_fw, int fw_cstride, const void* flow_bw, int bw_cstride, void* out,
+                int out_cstride, int out_choff, int N, int H, int W, int dtype, void* stream);
+
+/* One step of the non-learnable image propagation (model/propainter.py:137-170, learnable=False),
+ * planar NCHW frames [N,3,H,W] / masks [N,1,H,W] / flows [N,2,H,W]:
+ *   valid = fb_check(flow_prop, flow_check); m_w = bin(warp_bilinear(mask_prop));
+ *   u = bin(m_cur*valid*(1-m_w)); x_out = u*warp_<mode>(x_prop) + (1-u)*x_cur;
+ *   m_out = bin(m_cur*(1-valid*(1-m_w))).  */
+int pp_img_prop_step(const void* x_prop, const void* m_prop, const void* x_cur, const void* m_cur,
+                     const void* flow_prop, const void* flow_check, void* x_out, void* m_out, int N, int C,
+                     int H, int W, int mode, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * RAFT correlation (RAFT/corr.py:13-60, RAFT/utils/utils.py:57-71, RAFT/raft.py:73-84)
+ * ---------------------------------------------------------------------------------------------- */
+/* 2x2/stride-2 average pooling of per-source-pixel correlation maps: in [M, H, W] fp32 -> out [M, H/2, W/2]. */
+int pp_corr_avgpool(const float* in, float* out, int64_t M, int H, int W, void* stream);
+
+/* 4-level 9x9 bilinear lookup.  lvl[l] = [B*h*w, Hl, Wl] fp32 map of every source pixel; coords fp32
+ * NHWC [B,h,w,2] (x, y); out NHWC [B,h,w,out_cstride] channel l*81 + a*9 + b samples
+ * (x/2^l + a - 4, y/2^l + b - 4) (first index moves x; RAFT/corr.py:36-43); channels 324..C_out_pad-1 = 0. */
+int pp_corr_lookup(const float* lvl0, const float* lvl1, const float* lvl2, const float* lvl3, const float* coords,
+                   void* out, int out_cstride, int out_cpad, int B, int h, int w, int out_dtype, void* stream);
+
+/* convex 8x upsampling: flow fp32 NHWC [B,h,w,2]; mask NHWC [B,h,w,576] (channel k*64 + i*8 + j, already
+ * scaled by 0.25); out fp32 planar [B,2,8h,8w]. */
+int pp_convex_upsample(const float* flow, const void* mask, int mask_cstride, int mask_dtype, float* out, int B,
+                       int h, int w, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Sparse window attention (model/modules/sparse_transformer.py:158-281)
+ * ---------------------------------------------------------------------------------------------- */
+/* Host helper: window index tables for a padded Hp x Wp token grid with (wh, ww) windows:
+ * own[nW*wh*ww] and rolled[nW*n_rolled] flat positions (circular torch.roll semantics, :140-153,181-200).
+ * Returns n_rolled (148 for 5x9) or negative error; call with NULL outputs to size. */
+int pp_window_tables(int Hp, int Wp, int wh, int ww, int32_t* own, int32_t* rolled, int capacity_rolled);
+
+/* wmask[b, w] = sum over local frames of max over the window of mask (:227-229); mask [B,Lt,Hp,Wp] dtype. */
+int pp_window_mask(const void* mask, float* wmask, int B, int Lt, int Hp, int Wp, int wh, int ww, int dtype,
+                   void* stream);
+
+typedef struct {
+  int32_t dtype;               /* q/k/v/pooled/out dtype                                           */
+  int32_t B, T, Hp, Wp, C;     /* padded token grid, C = heads*head_dim                            */
+  int32_t heads;               /* head_dim = C / heads must be 128                                  */
+  int32_t wh, ww;              /* window (5, 9)                                                    */
+  int32_t n_rolled;            /* 148                                                              */
+  int32_t P;                   /* pooled tokens per frame                                          */
+  int32_t n_tind;              /* number of key frames for masked windows                          */
+  const void* q; const void* k; const void* v;   /* [B,T,Hp,Wp,C]                                  */
+  int32_t qkv_cstride;         /* elements per token in q/k/v (C, or 3C for a fused qkv buffer)     */
+  const void* pk; const void* pv;                /* [B,T,P,C] pooled key/value, pkv_cstride per token */
+  int32_t pkv_cstride;
+  const int32_t* own;          /* device [nW, wh*ww]                                               */
+  const int32_t* rolled;       /* device [nW, n_rolled]                                            */
+  const int32_t* tind;         /* device [n_tind] key frame indices                                */
+  const float* wmask;          /* device [B, nW]; > 0 => masked window                             */
+  void* out;                   /* [B,T,Hp,Wp,C] (cstride = C), every position written               */
+  int32_t impl;                /* 0 = auto (MFMA for fp16), 1 = force the scalar reference kernel   */
+} pp_attn_args_t;
+
+int pp_sparse_window_attention(const pp_attn_args_t* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Token <-> feature-map ops (model/modules/sparse_transformer.py:49-101) and small dense helpers
+ * ---------------------------------------------------------------------------------------------- */
+/* F.fold(kernel 7, stride 3, pad 3) of tokens [BT, fh*fw, C*49] (feature index c*49 + ky*7 + kx) into NHWC
+ * [BT,H,W,C]; if normalize != 0 the sum is divided by the overlap count (FusionFeedForward :82-95) and
+ * `act` is applied (GELU for the FFN, since unfold(gelu(x)) == gelu(unfold(x)) under zero padding). */
+int pp_fold_tokens(const void* tokens, void* out, int BT, int fh, int fw, int C, int H, int W, int normalize,
+                   int act, int dtype, void* stream);
+
+/* LayerNorm over the last dim (C multiple of 64, <= 1024): in/out [rows, C]. */
+int pp_layernorm(const void* in, const float* gamma, const float* beta, void* out, int64_t rows, int C, float eps,
+                 int dtype, void* stream);
+
+/* depthwise kxk stride-k conv ("pool_layer", sparse_transformer.py:136,209): in NHWC [N,H,W,C] -> [N,H/k,W/k,C];
+ * weight fp32 [C,k,k], bias fp32 [C]. */
+int pp_depthwise_pool(const void* in, const float* weight, const float* bias, void* out, int N, int H, int W, int C,
+                      int k, int dtype, void* stream);
+
+/* InstanceNorm2d (no affine, eps) over NHWC [N,H,W,C] + optional ReLU; stats fp32 workspace [N*C*2]. */
+int pp_instance_norm(const void* in, void* out, float* stats_ws, int N, int H, int W, int C, float eps, int relu,
+                     int dtype, void* stream);
+
+/* bilinear x2 upsampling, align_corners=True, NHWC [N,H,W,C] -> [N,2H,2W,C] (deconv blocks). */
+int pp_upsample2x(const void* in, void* out, int N, int H, int W, int C, int dtype, void* stream);
+
+/* offset/mask head activation of the deformable alignment (model/propainter.py:58-65,
+ * model/recurrent_flow_completion.py:32-40): in place on NHWC [N,H,W,432]: channels [0,288) ->
+ * mag*tanh(v) (+ flow_y on even / flow_x on odd channels when flow != NULL), [288,432) -> sigmoid. */
+int pp_dcn_offset_mask_act(void* offmask, int cstride, const void* flow, int fl_cstride, int fl_choff, float mag,
+                           int64_t npix, int dtype, void* stream);
+
+/* SepConvGRU gating (RAFT/update.py:45-60):  mode 0: out = r*h where r = zr[:, C:2C] (already sigmoid-ed);
+ * mode 1: out = (1-z)*h + z*q where z = zr[:, 0:C].  All NHWC with explicit cstride/choff. */
+int pp_gru_gate(const void* zr, int zr_cstride, const void* h, int h_cstride, int h_choff, const void* q,
+                int q_cstride, void* out, int out_cstride, int out_choff, int64_t npix, int C, int mode, int dtype,
+                void* stream);
+
+/* layout packers: planar NCHW [N,C,H,W] (src dtype) <-> NHWC channel window (dst dtype). */
+int pp_nchw_to_nhwc(const void* in, int in_dtype, void* out, int out_dtype, int out_cstride, int out_choff, int N,
+                    int C, int H, int W, float scale, void* stream);
+int pp_nhwc_to_nchw(const void* in, int in_dtype, int in_cstride, int in_choff, void* out, int out_dtype, int N,
+                    int C, int H, int W, int act, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PROPAINTER_HIP_H */

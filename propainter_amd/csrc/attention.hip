@@ -1,0 +1,352 @@
+// Sparse window attention for gfx950 (model/modules/sparse_transformer.py:158-281).
+//
+// Key set of a *masked* window (any local frame has a hole inside it), per key frame f in T_ind:
+//   45 own-window tokens | 148 rolled-neighbour tokens (circular, index table) | P pooled tokens
+// -> one softmax over n_tind * (193 + P) keys for all T*45 queries of the window.  *Unmasked* windows
+// do plain 45x45 self attention per frame.  The reference materialises the rolled / pooled K,V per
+// window (1.6 GB each at 720p); here K/V rows are gathered on the fly from the q/k/v token grids through
+// the index tables, flash-style (online softmax), and the masked/unmasked decision is read from a device
+// flag so there is no host synchronisation (the reference's nonzero()).
+//
+// attn_mfma_kernel (fp16): 256 threads = 4 waves x 16 queries, 64-key tiles.
+//   S^T = K Q^T   (v_mfma_f32_16x16x32_f16: A = K rows from LDS, B = Q fragments held in registers)
+//   -> every lane owns 16 scores of ONE query, so the row max/sum need only two cross-lane shuffles;
+//   O^T += V^T P^T  with P^T taken directly from the score accumulators (keys of a 32-key step are
+//   relabelled so that no data movement is needed) and V staged transposed in LDS.
+// attn_ref_kernel (any dtype): one wave per query, fp32 math; the parity path for fp32 and the
+//   on-device cross-check of the MFMA kernel.
+#include "common.h"
+
+namespace pp {
+
+struct AttnParams {
+  int B, T, Hp, Wp, C, heads, wsz, n_rolled, P, n_tind, nW;
+  const char* q; const char* k; const char* v;
+  int qkv_cs;
+  const char* pk; const char* pv;
+  int pkv_cs;
+  const int* own; const int* rolled; const int* tind;
+  const float* wmask;
+  char* out;
+};
+
+constexpr int HD = 128;  // head dim
+
+// pointer to the 128-wide head slice of key `r` (0..192 grid tokens, >= 193 pooled) of frame f
+template <typename T>
+__device__ __forceinline__ const T* key_row(const AttnParams& p, const T* grid, const T* pooled, int b, int f, int r,
+                                            const int* idx_lds, int head) {
+  const int ngrid = p.wsz + p.n_rolled;
+  if (r < ngrid)
+    return grid + (((long long)b * p.T + f) * p.Hp * p.Wp + idx_lds[r]) * p.qkv_cs + head * HD;
+  return pooled + (((long long)b * p.T + f) * p.P + (r - ngrid)) * p.pkv_cs + head * HD;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_ref_kernel(const AttnParams p) {
+  __shared__ int idx_lds[256];
+  const int head = blockIdx.x % p.heads;
+  const int w = (blockIdx.x / p.heads) % p.nW;
+  const int b = blockIdx.x / (p.heads * p.nW);
+  const int ngrid = p.wsz + p.n_rolled;
+  for (int i = threadIdx.x; i < ngrid; i += 256) idx_lds[i] = i < p.wsz ? p.own[w * p.wsz + i] : p.rolled[w * p.n_rolled + i - p.wsz];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int qi = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (qi >= p.T * p.wsz) return;
+  const bool masked = p.wmask[b * p.nW + w] > 0.f;
+  const int fq = qi / p.wsz, tok = qi % p.wsz;
+  const T* qg = reinterpret_cast<const T*>(p.q);
+  const T* kg = reinterpret_cast<const T*>(p.k);
+  const T* vg = reinterpret_cast<const T*>(p.v);
+  const T* pkg = reinterpret_cast<const T*>(p.pk);
+  const T* pvg = reinterpret_cast<const T*>(p.pv);
+  const long long qoff = (((long long)b * p.T + fq) * p.Hp * p.Wp + idx_lds[tok]);
+  const T* qp = qg + qoff * p.qkv_cs + head * HD;
+  const float q0 = to_f32(qp[lane]), q1 = to_f32(qp[lane + 64]);
+  const float scale = rsqrtf((float)HD);
+  const int kpf = masked ? ngrid + p.P : p.wsz;
+  const int nkeys = masked ? p.n_tind * kpf : p.wsz;
+  float m = -1e30f, l = 0.f, a0 = 0.f, a1 = 0.f;
+  for (int kk = 0; kk < nkeys; ++kk) {
+    const int f = masked ? p.tind[kk / kpf] : fq;
+    const int r = kk % kpf;
+    const T* kp = key_row<T>(p, kg, pkg, b, f, r, idx_lds, head);
+    const T* vp = key_row<T>(p, vg, pvg, b, f, r, idx_lds, head);
+    float s = q0 * to_f32(kp[lane]) + q1 * to_f32(kp[lane + 64]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    s *= scale;
+    const float mn = fmaxf(m, s);
+    const float alpha = __expf(m - mn), pe = __expf(s - mn);
+    l = l * alpha + pe;
+    a0 = a0 * alpha + pe * to_f32(vp[lane]);
+    a1 = a1 * alpha + pe * to_f32(vp[lane + 64]);
+    m = mn;
+  }
+  T* op = reinterpret_cast<T*>(p.out) + qoff * p.C + head * HD;
+  op[lane] = from_f32<T>(a0 / l);
+  op[lane + 64] = from_f32<T>(a1 / l);
+}
+
+constexpr int KT = 64;          // keys per tile
+constexpr int KS_LD = HD + 8;   // K tile row stride (elements)
+constexpr int VT_LD = KT + 8;   // V^T tile row stride (elements)
+
+__global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnParams p) {
+  typedef _Float16 T;
+  __shared__ __attribute__((aligned(16))) T Ks[KT * KS_LD];
+  __shared__ __attribute__((aligned(16))) T Vt[HD * VT_LD];
+  __shared__ int idx_lds[256];
+  const int head = blockIdx.x % p.heads;
+  const int w = (blockIdx.x / p.heads) % p.nW;
+  const int b = blockIdx.x / (p.heads * p.nW);
+  const bool masked = p.wmask[b * p.nW + w] > 0.f;
+  const int nq_total = p.T * p.wsz;
+  if (masked && (int)blockIdx.y * 64 >= nq_total) return;     // masked windows need ceil(T*45/64) tiles only
+  const int ngrid = p.wsz + p.n_rolled;
+  for (int i = threadIdx.x; i < ngrid; i += 256) idx_lds[i] = i < p.wsz ? p.own[w * p.wsz + i] : p.rolled[w * p.n_rolled + i - p.wsz];
+  __syncthreads();
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const T* qg = reinterpret_cast<const T*>(p.q);
+  const T* kg = reinterpret_cast<const T*>(p.k);
+  const T* vg = reinterpret_cast<const T*>(p.v);
+  const T* pkg = reinterpret_cast<const T*>(p.pk);
+  const T* pvg = reinterpret_cast<const T*>(p.pv);
+
+  // ---- this lane's query (column lane&15 of the wave's 16-query tile)
+  const int ql = wave * 16 + (lane & 15);
+  int fq, tok;
+  bool qvalid;
+  if (masked) {
+    const int qi = blockIdx.y * 64 + ql;
+    qvalid = qi < nq_total;
+    fq = qvalid ? qi / p.wsz : 0;
+    tok = qvalid ? qi % p.wsz : 0;
+  } else {
+    qvalid = ql < p.wsz;
+    fq = blockIdx.y;
+    tok = qvalid ? ql : 0;
+  }
+  const long long qoff = ((long long)b * p.T + fq) * p.Hp * p.Wp + idx_lds[tok];
+  f16x8 qf[4];
+  {
+    const T* qp = qg + qoff * p.qkv_cs + head * HD + (lane >> 4) * 8;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (qvalid) qf[s] = *reinterpret_cast<const f16x8*>(qp + s * 32);
+      else qf[s] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  }
+  const int kpf = masked ? ngrid + p.P : p.wsz;
+  const int nkeys = masked ? p.n_tind * kpf : p.wsz;
+  const float scale = rsqrtf((float)HD);
+
+  f32x4 oacc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) oacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -1e30f, l_run = 0.f;
+
+  const int frame_blk = blockIdx.y;   // key frame of an unmasked window's block
+  for (int k0 = 0; k0 < nkeys; k0 += KT) {
+    // ---- stage K (row-major) and V (transposed) tiles: 64 keys x 16 chunks of 8 channels.
+    // 16 consecutive lanes read one 256-byte key row (coalesced); zero-fill past the key list.
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 256 * i;
+      const int key = c >> 4, dch = c & 15;
+      const int kk = k0 + key;
+      u32x4 kr = u32x4{0, 0, 0, 0}, vr = u32x4{0, 0, 0, 0};
+      if (kk < nkeys) {
+        const int f = masked ? p.tind[kk / kpf] : frame_blk;
+        const int r = kk % kpf;
+        kr = *reinterpret_cast<const u32x4*>(key_row<T>(p, kg, pkg, b, f, r, idx_lds, head) + dch * 8);
+        vr = *reinterpret_cast<const u32x4*>(key_row<T>(p, vg, pvg, b, f, r, idx_lds, head) + dch * 8);
+      }
+      *reinterpret_cast<u32x4*>(&Ks[key * KS_LD + dch * 8]) = kr;
+      const T* ve = reinterpret_cast<const T*>(&vr);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) Vt[(dch * 8 + j) * VT_LD + key] = ve[j];
+    }
+    __syncthreads();
+
+    // ---- S^T tiles: sacc[kt][r] = score(key = k0 + kt*16 + (lane>>4)*4 + r, query = lane&15)
+    f32x4 sacc[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      sacc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const T* kp = &Ks[(kt * 16 + (lane & 15)) * KS_LD + (lane >> 4) * 8];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const f16x8 kf = *reinterpret_cast<const f16x8*>(kp + s * 32);
+        sacc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[s], sacc[kt], 0, 0, 0);
+      }
+    }
+    // ---- online softmax for this lane's query
+    float tmax = -1e30f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kk = k0 + kt * 16 + (lane >> 4) * 4 + r;
+        const float s = kk < nkeys ? sacc[kt][r] * scale : -1e30f;
+        sacc[kt][r] = s;
+        tmax = fmaxf(tmax, s);
+      }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float m_new = fmaxf(m_run, tmax);
+    const float alpha = __expf(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+    f16x8 pf[2];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __expf(sacc[kt][r] - m_new);
+        psum += e;
+        pf[kt >> 1][(kt & 1) * 4 + r] = (_Float16)e;
+      }
+    l_run = l_run * alpha + psum;     // per-lane partial; the 4 lane groups are summed at the end
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) oacc[dt][r] *= alpha;
+    }
+    // ---- O^T += V^T P^T : k-slot (lane>>4)*8 + i of step j <-> key 32j + (i>>2)*16 + (lane>>4)*4 + (i&3)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) {
+        const T* vp = &Vt[(dt * 16 + (lane & 15)) * VT_LD + 32 * j + (lane >> 4) * 4];
+        const f16x4 lo = *reinterpret_cast<const f16x4*>(vp);
+        const f16x4 hi = *reinterpret_cast<const f16x4*>(vp + 16);
+        const f16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[j], oacc[dt], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  l_run += __shfl_xor(l_run, 16);
+  l_run += __shfl_xor(l_run, 32);
+  if (qvalid) {
+    const float inv = 1.f / l_run;
+    T* op = reinterpret_cast<T*>(p.out) + qoff * p.C + head * HD + (lane >> 4) * 4;
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) {
+      const f16x4 o = {(_Float16)(oacc[dt][0] * inv), (_Float16)(oacc[dt][1] * inv), (_Float16)(oacc[dt][2] * inv),
+                       (_Float16)(oacc[dt][3] * inv)};
+      *reinterpret_cast<f16x4*>(op + dt * 16) = o;
+    }
+  }
+}
+
+// wmask[b, w] = sum_lt max_{window} mask   (one thread per (b, w))
+template <typename T>
+__global__ void window_mask_kernel(const T* __restrict__ mask, float* __restrict__ wmask, int B, int Lt, int Hp, int Wp, int wh,
+                                   int ww) {
+  const int nww = Wp / ww, nW = (Hp / wh) * nww;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * nW) return;
+  const int b = i / nW, w = i % nW;
+  const int y0 = (w / nww) * wh, x0 = (w % nww) * ww;
+  float s = 0.f;
+  for (int t = 0; t < Lt; ++t) {
+    float mx = -INFINITY;
+    for (int y = 0; y < wh; ++y)
+      for (int x = 0; x < ww; ++x) mx = fmaxf(mx, to_f32(mask[(((long long)b * Lt + t) * Hp + y0 + y) * Wp + x0 + x]));
+    s += mx;
+  }
+  wmask[i] = s;
+}
+
+}  // namespace pp
+
+using namespace pp;
+
+extern "C" int pp_window_tables(int Hp, int Wp, int wh, int ww, int32_t* own, int32_t* rolled, int capacity_rolled) {
+  PP_REQUIRE(Hp > 0 && Wp > 0 && wh > 0 && ww > 0 && Hp % wh == 0 && Wp % ww == 0, PP_ERR_ARG,
+             "pp_window_tables: grid %dx%d is not a multiple of the %dx%d window", Hp, Wp, wh, ww);
+  const int eh = (wh + 1) / 2, ew = (ww + 1) / 2;
+  // kept positions of the four rolled copies (sparse_transformer.py:144-153)
+  int n_rolled = 0;
+  for (int k = 0; k < 4; ++k)
+    for (int i = 0; i < wh; ++i)
+      for (int j = 0; j < ww; ++j) {
+        const bool zr = (k < 2) ? (i < wh - eh) : (i >= eh);
+        const bool zc = (k % 2 == 0) ? (j < ww - ew) : (j >= ew);
+        if (!(zr && zc)) ++n_rolled;
+      }
+  if (own == nullptr || rolled == nullptr) return n_rolled;
+  const int nwh = Hp / wh, nww = Wp / ww;
+  PP_REQUIRE(capacity_rolled >= nwh * nww * n_rolled, PP_ERR_WORKSPACE, "pp_window_tables: rolled capacity %d < %d", capacity_rolled,
+             nwh * nww * n_rolled);
+  for (int wy = 0; wy < nwh; ++wy)
+    for (int wx = 0; wx < nww; ++wx) {
+      const int w = wy * nww + wx;
+      int n = 0;
+      for (int i = 0; i < wh; ++i)
+        for (int j = 0; j < ww; ++j) own[w * wh * ww + i * ww + j] = (wy * wh + i) * Wp + wx * ww + j;
+      for (int k = 0; k < 4; ++k) {
+        // torch.roll(x, shift)[i] = x[(i - shift) mod n]; shifts: tl (-eh,-ew) tr (-eh,+ew) bl (+eh,-ew) br (+eh,+ew)
+        const int sh = (k < 2) ? -eh : eh, sw = (k % 2 == 0) ? -ew : ew;
+        for (int i = 0; i < wh; ++i)
+          for (int j = 0; j < ww; ++j) {
+            const bool zr = (k < 2) ? (i < wh - eh) : (i >= eh);
+            const bool zc = (k % 2 == 0) ? (j < ww - ew) : (j >= ew);
+            if (zr && zc) continue;
+            const int y = ((wy * wh + i - sh) % Hp + Hp) % Hp, x = ((wx * ww + j - sw) % Wp + Wp) % Wp;
+            rolled[w * n_rolled + n++] = y * Wp + x;
+          }
+      }
+    }
+  return n_rolled;
+}
+
+extern "C" int pp_window_mask(const void* mask, float* wmask, int B, int Lt, int Hp, int Wp, int wh, int ww, int dtype,
+                              void* stream) {
+  PP_REQUIRE(mask && wmask && B > 0 && Lt > 0 && Hp % wh == 0 && Wp % ww == 0, PP_ERR_ARG, "pp_window_mask: bad arguments");
+  PP_REQUIRE(dtype == PP_F32 || dtype == PP_F16, PP_ERR_DTYPE, "pp_window_mask: dtype %d", dtype);
+  const int n = B * (Hp / wh) * (Wp / ww);
+  if (dtype == PP_F16)
+    hipLaunchKernelGGL((window_mask_kernel<_Float16>), dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const _Float16*)mask, wmask, B, Lt, Hp, Wp, wh, ww);
+  else
+    hipLaunchKernelGGL((window_mask_kernel<float>), dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)mask,
+                       wmask, B, Lt, Hp, Wp, wh, ww);
+  return launch_status("pp_window_mask");
+}
+
+extern "C" int pp_sparse_window_attention(const pp_attn_args_t* a, void* stream) {
+  PP_REQUIRE(a != nullptr, PP_ERR_ARG, "pp_sparse_window_attention: null args");
+  PP_REQUIRE(a->dtype == PP_F32 || a->dtype == PP_F16, PP_ERR_DTYPE, "pp_sparse_window_attention: dtype %d", a->dtype);
+  PP_REQUIRE(a->B > 0 && a->T > 0 && a->heads > 0 && a->C == a->heads * HD, PP_ERR_ARG,
+             "pp_sparse_window_attention: C=%d heads=%d (head dim must be %d)", a->C, a->heads, HD);
+  PP_REQUIRE(a->Hp % a->wh == 0 && a->Wp % a->ww == 0, PP_ERR_ARG, "pp_sparse_window_attention: grid not padded to the window");
+  PP_REQUIRE(a->wh * a->ww + a->n_rolled <= 256 && a->wh * a->ww <= 64, PP_ERR_ARG, "pp_sparse_window_attention: window too large");
+  PP_REQUIRE(a->q && a->k && a->v && a->own && a->rolled && a->tind && a->wmask && a->out && (a->P == 0 || (a->pk && a->pv)),
+             PP_ERR_ARG, "pp_sparse_window_attention: null pointer");
+  PP_REQUIRE(a->n_tind > 0 && a->n_tind <= a->T, PP_ERR_ARG, "pp_sparse_window_attention: n_tind %d", a->n_tind);
+  const int esz = a->dtype == PP_F16 ? 2 : 4;
+  PP_REQUIRE((a->qkv_cstride * esz) % 16 == 0 && (a->pkv_cstride * esz) % 16 == 0 && (uintptr_t)a->q % 16 == 0 &&
+                 (uintptr_t)a->k % 16 == 0 && (uintptr_t)a->v % 16 == 0 && (uintptr_t)a->out % 16 == 0,
+             PP_ERR_ALIGN, "pp_sparse_window_attention: 16-byte alignment violated");
+  AttnParams p;
+  p.B = a->B; p.T = a->T; p.Hp = a->Hp; p.Wp = a->Wp; p.C = a->C; p.heads = a->heads; p.wsz = a->wh * a->ww;
+  p.n_rolled = a->n_rolled; p.P = a->P; p.n_tind = a->n_tind; p.nW = (a->Hp / a->wh) * (a->Wp / a->ww);
+  p.q = (const char*)a->q; p.k = (const char*)a->k; p.v = (const char*)a->v; p.qkv_cs = a->qkv_cstride;
+  p.pk = (const char*)a->pk; p.pv = (const char*)a->pv; p.pkv_cs = a->pkv_cstride;
+  p.own = a->own; p.rolled = a->rolled; p.tind = a->tind; p.wmask = a->wmask; p.out = (char*)a->out;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned gx = (unsigned)(p.B * p.nW * p.heads);
+  if (a->dtype == PP_F16 && a->impl != 1) {
+    hipLaunchKernelGGL(attn_mfma_kernel, dim3(gx, (unsigned)p.T), dim3(256), 0, st, p);
+  } else {
+    const unsigned gy = (unsigned)((p.T * p.wsz + 3) / 4);
+    if (a->dtype == PP_F16) hipLaunchKernelGGL((attn_ref_kernel<_Float16>), dim3(gx, gy), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((attn_ref_kernel<float>), dim3(gx, gy), dim3(256), 0, st, p);
+  }
+  return launch_status("pp_sparse_window_attention");
+}

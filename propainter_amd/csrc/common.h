@@ -1,0 +1,102 @@
+// Shared helpers for the gfx950 kernels of libpropainter_hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <math.h>
+
+#include "../../include/propainter_hip.h"
+
+namespace pp {
+
+void set_error(const char* fmt, ...);
+
+// Checks the launch and turns a hipError_t into the C-ABI return convention.
+inline int launch_status(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+
+#define PP_REQUIRE(cond, code, ...) \
+  do {                              \
+    if (!(cond)) {                  \
+      pp::set_error(__VA_ARGS__);   \
+      return (code);                \
+    }                               \
+  } while (0)
+
+// 16-byte vector of raw bits used for all wide global/LDS moves.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <typename T> struct dtype_of;
+template <> struct dtype_of<float> { static constexpr int code = PP_F32; };
+template <> struct dtype_of<_Float16> { static constexpr int code = PP_F16; };
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(_Float16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ _Float16 from_f32<_Float16>(float v) { return (_Float16)v; }
+
+__device__ __forceinline__ float apply_act(float v, int act, float param) {
+  switch (act) {
+    case PP_ACT_RELU: return v > 0.f ? v : 0.f;
+    case PP_ACT_LRELU: return v > 0.f ? v : v * param;
+    case PP_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+    case PP_ACT_TANH: return tanhf(v);
+    case PP_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+    default: return v;
+  }
+}
+
+// Loads `n` (<= 8) consecutive elements as fp32.
+template <typename T> __device__ __forceinline__ void load8(const T* p, float* v) {
+  if constexpr (sizeof(T) == 2) {
+    u32x4 raw = *reinterpret_cast<const u32x4*>(p);
+    const _Float16* h = reinterpret_cast<const _Float16*>(&raw);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)h[i];
+  } else {
+    f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+  }
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float* v) {
+  if constexpr (sizeof(T) == 2) {
+    u32x4 raw;
+    _Float16* h = reinterpret_cast<_Float16*>(&raw);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h[i] = (_Float16)v[i];
+    *reinterpret_cast<u32x4*>(p) = raw;
+  } else {
+    f32x4 a, b;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = v[i]; b[i] = v[4 + i]; }
+    *reinterpret_cast<f32x4*>(p) = a;
+    *reinterpret_cast<f32x4*>(p + 4) = b;
+  }
+}
+
+// grid_sample(align_corners=True) coordinate round trip exactly as torch computes it in fp32:
+// g = 2*c/(size-1) - 1 ; c' = ((g + 1) / 2) * (size - 1).   Keeps 'nearest' ties identical.
+__device__ __forceinline__ float grid_roundtrip(float c, int size) {
+  float d = (float)(size > 1 ? size - 1 : 1);
+  float g = 2.0f * c / d - 1.0f;
+  return ((g + 1.0f) * 0.5f) * (float)(size - 1);
+}
+
+inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+}  // namespace pp

@@ -1,0 +1,429 @@
+// Implicit-GEMM convolution on MFMA for gfx950 (wave64).  One kernel family serves every Conv2d /
+// Conv3d(1,k,k) / temporal Conv3d(3,1,1) / Linear / batched GEMM / modulated deformable conv on the
+// ProPainter path (see include/propainter_hip.h, pp_conv2d).
+//
+// GEMM view per group:  D[co][px] = sum_k Wp[co][k] * A[px][k],  px = output pixel, k = (tap, source,
+// channel).  A is never materialised: each 16-byte K-chunk (8 channels) of an A row is gathered straight
+// from the NHWC sources using a tiny device table {dy, dx, src, choff}; zero / replicate padding and the
+// bilinear+modulation of the deformable conv happen on the way into LDS.
+//
+// Tiling: 256 threads = 4 waves; block tile BM pixels x BN couts x 32 k; register-prefetched global
+// loads (issue tile t+1, compute tile t from LDS, then write t+1 into the other LDS buffer -> one
+// barrier per k-step).  Weights are the MFMA "A" operand and pixels the "B" operand, so each lane ends
+// up with 4 consecutive output channels of one pixel -> 8/16-byte NHWC stores.
+//   fp16: v_mfma_f32_16x16x32_f16 (8 k per lane);  fp32: v_mfma_f32_16x16x4_f32 (exact fp32).
+// LDS rows are padded by 16 bytes (stride 80 B fp16 / 144 B fp32) to spread the ds_read_b128 lanes.
+#include "common.h"
+
+namespace pp {
+
+struct ConvSrc {
+  const char* ptr;
+  int cstride, choff, cgroup;
+};
+
+struct ConvParams {
+  int N, H, W, OH, OW, sh, sw, ph, pw, pad_mode;
+  int cout_g, cout_pad, kchunks, nsrc;
+  ConvSrc src[PP_CONV_MAX_SRC];
+  const int4* ktable;
+  const char* weight;
+  long long weight_gstride;
+  const float* bias;
+  int act;
+  float act_param, out_scale;
+  const char* residual;
+  int res_cstride, res_choff, act2, out_f16;
+  char* out;
+  int out_cstride, out_choff, out_cgroup;
+  long long src_gstride, out_gstride;
+  const char* dcn;
+  int dcn_cstride, dcn_mask_off;
+  long long M;
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<_Float16> {
+  static constexpr int LDK = 40;  // 32 + 8 pad elements
+};
+template <> struct Mma<float> {
+  static constexpr int LDK = 36;  // 32 + 4 pad elements
+};
+
+// 8 consecutive elements of T as raw registers.
+template <typename T> struct Chunk;
+template <> struct Chunk<_Float16> { u32x4 v; };
+template <> struct Chunk<float> { u32x4 v[2]; };
+
+template <typename T> __device__ __forceinline__ Chunk<T> zero_chunk() {
+  Chunk<T> c;
+  if constexpr (sizeof(T) == 2) c.v = u32x4{0, 0, 0, 0};
+  else { c.v[0] = u32x4{0, 0, 0, 0}; c.v[1] = u32x4{0, 0, 0, 0}; }
+  return c;
+}
+template <typename T> __device__ __forceinline__ Chunk<T> load_chunk(const T* p) {
+  Chunk<T> c;
+  if constexpr (sizeof(T) == 2) c.v = *reinterpret_cast<const u32x4*>(p);
+  else { c.v[0] = *reinterpret_cast<const u32x4*>(p); c.v[1] = *reinterpret_cast<const u32x4*>(p + 4); }
+  return c;
+}
+template <typename T> __device__ __forceinline__ void store_chunk(T* p, const Chunk<T>& c) {
+  if constexpr (sizeof(T) == 2) *reinterpret_cast<u32x4*>(p) = c.v;
+  else { *reinterpret_cast<u32x4*>(p) = c.v[0]; *reinterpret_cast<u32x4*>(p + 4) = c.v[1]; }
+}
+template <typename T> __device__ __forceinline__ void chunk_to_f32(const Chunk<T>& c, float* f) {
+  const T* e = reinterpret_cast<const T*>(&c);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f[i] = to_f32(e[i]);
+}
+template <typename T> __device__ __forceinline__ Chunk<T> chunk_from_f32(const float* f) {
+  Chunk<T> c;
+  T* e = reinterpret_cast<T*>(&c);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) e[i] = from_f32<T>(f[i]);
+  return c;
+}
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool DEFORM>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
+  constexpr int LDK = Mma<T>::LDK;
+  constexpr int A_ROWS = BM / 64;                 // A rows gathered per thread (4 chunks per row)
+  constexpr int B_ROWS = (BN + 63) / 64;          // weight rows per thread
+  constexpr int WPX = BM / WAVES_M;               // pixels per wave
+  constexpr int WCO = BN / WAVES_N;               // couts per wave
+  constexpr int TM = WPX / 16, TN = WCO / 16;
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  static_assert(TM >= 1 && TN >= 1, "tile");
+
+  __shared__ __attribute__((aligned(16))) T lds[2 * (BM + BN) * LDK];
+  constexpr int STAGE = (BM + BN) * LDK;   // A tile followed by the weight tile, two stages
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int g = blockIdx.z;
+  const long long m0 = (long long)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+
+  // ---- per-thread gather state: A rows (tid>>2) + 64*i, chunk (tid&3) of every 32-wide k step
+  const int chunk = tid & 3;
+  const int arow0 = tid >> 2;
+  int a_iy0[A_ROWS], a_ix0[A_ROWS];
+  long long a_pix[A_ROWS];   // n*H*W, or -1 when the row is past M
+  long long a_m[A_ROWS];
+#pragma unroll
+  for (int i = 0; i < A_ROWS; ++i) {
+    long long m = m0 + arow0 + 64 * i;
+    a_m[i] = m;
+    if (m < p.M) {
+      int ox = (int)(m % p.OW);
+      long long r = m / p.OW;
+      int oy = (int)(r % p.OH);
+      long long n = r / p.OH;
+      a_iy0[i] = oy * p.sh - p.ph;
+      a_ix0[i] = ox * p.sw - p.pw;
+      a_pix[i] = n * (long long)p.H * p.W;
+    } else {
+      a_iy0[i] = 0; a_ix0[i] = 0; a_pix[i] = -1;
+    }
+  }
+  const T* wbase = reinterpret_cast<const T*>(p.weight) + (long long)g * p.weight_gstride;
+  const long long K = (long long)p.kchunks * 8;
+
+  Chunk<T> a_reg[A_ROWS][DEFORM ? 4 : 1];
+  float a_w[A_ROWS][DEFORM ? 4 : 1];   // deform: corner weights (already times modulation mask)
+  Chunk<T> b_reg[B_ROWS];
+
+  auto src_ptr = [&](int s, int& cstride, int& cbase) -> const T* {
+    const ConvSrc& S = p.src[s];   // s is wave-divergent only across the 4 chunks; select chain keeps SGPRs
+    cstride = S.cstride;
+    cbase = S.choff + g * S.cgroup;
+    return reinterpret_cast<const T*>(S.ptr) + (long long)g * p.src_gstride;
+  };
+
+  auto issue_loads = [&](int ks) {
+    const int4 e = p.ktable[ks * 4 + chunk];
+    const int s = e.z & 0xff;
+    int cstride = 0, cbase = 0;
+    const T* sp = nullptr;
+    if (s != 255) {
+      // explicit select over the (<= 4) sources
+      if (s == 0) sp = src_ptr(0, cstride, cbase);
+      else if (s == 1) sp = src_ptr(1, cstride, cbase);
+      else if (s == 2) sp = src_ptr(2, cstride, cbase);
+      else sp = src_ptr(3, cstride, cbase);
+    }
+#pragma unroll
+    for (int i = 0; i < A_ROWS; ++i) {
+      if constexpr (!DEFORM) {
+        a_reg[i][0] = zero_chunk<T>();
+        if (sp != nullptr && a_pix[i] >= 0) {
+          int iy = a_iy0[i] + e.x, ix = a_ix0[i] + e.y;
+          bool ok = true;
+          if (p.pad_mode == 1) {
+            iy = min(max(iy, 0), p.H - 1);
+            ix = min(max(ix, 0), p.W - 1);
+          } else {
+            ok = (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.W);
+          }
+          if (ok) a_reg[i][0] = load_chunk<T>(sp + (a_pix[i] + (long long)iy * p.W + ix) * cstride + cbase + e.w);
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { a_reg[i][c] = zero_chunk<T>(); a_w[i][c] = 0.f; }
+        if (sp != nullptr && a_pix[i] >= 0) {
+          const int grp = (e.z >> 8) & 0xff, tap = (e.z >> 16) & 0xff;
+          // stride-1 deformable conv: the offset/mask pixel is the output pixel itself
+          const T* om = reinterpret_cast<const T*>(p.dcn) + a_m[i] * p.dcn_cstride;
+          const float dyv = to_f32(om[2 * (grp * 9 + tap)]);
+          const float dxv = to_f32(om[2 * (grp * 9 + tap) + 1]);
+          const float mk = to_f32(om[p.dcn_mask_off + grp * 9 + tap]);
+          const float py = (float)(a_iy0[i] + e.x) + dyv;
+          const float px = (float)(a_ix0[i] + e.y) + dxv;
+          if (py > -1.f && py < (float)p.H && px > -1.f && px < (float)p.W) {
+            const float fy = floorf(py), fx = floorf(px);
+            const int y0 = (int)fy, x0 = (int)fx;
+            const float ly = py - fy, lx = px - fx;
+            const float wy[2] = {1.f - ly, ly}, wx[2] = {1.f - lx, lx};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const int yy = y0 + (c >> 1), xx = x0 + (c & 1);
+              if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) {
+                a_reg[i][c] = load_chunk<T>(sp + (a_pix[i] + (long long)yy * p.W + xx) * cstride + cbase + e.w);
+                a_w[i][c] = wy[c >> 1] * wx[c & 1] * mk;
+              }
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_ROWS; ++i) {
+      const int row = arow0 + 64 * i;
+      b_reg[i] = zero_chunk<T>();
+      if (row < BN && n0 + row < p.cout_pad)
+        b_reg[i] = load_chunk<T>(wbase + (long long)(n0 + row) * K + (long long)ks * 32 + chunk * 8);
+    }
+  };
+
+  auto commit_lds = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_ROWS; ++i) {
+      T* dst = lds + buf * STAGE + (arow0 + 64 * i) * LDK + chunk * 8;
+      if constexpr (!DEFORM) {
+        store_chunk<T>(dst, a_reg[i][0]);
+      } else {
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, f[8];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          chunk_to_f32<T>(a_reg[i][c], f);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] += a_w[i][c] * f[j];
+        }
+        store_chunk<T>(dst, chunk_from_f32<T>(acc));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_ROWS; ++i) {
+      const int row = arow0 + 64 * i;
+      if (row < BN) store_chunk<T>(lds + buf * STAGE + (BM + row) * LDK + chunk * 8, b_reg[i]);
+    }
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.kchunks / 4;
+  issue_loads(0);
+  commit_lds(0);
+  __syncthreads();
+  for (int ks = 0; ks < nk; ++ks) {
+    const int buf = ks & 1;
+    if (ks + 1 < nk) issue_loads(ks + 1);
+    const T* Ab = lds + buf * STAGE + (wm * WPX + (lane & 15)) * LDK;
+    const T* Bb = lds + buf * STAGE + (BM + wn * WCO + (lane & 15)) * LDK;
+    if constexpr (sizeof(T) == 2) {
+      f16x8 af[TM], bf[TN];
+#pragma unroll
+      for (int t = 0; t < TM; ++t) af[t] = *reinterpret_cast<const f16x8*>(Ab + t * 16 * LDK + (lane >> 4) * 8);
+#pragma unroll
+      for (int t = 0; t < TN; ++t) bf[t] = *reinterpret_cast<const f16x8*>(Bb + t * 16 * LDK + (lane >> 4) * 8);
+#pragma unroll
+      for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[a], af[b], acc[a][b], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        float af[TM], bf[TN];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) af[t] = Ab[t * 16 * LDK + kk * 4 + (lane >> 4)];
+#pragma unroll
+        for (int t = 0; t < TN; ++t) bf[t] = Bb[t * 16 * LDK + kk * 4 + (lane >> 4)];
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+          for (int b = 0; b < TM; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[a], af[b], acc[a][b], 0, 0, 0);
+      }
+    }
+    if (ks + 1 < nk) commit_lds(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds couts (lane>>4)*4 + r (r = 0..3) of pixel (lane&15) of every 16x16 tile
+  const int out_cbase = p.out_choff + g * p.out_cgroup;
+  char* outp = p.out + (long long)g * p.out_gstride * (p.out_f16 ? 2 : 4);
+#pragma unroll
+  for (int b = 0; b < TM; ++b) {
+    const long long m = m0 + wm * WPX + b * 16 + (lane & 15);
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int a = 0; a < TN; ++a) {
+      const int co = n0 + wn * WCO + a * 16 + (lane >> 4) * 4;
+      if (co >= p.cout_g) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float x = acc[a][b][r] * p.out_scale;
+        if (p.bias != nullptr && co + r < p.cout_g) x += p.bias[g * p.cout_g + co + r];
+        v[r] = apply_act(x, p.act, p.act_param);
+      }
+      if (p.residual != nullptr) {
+        const T* rp = reinterpret_cast<const T*>(p.residual) + m * p.res_cstride + p.res_choff + g * p.out_cgroup + co;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (co + r < p.cout_g) v[r] += to_f32(rp[r]);
+      }
+      if (p.act2 == PP_ACT_RELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+      }
+      const long long oidx = m * p.out_cstride + out_cbase + co;
+      const bool full = (co + 3 < p.cout_g);
+      if (p.out_f16) {
+        _Float16* op = reinterpret_cast<_Float16*>(outp) + oidx;
+        if (full && ((oidx & 3) == 0)) {
+          f16x4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+          *reinterpret_cast<f16x4*>(op) = h;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (co + r < p.cout_g) op[r] = (_Float16)v[r];
+        }
+      } else {
+        float* op = reinterpret_cast<float*>(outp) + oidx;
+        if (full && ((oidx & 3) == 0)) {
+          *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (co + r < p.cout_g) op[r] = v[r];
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
+static int launch_conv(const ConvParams& p, int groups, bool deform, hipStream_t stream) {
+  dim3 grid((unsigned)((p.M + BM - 1) / BM), (unsigned)((p.cout_g + BN - 1) / BN), (unsigned)groups);
+  if (deform)
+    hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, WAVES_M, WAVES_N, true>), grid, dim3(256), 0, stream, p);
+  else
+    hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, WAVES_M, WAVES_N, false>), grid, dim3(256), 0, stream, p);
+  return launch_status("pp_conv2d");
+}
+
+template <typename T> static int dispatch_conv(const ConvParams& p, int groups, bool deform, hipStream_t stream) {
+  if (p.cout_g > 64) return launch_conv<T, 128, 128, 2, 2>(p, groups, deform, stream);
+  if (p.cout_g > 32) return launch_conv<T, 128, 64, 2, 2>(p, groups, deform, stream);
+  if (p.cout_g > 16) return launch_conv<T, 128, 32, 2, 2>(p, groups, deform, stream);
+  return launch_conv<T, 128, 16, 4, 1>(p, groups, deform, stream);
+}
+
+}  // namespace pp
+
+extern "C" int pp_conv_build_ktable(int ntaps, const int32_t* dy, const int32_t* dx, int nsrc,
+                                    const int32_t* src_channels, int dcn_groups, int32_t* out, int out_capacity) {
+  PP_REQUIRE(ntaps > 0 && nsrc > 0 && nsrc <= PP_CONV_MAX_SRC && dy && dx && src_channels, PP_ERR_ARG,
+             "pp_conv_build_ktable: bad arguments");
+  int ctotal = 0;
+  for (int s = 0; s < nsrc; ++s) {
+    PP_REQUIRE(src_channels[s] > 0 && src_channels[s] % 8 == 0, PP_ERR_ALIGN,
+               "pp_conv_build_ktable: source %d has %d channels (must be a positive multiple of 8)", s, src_channels[s]);
+    ctotal += src_channels[s];
+  }
+  PP_REQUIRE(dcn_groups == 0 || (ctotal % dcn_groups == 0 && (ctotal / dcn_groups) % 8 == 0), PP_ERR_ARG,
+             "pp_conv_build_ktable: %d channels do not split into %d offset groups of 8n", ctotal, dcn_groups);
+  const int chunks = ntaps * (ctotal / 8);
+  const int padded = (chunks + 3) / 4 * 4;
+  if (out == nullptr) return padded;
+  PP_REQUIRE(out_capacity >= padded, PP_ERR_WORKSPACE, "pp_conv_build_ktable: need %d entries, got %d", padded, out_capacity);
+  int k = 0;
+  for (int t = 0; t < ntaps; ++t) {
+    int cglobal = 0;
+    for (int s = 0; s < nsrc; ++s)
+      for (int c = 0; c < src_channels[s]; c += 8, cglobal += 8, ++k) {
+        int grp = dcn_groups ? cglobal / (ctotal / dcn_groups) : 0;
+        out[4 * k + 0] = dy[t];
+        out[4 * k + 1] = dx[t];
+        out[4 * k + 2] = s | (grp << 8) | (t << 16);
+        out[4 * k + 3] = c;
+      }
+  }
+  for (; k < padded; ++k) { out[4 * k] = 0; out[4 * k + 1] = 0; out[4 * k + 2] = 255; out[4 * k + 3] = 0; }
+  return padded;
+}
+
+extern "C" int pp_conv2d(const pp_conv_args_t* a, void* stream) {
+  using namespace pp;
+  PP_REQUIRE(a != nullptr, PP_ERR_ARG, "pp_conv2d: null args");
+  PP_REQUIRE(a->dtype == PP_F32 || a->dtype == PP_F16, PP_ERR_DTYPE, "pp_conv2d: dtype %d", a->dtype);
+  PP_REQUIRE(a->out_dtype == PP_F32 || a->out_dtype == PP_F16, PP_ERR_DTYPE, "pp_conv2d: out_dtype %d", a->out_dtype);
+  PP_REQUIRE(a->N > 0 && a->H > 0 && a->W > 0 && a->OH > 0 && a->OW > 0 && a->groups > 0 && a->cout_g > 0, PP_ERR_ARG,
+             "pp_conv2d: bad extents N=%d H=%d W=%d OH=%d OW=%d groups=%d cout_g=%d", a->N, a->H, a->W, a->OH, a->OW,
+             a->groups, a->cout_g);
+  PP_REQUIRE(a->nsrc >= 1 && a->nsrc <= PP_CONV_MAX_SRC, PP_ERR_ARG, "pp_conv2d: nsrc %d", a->nsrc);
+  PP_REQUIRE(a->kchunks > 0 && a->kchunks % 4 == 0, PP_ERR_ARG, "pp_conv2d: kchunks %d must be a positive multiple of 4", a->kchunks);
+  PP_REQUIRE(a->cout_pad >= a->cout_g && a->cout_pad % 16 == 0, PP_ERR_ARG, "pp_conv2d: cout_pad %d (cout_g %d)", a->cout_pad, a->cout_g);
+  PP_REQUIRE(a->ktable && a->weight && a->out, PP_ERR_ARG, "pp_conv2d: null ktable/weight/out");
+  const int esz = a->dtype == PP_F16 ? 2 : 4;
+  for (int s = 0; s < a->nsrc; ++s) {
+    PP_REQUIRE(a->src[s].ptr != nullptr, PP_ERR_ARG, "pp_conv2d: source %d is null", s);
+    PP_REQUIRE(((uintptr_t)a->src[s].ptr % 16) == 0 && (a->src[s].cstride * esz) % 16 == 0 && (a->src[s].choff * esz) % 16 == 0 &&
+                   (a->src[s].cgroup * esz) % 16 == 0,
+               PP_ERR_ALIGN, "pp_conv2d: source %d violates 16-byte alignment (cstride %d choff %d cgroup %d)", s,
+               a->src[s].cstride, a->src[s].choff, a->src[s].cgroup);
+  }
+  PP_REQUIRE(((uintptr_t)a->weight % 16) == 0, PP_ERR_ALIGN, "pp_conv2d: weight pointer not 16-byte aligned");
+  if (a->dcn_offmask) {
+    PP_REQUIRE(a->stride_h == 1 && a->stride_w == 1 && a->OH == a->H && a->OW == a->W, PP_ERR_ARG,
+               "pp_conv2d: deformable mode needs stride 1 and same-size output");
+  }
+  ConvParams p;
+  p.N = a->N; p.H = a->H; p.W = a->W; p.OH = a->OH; p.OW = a->OW;
+  p.sh = a->stride_h; p.sw = a->stride_w; p.ph = a->pad_h; p.pw = a->pad_w; p.pad_mode = a->pad_mode;
+  p.cout_g = a->cout_g; p.cout_pad = a->cout_pad; p.kchunks = a->kchunks; p.nsrc = a->nsrc;
+  for (int s = 0; s < PP_CONV_MAX_SRC; ++s) {
+    const int ss = s < a->nsrc ? s : 0;
+    p.src[s].ptr = (const char*)a->src[ss].ptr; p.src[s].cstride = a->src[ss].cstride;
+    p.src[s].choff = a->src[ss].choff; p.src[s].cgroup = a->src[ss].cgroup;
+  }
+  p.ktable = (const int4*)a->ktable; p.weight = (const char*)a->weight; p.weight_gstride = a->weight_gstride;
+  p.bias = a->bias; p.act = a->act; p.act_param = a->act_param; p.out_scale = a->out_scale;
+  p.residual = (const char*)a->residual; p.res_cstride = a->res_cstride; p.res_choff = a->res_choff; p.act2 = a->act2;
+  p.out_f16 = a->out_dtype == PP_F16; p.out = (char*)a->out; p.out_cstride = a->out_cstride; p.out_choff = a->out_choff;
+  p.out_cgroup = a->out_cgroup; p.src_gstride = a->src_gstride; p.out_gstride = a->out_gstride;
+  p.dcn = (const char*)a->dcn_offmask; p.dcn_cstride = a->dcn_cstride; p.dcn_mask_off = a->dcn_mask_off;
+  p.M = (long long)a->N * a->OH * a->OW;
+  const bool deform = a->dcn_offmask != nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  if (a->dtype == PP_F16) return dispatch_conv<_Float16>(p, a->groups, deform, st);
+  return dispatch_conv<float>(p, a->groups, deform, st);
+}

@@ -1,0 +1,155 @@
+// RAFT correlation pyramid pooling, 9x9x4 bilinear lookup and convex 8x upsampling for gfx950.
+// All three are HBM/latency-bound gathers; the all-pairs volume itself is a batched GEMM on pp_conv2d.
+#include "common.h"
+
+namespace pp {
+
+// out[m, y, x] = mean of the 2x2 block of in[m] (floor sizes, F.avg_pool2d(2, 2)); one thread per output.
+__global__ void corr_avgpool_kernel(const float* __restrict__ in, float* __restrict__ out, long long M, int H, int W) {
+  const int OH = H / 2, OW = W / 2;
+  const long long total = M * OH * OW;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % OW);
+    const int oy = (int)((i / OW) % OH);
+    const long long m = i / ((long long)OW * OH);
+    const float* s = in + (m * H + 2 * oy) * W + 2 * ox;
+    out[i] = (s[0] + s[1] + s[W] + s[W + 1]) * 0.25f;
+  }
+}
+
+// One 256-thread block per source pixel, one wave per pyramid level.  The wave stages the 10x10 patch
+// around (x/2^l, y/2^l) in LDS (zeros outside the map), then 81 lanes-outputs blend 4 neighbours with the
+// common fractional weights.  Output channel l*81 + a*9 + b <- sample (x + a - 4, y + b - 4).
+template <typename TO>
+__global__ __launch_bounds__(256) void corr_lookup_kernel(const float* __restrict__ l0, const float* __restrict__ l1,
+                                                          const float* __restrict__ l2, const float* __restrict__ l3,
+                                                          const float* __restrict__ coords, TO* __restrict__ out,
+                                                          int ocs, int ocpad, int h, int w) {
+  __shared__ float patch[4][10][11];
+  const long long pix = blockIdx.x;
+  const int lvl = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const float* base = lvl == 0 ? l0 : lvl == 1 ? l1 : lvl == 2 ? l2 : l3;
+  const int Hl = h >> lvl, Wl = w >> lvl;
+  const float* map = base + pix * (long long)Hl * Wl;
+  const float scale = 1.f / (float)(1 << lvl);
+  // bilinear_sampler normalises with 2c/(W-1)-1 and grid_sample maps back (RAFT/utils/utils.py:61-65)
+  const float cx = coords[pix * 2] * scale, cy = coords[pix * 2 + 1] * scale;
+  // all 81 taps share the fractional part when computed on the un-shifted centre; to stay faithful to
+  // the reference's per-tap round trip we evaluate the round trip per tap below, but stage the patch from
+  // the floor of the centre (taps are centre + integer, so floor(tap) = floor(centre) + integer up to
+  // 1-ulp effects that only move weight between two staged neighbours).
+  const int x0 = (int)floorf(cx) - 4, y0 = (int)floorf(cy) - 4;
+  for (int i = lane; i < 100; i += 64) {
+    const int r = i / 10, c = i % 10;
+    const int yy = y0 + r, xx = x0 + c;
+    patch[lvl][r][c] = (yy >= 0 && yy < Hl && xx >= 0 && xx < Wl) ? map[(long long)yy * Wl + xx] : 0.f;
+  }
+  __syncthreads();
+  TO* op = out + pix * ocs + lvl * 81;
+  for (int i = lane; i < 81; i += 64) {
+    const int a = i / 9, b = i % 9;           // a moves x, b moves y
+    const float px = grid_roundtrip(cx + (float)(a - 4), Wl);
+    const float py = grid_roundtrip(cy + (float)(b - 4), Hl);
+    const float fx = floorf(px), fy = floorf(py);
+    const float lx = px - fx, ly = py - fy;
+    int c0 = (int)fx - x0, r0 = (int)fy - y0;  // position inside the staged patch
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int rr = r0 + (k >> 1), cc = c0 + (k & 1);
+      const float wgt = ((k & 1) ? lx : 1.f - lx) * ((k >> 1) ? ly : 1.f - ly);
+      float s = 0.f;
+      if (rr >= 0 && rr < 10 && cc >= 0 && cc < 10) s = patch[lvl][rr][cc];
+      else {
+        const int yy = y0 + rr, xx = x0 + cc;   // 1-ulp spill outside the staged window: read directly
+        if (yy >= 0 && yy < Hl && xx >= 0 && xx < Wl) s = map[(long long)yy * Wl + xx];
+      }
+      v += wgt * s;
+    }
+    op[i] = from_f32<TO>(v);
+  }
+  if (lvl == 3)
+    for (int i = 324 + lane; i < ocpad; i += 64) out[pix * ocs + i] = from_f32<TO>(0.f);
+}
+
+// One thread per fine output pixel pair (both flow channels): softmax over the 9 mask logits of its
+// (coarse pixel, sub-position) and convex combination of the 3x3 coarse neighbourhood of 8*flow.
+template <typename TM>
+__global__ void convex_upsample_kernel(const float* __restrict__ flow, const TM* __restrict__ mask, int mcs,
+                                       float* __restrict__ out, int B, int h, int w) {
+  const int OW = 8 * w, OH = 8 * h;
+  const long long total = (long long)B * OH * OW;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int X = (int)(i % OW), Y = (int)((i / OW) % OH);
+    const long long n = i / ((long long)OW * OH);
+    const int x = X >> 3, y = Y >> 3, sub = (Y & 7) * 8 + (X & 7);
+    const TM* mp = mask + ((n * h + y) * (long long)w + x) * mcs + sub;
+    float lg[9], mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { lg[k] = to_f32(mp[k * 64]); mx = fmaxf(mx, lg[k]); }
+    float den = 0.f, ax = 0.f, ay = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const float e = __expf(lg[k] - mx);
+      den += e;
+      const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+      if (yy >= 0 && yy < h && xx >= 0 && xx < w) {
+        const float* fp = flow + ((n * h + yy) * (long long)w + xx) * 2;
+        ax += e * 8.f * fp[0];
+        ay += e * 8.f * fp[1];
+      }
+    }
+    out[((n * 2 + 0) * OH + Y) * (long long)OW + X] = ax / den;
+    out[((n * 2 + 1) * OH + Y) * (long long)OW + X] = ay / den;
+  }
+}
+
+static inline int grid_for(long long total, int block = 256) {
+  long long g = (total + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > 256 * 16 ? 256 * 16 : g));
+}
+
+}  // namespace pp
+
+using namespace pp;
+
+extern "C" int pp_corr_avgpool(const float* in, float* out, int64_t M, int H, int W, void* stream) {
+  PP_REQUIRE(in && out && M > 0 && H >= 2 && W >= 2, PP_ERR_ARG, "pp_corr_avgpool: bad arguments");
+  hipLaunchKernelGGL(corr_avgpool_kernel, dim3(grid_for(M * (H / 2) * (W / 2))), dim3(256), 0, (hipStream_t)stream, in, out,
+                     (long long)M, H, W);
+  return launch_status("pp_corr_avgpool");
+}
+
+extern "C" int pp_corr_lookup(const float* lvl0, const float* lvl1, const float* lvl2, const float* lvl3,
+                              const float* coords, void* out, int out_cstride, int out_cpad, int B, int h, int w,
+                              int out_dtype, void* stream) {
+  PP_REQUIRE(lvl0 && lvl1 && lvl2 && lvl3 && coords && out, PP_ERR_ARG, "pp_corr_lookup: null pointer");
+  PP_REQUIRE(B > 0 && (h >> 3) >= 2 && (w >> 3) >= 2, PP_ERR_ARG,
+             "pp_corr_lookup: level-3 map would be %dx%d (RAFT needs >= 2x2: inputs of at least 128x128)", h >> 3, w >> 3);
+  PP_REQUIRE(out_cpad >= 324 && out_cstride >= out_cpad, PP_ERR_ARG, "pp_corr_lookup: out_cpad %d / cstride %d", out_cpad, out_cstride);
+  PP_REQUIRE(out_dtype == PP_F32 || out_dtype == PP_F16, PP_ERR_DTYPE, "pp_corr_lookup: dtype %d", out_dtype);
+  const long long npix = (long long)B * h * w;
+  hipStream_t st = (hipStream_t)stream;
+  if (out_dtype == PP_F16)
+    hipLaunchKernelGGL((corr_lookup_kernel<_Float16>), dim3((unsigned)npix), dim3(256), 0, st, lvl0, lvl1, lvl2, lvl3, coords,
+                       (_Float16*)out, out_cstride, out_cpad, h, w);
+  else
+    hipLaunchKernelGGL((corr_lookup_kernel<float>), dim3((unsigned)npix), dim3(256), 0, st, lvl0, lvl1, lvl2, lvl3, coords,
+                       (float*)out, out_cstride, out_cpad, h, w);
+  return launch_status("pp_corr_lookup");
+}
+
+extern "C" int pp_convex_upsample(const float* flow, const void* mask, int mask_cstride, int mask_dtype, float* out, int B,
+                                  int h, int w, void* stream) {
+  PP_REQUIRE(flow && mask && out && B > 0 && h > 0 && w > 0 && mask_cstride >= 576, PP_ERR_ARG, "pp_convex_upsample: bad arguments");
+  PP_REQUIRE(mask_dtype == PP_F32 || mask_dtype == PP_F16, PP_ERR_DTYPE, "pp_convex_upsample: dtype %d", mask_dtype);
+  const int g = grid_for((long long)B * 64 * h * w);
+  hipStream_t st = (hipStream_t)stream;
+  if (mask_dtype == PP_F16)
+    hipLaunchKernelGGL((convex_upsample_kernel<_Float16>), dim3(g), dim3(256), 0, st, flow, (const _Float16*)mask, mask_cstride,
+                       out, B, h, w);
+  else
+    hipLaunchKernelGGL((convex_upsample_kernel<float>), dim3(g), dim3(256), 0, st, flow, (const float*)mask, mask_cstride, out,
+                       B, h, w);
+  return launch_status("pp_convex_upsample");
+}

@@ -1,0 +1,222 @@
+// Flow-guided sampling kernels (HBM-bound gathers): flow warp, forward-backward consistency check and
+// the fused step of the non-learnable image propagation.  Coordinates are always computed in fp32
+// (the reference builds its grid in x.dtype, model/modules/flow_loss_utils.py:32, which quantises
+// coordinates > 1024 in fp16 mode; we compare against the fp32 oracle instead).
+#include "common.h"
+
+namespace pp {
+
+// Bilinear tap set with zeros padding at pixel coordinates (px, py) of an HxW image.
+struct Taps {
+  int idx[4];     // y*W + x, or -1
+  float w[4];
+};
+
+__device__ __forceinline__ Taps bilinear_taps(float px, float py, int H, int W) {
+  Taps t;
+  const float fx = floorf(px), fy = floorf(py);
+  const int x0 = (int)fx, y0 = (int)fy;
+  const float lx = px - fx, ly = py - fy;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int xx = x0 + (c & 1), yy = y0 + (c >> 1);
+    const bool ok = xx >= 0 && xx < W && yy >= 0 && yy < H;
+    t.idx[c] = ok ? yy * W + xx : -1;
+    t.w[c] = ((c & 1) ? lx : 1.f - lx) * ((c >> 1) ? ly : 1.f - ly);
+  }
+  return t;
+}
+
+// NHWC warp: one thread per (pixel, 8-channel chunk) (or per pixel when C <= 4).
+template <typename T, bool WIDE>
+__global__ void flow_warp_kernel(const T* __restrict__ x, int xcs, int xco, const T* __restrict__ flow, int fcs,
+                                 int fco, T* __restrict__ out, int ocs, int oco, int N, int H, int W, int C, int mode) {
+  const int cchunks = WIDE ? C / 8 : 1;
+  const long long total = (long long)N * H * W * cchunks;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % cchunks);
+    const long long pix = i / cchunks;
+    const int xw = (int)(pix % W);
+    const int yh = (int)((pix / W) % H);
+    const long long nb = (pix / ((long long)W * H)) * (long long)H * W;
+    const float fx = to_f32(flow[pix * fcs + fco]), fy = to_f32(flow[pix * fcs + fco + 1]);
+    const float px = grid_roundtrip((float)xw + fx, W), py = grid_roundtrip((float)yh + fy, H);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (mode == 1) {
+      const float rx = nearbyintf(px), ry = nearbyintf(py);
+      const int xi = (int)rx, yi = (int)ry;
+      if (xi >= 0 && xi < W && yi >= 0 && yi < H) {
+        const T* sp = x + (nb + (long long)yi * W + xi) * xcs + xco + cc * 8;
+        if constexpr (WIDE) load8<T>(sp, acc);
+        else for (int c = 0; c < C; ++c) acc[c] = to_f32(sp[c]);
+      }
+    } else {
+      const Taps t = bilinear_taps(px, py, H, W);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (t.idx[k] < 0) continue;
+        const T* sp = x + (nb + t.idx[k]) * xcs + xco + cc * 8;
+        if constexpr (WIDE) {
+          float v[8];
+          load8<T>(sp, v);
+#pragma unroll
+          for (int c = 0; c < 8; ++c) acc[c] += t.w[k] * v[c];
+        } else {
+          for (int c = 0; c < C; ++c) acc[c] += t.w[k] * to_f32(sp[c]);
+        }
+      }
+    }
+    T* op = out + pix * ocs + oco + cc * 8;
+    if constexpr (WIDE) store8<T>(op, acc);
+    else for (int c = 0; c < C; ++c) op[c] = from_f32<T>(acc[c]);
+  }
+}
+
+template <typename T>
+__global__ void fb_check_kernel(const T* __restrict__ fw, int fwcs, const T* __restrict__ bw, int bwcs, T* __restrict__ out,
+                                int ocs, int oco, int N, int H, int W) {
+  const long long total = (long long)N * H * W;
+  for (long long pix = blockIdx.x * (long long)blockDim.x + threadIdx.x; pix < total; pix += (long long)gridDim.x * blockDim.x) {
+    const int xw = (int)(pix % W);
+    const int yh = (int)((pix / W) % H);
+    const long long nb = (pix / ((long long)W * H)) * (long long)H * W;
+    const float fx = to_f32(fw[pix * fwcs]), fy = to_f32(fw[pix * fwcs + 1]);
+    const Taps t = bilinear_taps(grid_roundtrip((float)xw + fx, W), grid_roundtrip((float)yh + fy, H), H, W);
+    float bx = 0.f, by = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (t.idx[k] >= 0) {
+        bx += t.w[k] * to_f32(bw[(nb + t.idx[k]) * bwcs]);
+        by += t.w[k] * to_f32(bw[(nb + t.idx[k]) * bwcs + 1]);
+      }
+    // the reference rounds the warped flow to the tensor dtype before the test
+    bx = to_f32(from_f32<T>(bx)); by = to_f32(from_f32<T>(by));
+    const float dx = fx + bx, dy = fy + by;
+    const float mag = fx * fx + fy * fy + bx * bx + by * by;
+    out[pix * ocs + oco] = from_f32<T>((dx * dx + dy * dy) < (0.01f * mag + 0.5f) ? 1.f : 0.f);
+  }
+}
+
+// Planar (NCHW) fused image-propagation step; one thread per pixel.
+template <typename T>
+__global__ void img_prop_step_kernel(const T* __restrict__ x_prop, const T* __restrict__ m_prop, const T* __restrict__ x_cur,
+                                     const T* __restrict__ m_cur, const T* __restrict__ f_prop, const T* __restrict__ f_chk,
+                                     T* __restrict__ x_out, T* __restrict__ m_out, int N, int C, int H, int W, int mode) {
+  const long long hw = (long long)H * W;
+  const long long total = (long long)N * hw;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int xw = (int)(i % W);
+    const int yh = (int)((i / W) % H);
+    const long long n = i / hw;
+    const long long p = i - n * hw;
+    const T* fp = f_prop + n * 2 * hw;
+    const T* fc = f_chk + n * 2 * hw;
+    const float fx = to_f32(fp[p]), fy = to_f32(fp[hw + p]);
+    const float px = grid_roundtrip((float)xw + fx, W), py = grid_roundtrip((float)yh + fy, H);
+    const Taps t = bilinear_taps(px, py, H, W);
+    float bx = 0.f, by = 0.f, mw = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (t.idx[k] >= 0) {
+        bx += t.w[k] * to_f32(fc[t.idx[k]]);
+        by += t.w[k] * to_f32(fc[hw + t.idx[k]]);
+        mw += t.w[k] * to_f32(m_prop[n * hw + t.idx[k]]);
+      }
+    bx = to_f32(from_f32<T>(bx)); by = to_f32(from_f32<T>(by)); mw = to_f32(from_f32<T>(mw));
+    const float dx = fx + bx, dy = fy + by;
+    const float valid = (dx * dx + dy * dy) < (0.01f * (fx * fx + fy * fy + bx * bx + by * by) + 0.5f) ? 1.f : 0.f;
+    const float mwb = mw > 0.1f ? 1.f : 0.f;
+    const float mc = to_f32(m_cur[n * hw + p]);
+    const float u = (mc * valid * (1.f - mwb)) > 0.1f ? 1.f : 0.f;
+    const float mo = (mc * (1.f - valid * (1.f - mwb))) > 0.1f ? 1.f : 0.f;
+    m_out[n * hw + p] = from_f32<T>(mo);
+    int sidx = -1;
+    if (mode == 1) {
+      const int xi = (int)nearbyintf(px), yi = (int)nearbyintf(py);
+      if (xi >= 0 && xi < W && yi >= 0 && yi < H) sidx = yi * W + xi;
+    }
+    for (int c = 0; c < C; ++c) {
+      const T* xp = x_prop + (n * C + c) * hw;
+      float wv = 0.f;
+      if (mode == 1) {
+        if (sidx >= 0) wv = to_f32(xp[sidx]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (t.idx[k] >= 0) wv += t.w[k] * to_f32(xp[t.idx[k]]);
+        wv = to_f32(from_f32<T>(wv));
+      }
+      const float cur = to_f32(x_cur[(n * C + c) * hw + p]);
+      x_out[(n * C + c) * hw + p] = from_f32<T>(u * wv + (1.f - u) * cur);
+    }
+  }
+}
+
+static inline int grid_for(long long total, int block = 256) {
+  long long g = (total + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > 256 * 16 ? 256 * 16 : g));
+}
+
+}  // namespace pp
+
+using namespace pp;
+
+extern "C" int pp_flow_warp(const void* x, int x_cstride, int x_choff, const void* flow, int fl_cstride, int fl_choff,
+                            void* out, int out_cstride, int out_choff, int N, int H, int W, int C, int mode, int dtype,
+                            void* stream) {
+  PP_REQUIRE(x && flow && out && N > 0 && H > 0 && W > 0 && C > 0, PP_ERR_ARG, "pp_flow_warp: bad arguments");
+  PP_REQUIRE(dtype == PP_F32 || dtype == PP_F16, PP_ERR_DTYPE, "pp_flow_warp: dtype %d", dtype);
+  PP_REQUIRE(mode == 0 || mode == 1, PP_ERR_ARG, "pp_flow_warp: mode %d", mode);
+  const bool wide = C % 8 == 0;
+  PP_REQUIRE(wide || C <= 4, PP_ERR_ALIGN, "pp_flow_warp: C=%d must be a multiple of 8 or <= 4", C);
+  const int esz = dtype == PP_F16 ? 2 : 4;
+  if (wide)
+    PP_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)out % 16 == 0 && (x_cstride * esz) % 16 == 0 && (x_choff * esz) % 16 == 0 &&
+                   (out_cstride * esz) % 16 == 0 && (out_choff * esz) % 16 == 0,
+               PP_ERR_ALIGN, "pp_flow_warp: 16-byte alignment violated");
+  hipStream_t st = (hipStream_t)stream;
+  const long long total = (long long)N * H * W * (wide ? C / 8 : 1);
+  const int g = grid_for(total);
+#define LAUNCH(T, WIDE)                                                                                              \
+  hipLaunchKernelGGL((flow_warp_kernel<T, WIDE>), dim3(g), dim3(256), 0, st, (const T*)x, x_cstride, x_choff,        \
+                     (const T*)flow, fl_cstride, fl_choff, (T*)out, out_cstride, out_choff, N, H, W, C, mode)
+  if (dtype == PP_F16) { if (wide) LAUNCH(_Float16, true); else LAUNCH(_Float16, false); }
+  else { if (wide) LAUNCH(float, true); else LAUNCH(float, false); }
+#undef LAUNCH
+  return launch_status("pp_flow_warp");
+}
+
+extern "C" int pp_fb_check(const void* flow_fw, int fw_cstride, const void* flow_bw, int bw_cstride, void* out,
+                           int out_cstride, int out_choff, int N, int H, int W, int dtype, void* stream) {
+  PP_REQUIRE(flow_fw && flow_bw && out && N > 0 && H > 0 && W > 0, PP_ERR_ARG, "pp_fb_check: bad arguments");
+  PP_REQUIRE(dtype == PP_F32 || dtype == PP_F16, PP_ERR_DTYPE, "pp_fb_check: dtype %d", dtype);
+  hipStream_t st = (hipStream_t)stream;
+  const int g = grid_for((long long)N * H * W);
+  if (dtype == PP_F16)
+    hipLaunchKernelGGL((fb_check_kernel<_Float16>), dim3(g), dim3(256), 0, st, (const _Float16*)flow_fw, fw_cstride,
+                       (const _Float16*)flow_bw, bw_cstride, (_Float16*)out, out_cstride, out_choff, N, H, W);
+  else
+    hipLaunchKernelGGL((fb_check_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)flow_fw, fw_cstride,
+                       (const float*)flow_bw, bw_cstride, (float*)out, out_cstride, out_choff, N, H, W);
+  return launch_status("pp_fb_check");
+}
+
+extern "C" int pp_img_prop_step(const void* x_prop, const void* m_prop, const void* x_cur, const void* m_cur,
+                                const void* flow_prop, const void* flow_check, void* x_out, void* m_out, int N, int C,
+                                int H, int W, int mode, int dtype, void* stream) {
+  PP_REQUIRE(x_prop && m_prop && x_cur && m_cur && flow_prop && flow_check && x_out && m_out, PP_ERR_ARG,
+             "pp_img_prop_step: null pointer");
+  PP_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && (mode == 0 || mode == 1), PP_ERR_ARG, "pp_img_prop_step: bad extents");
+  PP_REQUIRE(dtype == PP_F32 || dtype == PP_F16, PP_ERR_DTYPE, "pp_img_prop_step: dtype %d", dtype);
+  hipStream_t st = (hipStream_t)stream;
+  const int g = grid_for((long long)N * H * W);
+  if (dtype == PP_F16)
+    hipLaunchKernelGGL((img_prop_step_kernel<_Float16>), dim3(g), dim3(256), 0, st, (const _Float16*)x_prop,
+                       (const _Float16*)m_prop, (const _Float16*)x_cur, (const _Float16*)m_cur, (const _Float16*)flow_prop,
+                       (const _Float16*)flow_check, (_Float16*)x_out, (_Float16*)m_out, N, C, H, W, mode);
+  else
+    hipLaunchKernelGGL((img_prop_step_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)x_prop, (const float*)m_prop,
+                       (const float*)x_cur, (const float*)m_cur, (const float*)flow_prop, (const float*)flow_check,
+                       (float*)x_out, (float*)m_out, N, C, H, W, mode);
+  return launch_status("pp_img_prop_step");
+}

@@ -1,0 +1,354 @@
+// Token <-> feature-map kernels and small dense helpers (all HBM-bound, vectorised 16-byte accesses):
+// fold (SoftComp / FusionFeedForward), LayerNorm, depthwise pooling, InstanceNorm, bilinear x2
+// upsampling, the deformable offset/mask head activation, GRU gating and layout packers.
+#include "common.h"
+
+namespace pp {
+
+static inline int grid_for(long long total, int block = 256) {
+  long long g = (total + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > 256 * 16 ? 256 * 16 : g));
+}
+
+// F.fold(7, stride 3, pad 3) as a gather: output pixel (y, x) sums the <= 3x3 patches that cover it.
+// tokens [BT, fh*fw, C*49] with feature index c*49 + ky*7 + kx.  One thread per (pixel, channel);
+// consecutive threads take consecutive channels so the NHWC store is coalesced (the token reads are
+// 98-byte strided by construction of the reference's feature order).
+template <typename T>
+__global__ void fold_tokens_kernel(const T* __restrict__ tok, T* __restrict__ out, int BT, int fh, int fw, int C, int H, int W,
+                                   int normalize, int act) {
+  const long long total = (long long)BT * H * W * C;
+  const long long tstride = (long long)C * 49;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long long pix = i / C;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H);
+    const long long n = pix / ((long long)W * H);
+    float acc = 0.f;
+    int cnt = 0;
+    // patches py with 3*py - 3 <= y <= 3*py + 3
+    const int py0 = max(0, (y - 3 + 2) / 3), py1 = min(fh - 1, (y + 3) / 3);
+    const int px0 = max(0, (x - 3 + 2) / 3), px1 = min(fw - 1, (x + 3) / 3);
+    for (int py = py0; py <= py1; ++py) {
+      const int ky = y + 3 - 3 * py;
+      for (int px = px0; px <= px1; ++px) {
+        const int kx = x + 3 - 3 * px;
+        acc += to_f32(tok[(n * fh * fw + (long long)py * fw + px) * tstride + c * 49 + ky * 7 + kx]);
+        ++cnt;
+      }
+    }
+    if (normalize) acc = acc / (float)cnt;
+    out[i] = from_f32<T>(apply_act(acc, act, 0.f));
+  }
+}
+
+// LayerNorm: one wave per row, C/64 elements per lane kept in registers (two-pass, fp32 statistics).
+template <typename T, int PER_LANE>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ in, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, T* __restrict__ out, long long rows,
+                                                        int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* ip = in + row * C;
+  float v[PER_LANE];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER_LANE; ++i) { v[i] = to_f32(ip[lane + 64 * i]); s += v[i]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER_LANE; ++i) { const float d = v[i] - mean; q += d * d; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+  const float rstd = rsqrtf(q / (float)C + eps);
+  T* op = out + row * C;
+#pragma unroll
+  for (int i = 0; i < PER_LANE; ++i) {
+    const int c = lane + 64 * i;
+    op[c] = from_f32<T>((v[i] - mean) * rstd * gamma[c] + beta[c]);
+  }
+}
+
+// depthwise k x k stride-k conv, NHWC; one thread per output (pixel, channel).
+template <typename T>
+__global__ void depthwise_pool_kernel(const T* __restrict__ in, const float* __restrict__ wgt, const float* __restrict__ bias,
+                                      T* __restrict__ out, int N, int H, int W, int C, int k) {
+  const int OH = H / k, OW = W / k;
+  const long long total = (long long)N * OH * OW * C;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long long pix = i / C;
+    const int ox = (int)(pix % OW), oy = (int)((pix / OW) % OH);
+    const long long n = pix / ((long long)OW * OH);
+    float acc = bias ? bias[c] : 0.f;
+    for (int ky = 0; ky < k; ++ky)
+      for (int kx = 0; kx < k; ++kx)
+        acc += wgt[(c * k + ky) * k + kx] * to_f32(in[((n * H + oy * k + ky) * (long long)W + ox * k + kx) * C + c]);
+    out[i] = from_f32<T>(acc);
+  }
+}
+
+// InstanceNorm statistics: grid (channel-block of 64, slice, n): each thread accumulates one channel over a
+// slice of the pixels; partial sums are combined with atomics into ws[n][c][2] (sum, sumsq in fp32).
+template <typename T>
+__global__ void inorm_stats_kernel(const T* __restrict__ in, float* __restrict__ ws, int HW, int C, int slices) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int sub = threadIdx.x >> 6;                    // 4 pixel phases per block
+  const int n = blockIdx.z;
+  if (c >= C) return;
+  const int per = (HW + slices - 1) / slices;
+  const int p0 = blockIdx.y * per, p1 = min(HW, p0 + per);
+  float s = 0.f, q = 0.f;
+  for (int p = p0 + sub; p < p1; p += 4) {
+    const float v = to_f32(in[((long long)n * HW + p) * C + c]);
+    s += v; q += v * v;
+  }
+  atomicAdd(&ws[((long long)n * C + c) * 2], s);
+  atomicAdd(&ws[((long long)n * C + c) * 2 + 1], q);
+}
+
+template <typename T>
+__global__ void inorm_apply_kernel(const T* __restrict__ in, const float* __restrict__ ws, T* __restrict__ out, long long N,
+                                   int HW, int C, float eps, int relu) {
+  const long long total = N * HW * (C / 8);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % (C / 8));
+    const long long pix = i / (C / 8);
+    const long long n = pix / HW;
+    float v[8];
+    load8<T>(in + pix * C + cc * 8, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float s = ws[(n * C + cc * 8 + j) * 2], q = ws[(n * C + cc * 8 + j) * 2 + 1];
+      const float mean = s / (float)HW;
+      const float var = fmaxf(q / (float)HW - mean * mean, 0.f);
+      float r = (v[j] - mean) * rsqrtf(var + eps);
+      v[j] = relu ? fmaxf(r, 0.f) : r;
+    }
+    store8<T>(out + pix * C + cc * 8, v);
+  }
+}
+
+// bilinear x2, align_corners=True: src = dst * (in-1)/(out-1)
+template <typename T>
+__global__ void upsample2x_kernel(const T* __restrict__ in, T* __restrict__ out, int N, int H, int W, int C) {
+  const int OH = 2 * H, OW = 2 * W;
+  const int cch = C / 8;
+  const float sy = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
+  const float sx = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
+  const long long total = (long long)N * OH * OW * cch;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % cch);
+    const long long pix = i / cch;
+    const int ox = (int)(pix % OW), oy = (int)((pix / OW) % OH);
+    const long long n = pix / ((long long)OW * OH);
+    const float fy = sy * (float)oy, fx = sx * (float)ox;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    float a[8], b[8], c[8], d[8], o[8];
+    const T* base = in + n * (long long)H * W * C + cc * 8;
+    load8<T>(base + ((long long)y0 * W + x0) * C, a);
+    load8<T>(base + ((long long)y0 * W + x1) * C, b);
+    load8<T>(base + ((long long)y1 * W + x0) * C, c);
+    load8<T>(base + ((long long)y1 * W + x1) * C, d);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      o[j] = (1.f - ly) * ((1.f - lx) * a[j] + lx * b[j]) + ly * ((1.f - lx) * c[j] + lx * d[j]);
+    store8<T>(out + pix * C + cc * 8, o);
+  }
+}
+
+template <typename T>
+__global__ void dcn_offmask_act_kernel(T* __restrict__ om, int cs, const T* __restrict__ flow, int fcs, int fco, float mag,
+                                       long long npix) {
+  const long long total = npix * 54;   // 432 / 8
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % 54);
+    const long long pix = i / 54;
+    float v[8];
+    T* p = om + pix * cs + cc * 8;
+    load8<T>(p, v);
+    if (cc < 36) {
+      float fx = 0.f, fy = 0.f;
+      if (flow) { fx = to_f32(flow[pix * fcs + fco]); fy = to_f32(flow[pix * fcs + fco + 1]); }
+      // offset + flow.flip(1).repeat(...): even channels (dy) get flow_y, odd channels (dx) get flow_x
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = mag * tanhf(v[j]) + ((j & 1) ? fx : fy);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = 1.f / (1.f + __expf(-v[j]));
+    }
+    store8<T>(p, v);
+  }
+}
+
+template <typename T>
+__global__ void gru_gate_kernel(const T* __restrict__ zr, int zcs, const T* __restrict__ h, int hcs, int hco,
+                                const T* __restrict__ q, int qcs, T* __restrict__ out, int ocs, int oco, long long npix, int C,
+                                int mode) {
+  const int cch = C / 8;
+  const long long total = npix * cch;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % cch);
+    const long long pix = i / cch;
+    float a[8], hv[8], o[8];
+    load8<T>(h + pix * hcs + hco + cc * 8, hv);
+    if (mode == 0) {
+      load8<T>(zr + pix * zcs + C + cc * 8, a);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = a[j] * hv[j];
+    } else {
+      float qv[8];
+      load8<T>(zr + pix * zcs + cc * 8, a);
+      load8<T>(q + pix * qcs + cc * 8, qv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (1.f - a[j]) * hv[j] + a[j] * qv[j];
+    }
+    store8<T>(out + pix * ocs + oco + cc * 8, o);
+  }
+}
+
+// planar -> pixel-major with dtype conversion; one thread per (pixel, channel), pixel fastest on the read side.
+template <typename TI, typename TO>
+__global__ void nchw_to_nhwc_kernel(const TI* __restrict__ in, TO* __restrict__ out, int ocs, int oco, int N, int C, int HW,
+                                    float scale) {
+  const long long total = (long long)N * C * HW;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int p = (int)(i % HW);
+    const int c = (int)((i / HW) % C);
+    const long long n = i / ((long long)HW * C);
+    out[(n * HW + p) * ocs + oco + c] = from_f32<TO>(to_f32(in[i]) * scale);
+  }
+}
+template <typename TI, typename TO>
+__global__ void nhwc_to_nchw_kernel(const TI* __restrict__ in, int ics, int ico, TO* __restrict__ out, int N, int C, int HW,
+                                    int act) {
+  const long long total = (long long)N * C * HW;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int p = (int)(i % HW);
+    const int c = (int)((i / HW) % C);
+    const long long n = i / ((long long)HW * C);
+    out[i] = from_f32<TO>(apply_act(to_f32(in[(n * HW + p) * ics + ico + c]), act, 0.f));
+  }
+}
+
+}  // namespace pp
+
+using namespace pp;
+
+#define PP_DISPATCH_T(dtype, ...)                          \
+  if ((dtype) == PP_F16) { using T = _Float16; __VA_ARGS__ } \
+  else { using T = float; __VA_ARGS__ }
+
+extern "C" int pp_fold_tokens(const void* tokens, void* out, int BT, int fh, int fw, int C, int H, int W, int normalize,
+                              int act, int dtype, void* stream) {
+  PP_REQUIRE(tokens && out && BT > 0 && fh > 0 && fw > 0 && C > 0 && H > 0 && W > 0, PP_ERR_ARG, "pp_fold_tokens: bad arguments");
+  PP_REQUIRE(dtype == PP_F32 || dtype == PP_F16, PP_ERR_DTYPE, "pp_fold_tokens: dtype %d", dtype);
+  PP_REQUIRE(fh == (H + 6 - 7) / 3 + 1 && fw == (W + 6 - 7) / 3 + 1, PP_ERR_ARG, "pp_fold_tokens: token grid %dx%d does not match %dx%d", fh, fw, H, W);
+  const int g = grid_for((long long)BT * H * W * C);
+  PP_DISPATCH_T(dtype, hipLaunchKernelGGL((fold_tokens_kernel<T>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const T*)tokens,
+                                          (T*)out, BT, fh, fw, C, H, W, normalize, act);)
+  return launch_status("pp_fold_tokens");
+}
+
+extern "C" int pp_layernorm(const void* in, const float* gamma, const float* beta, void* out, int64_t rows, int C, float eps,
+                            int dtype, void* stream) {
+  PP_REQUIRE(in && gamma && beta && out && rows > 0, PP_ERR_ARG, "pp_layernorm: bad arguments");
+  PP_REQUIRE(C == 512, PP_ERR_ARG, "pp_layernorm: C=%d (only 512 is instantiated)", C);
+  PP_REQUIRE(dtype == PP_F32 || dtype == PP_F16, PP_ERR_DTYPE, "pp_layernorm: dtype %d", dtype);
+  const unsigned g = (unsigned)((rows + 3) / 4);
+  PP_DISPATCH_T(dtype, hipLaunchKernelGGL((layernorm_kernel<T, 8>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const T*)in, gamma,
+                                          beta, (T*)out, (long long)rows, C, eps);)
+  return launch_status("pp_layernorm");
+}
+
+extern "C" int pp_depthwise_pool(const void* in, const float* weight, const float* bias, void* out, int N, int H, int W, int C,
+                                 int k, int dtype, void* stream) {
+  PP_REQUIRE(in && weight && out && N > 0 && H >= k && W >= k && C > 0 && k > 0, PP_ERR_ARG, "pp_depthwise_pool: bad arguments");
+  PP_REQUIRE(dtype == PP_F32 || dtype == PP_F16, PP_ERR_DTYPE, "pp_depthwise_pool: dtype %d", dtype);
+  const int g = grid_for((long long)N * (H / k) * (W / k) * C);
+  PP_DISPATCH_T(dtype, hipLaunchKernelGGL((depthwise_pool_kernel<T>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const T*)in,
+                                          weight, bias, (T*)out, N, H, W, C, k);)
+  return launch_status("pp_depthwise_pool");
+}
+
+extern "C" int pp_instance_norm(const void* in, void* out, float* stats_ws, int N, int H, int W, int C, float eps, int relu,
+                                int dtype, void* stream) {
+  PP_REQUIRE(in && out && stats_ws && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, PP_ERR_ARG, "pp_instance_norm: bad arguments");
+  PP_REQUIRE(dtype == PP_F32 || dtype == PP_F16, PP_ERR_DTYPE, "pp_instance_norm: dtype %d", dtype);
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(stats_ws, 0, sizeof(float) * 2 * (size_t)N * C, st);
+  if (e != hipSuccess) { set_error("pp_instance_norm: memset: %s", hipGetErrorString(e)); return (int)e; }
+  const int HW = H * W;
+  int slices = HW / 512; if (slices < 1) slices = 1; if (slices > 128) slices = 128;
+  dim3 sg((C + 63) / 64, slices, N);
+  PP_DISPATCH_T(dtype,
+                hipLaunchKernelGGL((inorm_stats_kernel<T>), sg, dim3(256), 0, st, (const T*)in, stats_ws, HW, C, slices);
+                hipLaunchKernelGGL((inorm_apply_kernel<T>), dim3(grid_for((long long)N * HW * (C / 8))), dim3(256), 0, st,
+                                   (const T*)in, stats_ws, (T*)out, (long long)N, HW, C, eps, relu);)
+  return launch_status("pp_instance_norm");
+}
+
+extern "C" int pp_upsample2x(const void* in, void* out, int N, int H, int W, int C, int dtype, void* stream) {
+  PP_REQUIRE(in && out && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, PP_ERR_ARG, "pp_upsample2x: bad arguments (C=%d)", C);
+  PP_REQUIRE(dtype == PP_F32 || dtype == PP_F16, PP_ERR_DTYPE, "pp_upsample2x: dtype %d", dtype);
+  const int g = grid_for((long long)N * 4 * H * W * (C / 8));
+  PP_DISPATCH_T(dtype, hipLaunchKernelGGL((upsample2x_kernel<T>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const T*)in, (T*)out,
+                                          N, H, W, C);)
+  return launch_status("pp_upsample2x");
+}
+
+extern "C" int pp_dcn_offset_mask_act(void* offmask, int cstride, const void* flow, int fl_cstride, int fl_choff, float mag,
+                                      int64_t npix, int dtype, void* stream) {
+  PP_REQUIRE(offmask && npix > 0 && cstride >= 432 && cstride % 8 == 0, PP_ERR_ARG, "pp_dcn_offset_mask_act: bad arguments");
+  PP_REQUIRE(dtype == PP_F32 || dtype == PP_F16, PP_ERR_DTYPE, "pp_dcn_offset_mask_act: dtype %d", dtype);
+  const int g = grid_for((long long)npix * 54);
+  PP_DISPATCH_T(dtype, hipLaunchKernelGGL((dcn_offmask_act_kernel<T>), dim3(g), dim3(256), 0, (hipStream_t)stream, (T*)offmask,
+                                          cstride, (const T*)flow, fl_cstride, fl_choff, mag, (long long)npix);)
+  return launch_status("pp_dcn_offset_mask_act");
+}
+
+extern "C" int pp_gru_gate(const void* zr, int zr_cstride, const void* h, int h_cstride, int h_choff, const void* q,
+                           int q_cstride, void* out, int out_cstride, int out_choff, int64_t npix, int C, int mode, int dtype,
+                           void* stream) {
+  PP_REQUIRE(zr && h && out && npix > 0 && C > 0 && C % 8 == 0 && (mode == 0 || (mode == 1 && q)), PP_ERR_ARG,
+             "pp_gru_gate: bad arguments");
+  PP_REQUIRE(dtype == PP_F32 || dtype == PP_F16, PP_ERR_DTYPE, "pp_gru_gate: dtype %d", dtype);
+  const int g = grid_for((long long)npix * (C / 8));
+  PP_DISPATCH_T(dtype, hipLaunchKernelGGL((gru_gate_kernel<T>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const T*)zr, zr_cstride,
+                                          (const T*)h, h_cstride, h_choff, (const T*)q, q_cstride, (T*)out, out_cstride, out_choff,
+                                          (long long)npix, C, mode);)
+  return launch_status("pp_gru_gate");
+}
+
+#define PP_DISPATCH_2(di, dout, ...)                                                     \
+  if ((di) == PP_F16 && (dout) == PP_F16) { using TI = _Float16; using TO = _Float16; __VA_ARGS__ } \
+  else if ((di) == PP_F16) { using TI = _Float16; using TO = float; __VA_ARGS__ }            \
+  else if ((dout) == PP_F16) { using TI = float; using TO = _Float16; __VA_ARGS__ }          \
+  else { using TI = float; using TO = float; __VA_ARGS__ }
+
+extern "C" int pp_nchw_to_nhwc(const void* in, int in_dtype, void* out, int out_dtype, int out_cstride, int out_choff, int N,
+                               int C, int H, int W, float scale, void* stream) {
+  PP_REQUIRE(in && out && N > 0 && C > 0 && H > 0 && W > 0 && out_cstride >= C, PP_ERR_ARG, "pp_nchw_to_nhwc: bad arguments");
+  PP_REQUIRE((in_dtype | out_dtype) <= 1 && in_dtype >= 0 && out_dtype >= 0, PP_ERR_DTYPE, "pp_nchw_to_nhwc: dtype");
+  const int g = grid_for((long long)N * C * H * W);
+  PP_DISPATCH_2(in_dtype, out_dtype,
+                hipLaunchKernelGGL((nchw_to_nhwc_kernel<TI, TO>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const TI*)in, (TO*)out,
+                                   out_cstride, out_choff, N, C, H * W, scale);)
+  return launch_status("pp_nchw_to_nhwc");
+}
+
+extern "C" int pp_nhwc_to_nchw(const void* in, int in_dtype, int in_cstride, int in_choff, void* out, int out_dtype, int N, int C,
+                               int H, int W, int act, void* stream) {
+  PP_REQUIRE(in && out && N > 0 && C > 0 && H > 0 && W > 0 && in_cstride >= C, PP_ERR_ARG, "pp_nhwc_to_nchw: bad arguments");
+  PP_REQUIRE((in_dtype | out_dtype) <= 1 && in_dtype >= 0 && out_dtype >= 0, PP_ERR_DTYPE, "pp_nhwc_to_nchw: dtype");
+  const int g = grid_for((long long)N * C * H * W);
+  PP_DISPATCH_2(in_dtype, out_dtype,
+                hipLaunchKernelGGL((nhwc_to_nchw_kernel<TI, TO>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const TI*)in, in_cstride,
+                                   in_choff, (TO*)out, N, C, H * W, act);)
+  return launch_status("pp_nhwc_to_nchw");
+}
