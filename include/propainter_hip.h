@@ -80,7 +80,7 @@ typedef struct {
   int32_t pad_mode;              /* 0 = zeros, 1 = replicate (clamp)                           */
   int32_t groups;                /* grid.z; also used as the batch count of a batched GEMM     */
   int32_t cout_g;                /* real output channels per group                             */
-  int32_t cout_pad;              /* rows per group in the packed weights (multiple of 16)      */
+  int32_t cout_pad;              /* rows per group present in `weight` (>= cout_g; extra rows 0) */
   int32_t kchunks;               /* K/8 per group, multiple of 4                               */
   int32_t nsrc;
   pp_conv_src_t src[PP_CONV_MAX_SRC];
@@ -88,7 +88,7 @@ typedef struct {
   const void* weight;            /* device, packed [groups][cout_pad][kchunks*8], dtype        */
   int64_t weight_gstride;        /* elements between groups in `weight` (cout_pad*K normally)  */
   const float* bias;             /* device fp32 [groups*cout_g] or NULL                        */
-  int32_t act;                   /* PP_ACT_* applied to (acc*out_scale + bias)                 */
+  int32_t act;                   /* PP_ACT_* applied to (acc + bias)*out_scale                 */
   float act_param;
   float out_scale;
   const void* residual;          /* optional NHWC tensor added after `act` (dtype = dtype)     */

@@ -1,0 +1,164 @@
+"""Host side of the implicit-GEMM convolution: weight packing, K-chunk tables and launch plumbing.
+
+Activations are NHWC torch tensors ``[N, H, W, Cstride]``; a *source* is ``(tensor, choff)`` = the channel
+window starting at ``choff``.  Channel counts of every source are padded to a multiple of 8 (the K-chunk
+of the kernel); padded channels must hold finite values (zero-initialised buffers) because their packed
+weights are zero.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import hip
+
+ACTS = {None: hip.ACT_NONE, "none": hip.ACT_NONE, "relu": hip.ACT_RELU, "lrelu": hip.ACT_LRELU,
+        "sigmoid": hip.ACT_SIGMOID, "tanh": hip.ACT_TANH, "gelu": hip.ACT_GELU}
+
+
+def pad8(c):
+    return (int(c) + 7) // 8 * 8
+
+
+def _pair(v):
+    return (int(v), int(v)) if isinstance(v, int) else (int(v[0]), int(v[1]))
+
+
+def fold_batchnorm(weight, bias, bn_weight, bn_bias, mean, var, eps=1e-5):
+    """conv followed by eval-mode BatchNorm == conv with scaled weights (RAFT cnet, RAFT/extractor.py:126)."""
+    s = bn_weight.double() / torch.sqrt(var.double() + eps)
+    w = weight.double() * s.view(-1, 1, 1, 1)
+    b = (bias.double() - mean.double()) * s + bn_bias.double()
+    return w.float(), b.float()
+
+
+def pack_weight(weight, src_channels, groups=1, k_multiple=32):
+    """weight [Cout, Cin_g, kh, kw] (any float dtype, CPU or GPU) -> (packed fp32 [groups, cout_pad, K], K, cout_g).
+    K order = (ky, kx, source, channel) with every source padded to a multiple of 8 channels."""
+    w = weight.detach().float()
+    cout, cin_g, kh, kw = w.shape
+    assert sum(src_channels) == cin_g, (src_channels, cin_g)
+    parts, off = [], 0
+    for c in src_channels:
+        part = w[:, off:off + c]
+        if pad8(c) != c:
+            part = torch.cat([part, part.new_zeros(cout, pad8(c) - c, kh, kw)], 1)
+        parts.append(part)
+        off += c
+    w = torch.cat(parts, 1).permute(0, 2, 3, 1).reshape(cout, -1)        # [Cout, kh*kw*Cpad]
+    k_real = w.shape[1]
+    K = (k_real + k_multiple - 1) // k_multiple * k_multiple
+    cout_g = cout // groups
+    cout_pad = (cout_g + 15) // 16 * 16
+    packed = w.new_zeros(groups, cout_pad, K)
+    packed[:, :cout_g, :k_real] = w.view(groups, cout_g, k_real)
+    return packed, K, cout_g
+
+
+class ConvLayer:
+    """One convolution / linear layer prepared for pp_conv2d (weights packed once, on the device)."""
+
+    def __init__(self, weight, bias, *, stride=1, padding=0, dilation=1, groups=1, src_channels=None,
+                 pad_mode="zeros", dtype=torch.float16, device="cuda", taps=None, dcn_groups=0):
+        if weight.dim() == 2:                       # nn.Linear
+            weight = weight[:, :, None, None]
+        cout, cin_g, kh, kw = weight.shape
+        self.stride, self.padding, self.dilation = _pair(stride), _pair(padding), _pair(dilation)
+        self.groups = groups
+        self.kh, self.kw = kh, kw
+        self.src_channels = list(src_channels) if src_channels is not None else [cin_g]
+        self.src_cpad = [pad8(c) for c in self.src_channels]
+        self.pad_mode = 1 if pad_mode == "replicate" else 0
+        self.dtype = dtype
+        packed, K, cout_g = pack_weight(weight, self.src_channels, groups)
+        self.cout_g, self.cout = cout_g, cout
+        self.cout_pad = packed.shape[1]
+        self.K = K
+        self.weight = packed.to(device=device, dtype=dtype).contiguous()
+        self.bias = None if bias is None else bias.detach().float().to(device).contiguous()
+        if taps is None:
+            taps = [(ky * self.dilation[0], kx * self.dilation[1]) for ky in range(kh) for kx in range(kw)]
+        kt = hip.build_ktable(taps, self.src_cpad, dcn_groups)
+        assert kt.shape[0] * 8 == K, (kt.shape, K)
+        self.kchunks = kt.shape[0]
+        self.ktable = torch.from_numpy(kt).to(device)
+        self.dcn = dcn_groups > 0
+
+    def out_hw(self, H, W):
+        OH = (H + 2 * self.padding[0] - self.dilation[0] * (self.kh - 1) - 1) // self.stride[0] + 1
+        OW = (W + 2 * self.padding[1] - self.dilation[1] * (self.kw - 1) - 1) // self.stride[1] + 1
+        return OH, OW
+
+    def __call__(self, srcs, out=None, out_choff=0, act=None, act_param=0.0, out_scale=1.0, residual=None,
+                 res_choff=0, act2=None, out_dtype=None, dcn_offmask=None, out_hw=None):
+        """srcs: list of tensors or (tensor, choff) (NHWC, dtype == layer dtype).  Returns `out` NHWC."""
+        srcs = [(s, 0) if torch.is_tensor(s) else s for s in srcs]
+        assert len(srcs) == len(self.src_channels), (len(srcs), self.src_channels)
+        x0 = srcs[0][0]
+        N, H, W = x0.shape[0], x0.shape[1], x0.shape[2]
+        OH, OW = out_hw if out_hw is not None else self.out_hw(H, W)
+        odt = out_dtype or self.dtype
+        if out is None:
+            cp = pad8(self.cout)
+            out = (torch.zeros if cp != self.cout else torch.empty)((N, OH, OW, cp), dtype=odt, device=x0.device)
+        a = hip.ConvArgs()
+        a.dtype = hip.dtype_code(self.dtype)
+        a.N, a.H, a.W, a.OH, a.OW = N, H, W, OH, OW
+        a.stride_h, a.stride_w = self.stride
+        a.pad_h, a.pad_w = self.padding
+        a.pad_mode = self.pad_mode
+        a.groups, a.cout_g, a.cout_pad, a.kchunks, a.nsrc = self.groups, self.cout_g, self.cout_pad, self.kchunks, len(srcs)
+        for i, (t, choff) in enumerate(srcs):
+            if t.dtype != self.dtype or not t.is_contiguous() or t.shape[:3] != x0.shape[:3]:
+                raise ValueError(f"conv source {i}: dtype {t.dtype} / shape {tuple(t.shape)} incompatible")
+            a.src[i].ptr = t.data_ptr()
+            a.src[i].cstride = t.shape[-1]
+            a.src[i].choff = choff
+            a.src[i].cgroup = self.src_channels[i] if self.groups > 1 else 0
+        a.ktable = self.ktable.data_ptr()
+        a.weight = self.weight.data_ptr()
+        a.weight_gstride = self.cout_pad * self.K
+        a.bias = self.bias.data_ptr() if self.bias is not None else None
+        a.act, a.act_param, a.out_scale = ACTS[act], float(act_param), float(out_scale)
+        if residual is not None:
+            assert residual.dtype == self.dtype and residual.is_contiguous()
+            a.residual, a.res_cstride, a.res_choff = residual.data_ptr(), residual.shape[-1], res_choff
+        a.act2 = ACTS[act2]
+        a.out_dtype = hip.dtype_code(out.dtype)
+        assert out.is_contiguous() and out.shape[:3] == (N, OH, OW)
+        a.out, a.out_cstride, a.out_choff, a.out_cgroup = out.data_ptr(), out.shape[-1], out_choff, self.cout_g
+        if dcn_offmask is not None:
+            assert self.dcn and dcn_offmask.dtype == self.dtype and dcn_offmask.is_contiguous()
+            a.dcn_offmask, a.dcn_cstride, a.dcn_mask_off = dcn_offmask.data_ptr(), dcn_offmask.shape[-1], 288
+        self._keep = (srcs, out, residual, dcn_offmask)
+        hip.conv2d_raw(a)
+        return out
+
+
+_gemm_tables = {}
+
+
+def batched_gemm_nt(a, bt, out_scale=1.0):
+    """out[b, m, n] = out_scale * sum_k a[b, m, k] * bt[b, n, k]   (fp32 output; a, bt same dtype, K % 32 == 0).
+    Used for the RAFT all-pairs correlation volume (RAFT/corr.py:52-60)."""
+    B, M, K = a.shape
+    Bb, Nn, Kb = bt.shape
+    assert B == Bb and K == Kb and K % 32 == 0 and a.dtype == bt.dtype and a.is_contiguous() and bt.is_contiguous()
+    key = (K, str(a.device))
+    if key not in _gemm_tables:
+        _gemm_tables[key] = torch.from_numpy(hip.build_ktable([(0, 0)], [K])).to(a.device)
+    kt = _gemm_tables[key]
+    out = torch.empty((B, M, Nn), dtype=torch.float32, device=a.device)
+    g = hip.ConvArgs()
+    g.dtype = hip.dtype_code(a.dtype)
+    g.N, g.H, g.W, g.OH, g.OW = 1, 1, M, 1, M
+    g.stride_h = g.stride_w = 1
+    g.groups, g.cout_g, g.cout_pad, g.kchunks, g.nsrc = B, Nn, Nn, K // 8, 1
+    g.src[0].ptr, g.src[0].cstride, g.src[0].choff, g.src[0].cgroup = a.data_ptr(), K, 0, 0
+    g.ktable, g.weight, g.weight_gstride = kt.data_ptr(), bt.data_ptr(), Nn * K
+    g.act, g.out_scale, g.act2 = hip.ACT_NONE, float(out_scale), hip.ACT_NONE
+    g.out_dtype = hip.PP_F32
+    g.out, g.out_cstride, g.out_choff, g.out_cgroup = out.data_ptr(), Nn, 0, 0
+    g.src_gstride, g.out_gstride = M * K, M * Nn
+    hip.conv2d_raw(g)
+    return out

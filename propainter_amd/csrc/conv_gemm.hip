@@ -290,9 +290,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float x = acc[a][b][r] * p.out_scale;
+        float x = acc[a][b][r];
         if (p.bias != nullptr && co + r < p.cout_g) x += p.bias[g * p.cout_g + co + r];
-        v[r] = apply_act(x, p.act, p.act_param);
+        v[r] = apply_act(x * p.out_scale, p.act, p.act_param);
       }
       if (p.residual != nullptr) {
         const T* rp = reinterpret_cast<const T*>(p.residual) + m * p.res_cstride + p.res_choff + g * p.out_cgroup + co;
@@ -391,7 +391,7 @@ extern "C" int pp_conv2d(const pp_conv_args_t* a, void* stream) {
              a->groups, a->cout_g);
   PP_REQUIRE(a->nsrc >= 1 && a->nsrc <= PP_CONV_MAX_SRC, PP_ERR_ARG, "pp_conv2d: nsrc %d", a->nsrc);
   PP_REQUIRE(a->kchunks > 0 && a->kchunks % 4 == 0, PP_ERR_ARG, "pp_conv2d: kchunks %d must be a positive multiple of 4", a->kchunks);
-  PP_REQUIRE(a->cout_pad >= a->cout_g && a->cout_pad % 16 == 0, PP_ERR_ARG, "pp_conv2d: cout_pad %d (cout_g %d)", a->cout_pad, a->cout_g);
+  PP_REQUIRE(a->cout_pad >= a->cout_g, PP_ERR_ARG, "pp_conv2d: cout_pad %d (cout_g %d)", a->cout_pad, a->cout_g);
   PP_REQUIRE(a->ktable && a->weight && a->out, PP_ERR_ARG, "pp_conv2d: null ktable/weight/out");
   const int esz = a->dtype == PP_F16 ? 2 : 4;
   for (int s = 0; s < a->nsrc; ++s) {

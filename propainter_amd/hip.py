@@ -1,0 +1,350 @@
+"""ctypes binding of libpropainter_hip.so (the C-ABI declared in include/propainter_hip.h).
+
+There is no CPU fallback: every op below requires the HIP library, and raises if it cannot be
+loaded or if a tensor is not on a GPU.  Tensors are passed as raw ``data_ptr()`` + explicit sizes and
+all work is enqueued on ``torch.cuda.current_stream()``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from . import build as _build
+
+PP_F32, PP_F16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID, ACT_TANH, ACT_GELU = 0, 1, 2, 3, 4, 5
+MAX_SRC = 4
+
+
+class ConvSrc(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("cstride", C.c_int32), ("choff", C.c_int32), ("cgroup", C.c_int32),
+                ("pad_", C.c_int32)]
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32), ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("OH", C.c_int32),
+        ("OW", C.c_int32), ("stride_h", C.c_int32), ("stride_w", C.c_int32), ("pad_h", C.c_int32),
+        ("pad_w", C.c_int32), ("pad_mode", C.c_int32), ("groups", C.c_int32), ("cout_g", C.c_int32),
+        ("cout_pad", C.c_int32), ("kchunks", C.c_int32), ("nsrc", C.c_int32), ("src", ConvSrc * MAX_SRC),
+        ("ktable", C.c_void_p), ("weight", C.c_void_p), ("weight_gstride", C.c_int64), ("bias", C.c_void_p),
+        ("act", C.c_int32), ("act_param", C.c_float), ("out_scale", C.c_float), ("residual", C.c_void_p),
+        ("res_cstride", C.c_int32), ("res_choff", C.c_int32), ("act2", C.c_int32), ("out_dtype", C.c_int32),
+        ("out", C.c_void_p), ("out_cstride", C.c_int32), ("out_choff", C.c_int32), ("out_cgroup", C.c_int32),
+        ("src_gstride", C.c_int64), ("out_gstride", C.c_int64), ("dcn_offmask", C.c_void_p),
+        ("dcn_cstride", C.c_int32), ("dcn_mask_off", C.c_int32),
+    ]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32), ("B", C.c_int32), ("T", C.c_int32), ("Hp", C.c_int32), ("Wp", C.c_int32),
+        ("C", C.c_int32), ("heads", C.c_int32), ("wh", C.c_int32), ("ww", C.c_int32), ("n_rolled", C.c_int32),
+        ("P", C.c_int32), ("n_tind", C.c_int32), ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p),
+        ("qkv_cstride", C.c_int32), ("pk", C.c_void_p), ("pv", C.c_void_p), ("pkv_cstride", C.c_int32),
+        ("own", C.c_void_p), ("rolled", C.c_void_p), ("tind", C.c_void_p), ("wmask", C.c_void_p),
+        ("out", C.c_void_p), ("impl", C.c_int32),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """Loads (building in-tree with hipcc if needed) libpropainter_hip.so.  Raises on failure."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB_PATH
+    if not os.path.exists(path):
+        path = _build.build(verbose=False)
+    L = C.CDLL(path)
+    L.pp_last_error_string.restype = C.c_char_p
+    for name in ("pp_conv2d", "pp_sparse_window_attention"):
+        getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
+    if L.pp_sizeof_conv_args() != C.sizeof(ConvArgs) or L.pp_sizeof_attn_args() != C.sizeof(AttnArgs):
+        raise RuntimeError("libpropainter_hip.so ABI mismatch with propainter_amd/hip.py (struct sizes differ)")
+    _lib = L
+    return L
+
+
+def loaded_library_path():
+    return _build.LIB_PATH if _lib is not None else None
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = lib().pp_last_error_string().decode(errors="replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def dtype_code(dt):
+    if dt == torch.float32:
+        return PP_F32
+    if dt == torch.float16:
+        return PP_F16
+    raise TypeError(f"unsupported dtype {dt} (libpropainter_hip supports float32 and float16)")
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("libpropainter_hip kernels need GPU tensors: there is no CPU fallback in the product path")
+    return C.c_void_p(t.data_ptr())
+
+
+def _i(v):
+    return C.c_int(int(v))
+
+
+def require_gpu(t, who):
+    """The product path has no CPU implementation: modules call this before touching the engine."""
+    if not t.is_cuda:
+        raise RuntimeError(f"{who} runs on the HIP engine only (no CPU path in the product); got a {t.device} tensor")
+
+
+# ----------------------------------------------------------------------------------------------
+# host helpers (no GPU needed)
+# ----------------------------------------------------------------------------------------------
+def build_ktable(taps, src_channels, dcn_groups=0):
+    """taps: list of (dy, dx); src_channels: padded (multiple-of-8) channel count per source.
+    Returns int32 numpy array [kchunks, 4]."""
+    L = lib()
+    n = len(taps)
+    dy = (C.c_int32 * n)(*[int(t[0]) for t in taps])
+    dx = (C.c_int32 * n)(*[int(t[1]) for t in taps])
+    sc = (C.c_int32 * len(src_channels))(*[int(c) for c in src_channels])
+    size = L.pp_conv_build_ktable(n, dy, dx, len(src_channels), sc, int(dcn_groups), None, 0)
+    if size < 0:
+        _check(size, "pp_conv_build_ktable")
+    out = np.zeros((size, 4), dtype=np.int32)
+    rc = L.pp_conv_build_ktable(n, dy, dx, len(src_channels), sc, int(dcn_groups),
+                                out.ctypes.data_as(C.POINTER(C.c_int32)), size)
+    if rc < 0:
+        _check(rc, "pp_conv_build_ktable")
+    return out
+
+
+def window_tables(Hp, Wp, wh=5, ww=9):
+    """Returns (own [nW, wh*ww], rolled [nW, n_rolled]) int32 numpy arrays."""
+    L = lib()
+    n_rolled = L.pp_window_tables(Hp, Wp, wh, ww, None, None, 0)
+    if n_rolled < 0:
+        _check(n_rolled, "pp_window_tables")
+    nW = (Hp // wh) * (Wp // ww)
+    own = np.zeros((nW, wh * ww), dtype=np.int32)
+    rolled = np.zeros((nW, n_rolled), dtype=np.int32)
+    rc = L.pp_window_tables(Hp, Wp, wh, ww, own.ctypes.data_as(C.POINTER(C.c_int32)),
+                            rolled.ctypes.data_as(C.POINTER(C.c_int32)), rolled.size)
+    if rc < 0:
+        _check(rc, "pp_window_tables")
+    return own, rolled
+
+
+# ----------------------------------------------------------------------------------------------
+# device ops
+# ----------------------------------------------------------------------------------------------
+def conv2d_raw(args: ConvArgs):
+    _check(lib().pp_conv2d(C.byref(args), _stream()), "pp_conv2d")
+
+
+def flow_warp(x, flow, out=None, mode="bilinear", x_choff=0, C_=None, fl_choff=0, out_choff=0):
+    """x [N,H,W,Cx] NHWC, flow [N,H,W,>=2] NHWC; warps channels [x_choff, x_choff+C_)."""
+    N, H, W, Cx = x.shape
+    C_ = Cx if C_ is None else C_
+    if out is None:
+        out = torch.empty((N, H, W, C_), dtype=x.dtype, device=x.device)
+    assert x.is_contiguous() and flow.is_contiguous() and out.is_contiguous() and flow.dtype == x.dtype
+    _check(lib().pp_flow_warp(_p(x), _i(Cx), _i(x_choff), _p(flow), _i(flow.shape[-1]), _i(fl_choff), _p(out),
+                              _i(out.shape[-1]), _i(out_choff), _i(N), _i(H), _i(W), _i(C_),
+                              _i(1 if mode == "nearest" else 0), _i(dtype_code(x.dtype)), _stream()), "pp_flow_warp")
+    return out
+
+
+def fb_check(flow_fw, flow_bw, out=None, out_choff=0):
+    """flows NHWC [N,H,W,2(+)]; returns/updates `out` NHWC with the validity map in channel out_choff."""
+    N, H, W, _ = flow_fw.shape
+    if out is None:
+        out = torch.empty((N, H, W, 1), dtype=flow_fw.dtype, device=flow_fw.device)
+    assert flow_fw.is_contiguous() and flow_bw.is_contiguous() and out.is_contiguous()
+    _check(lib().pp_fb_check(_p(flow_fw), _i(flow_fw.shape[-1]), _p(flow_bw), _i(flow_bw.shape[-1]), _p(out),
+                             _i(out.shape[-1]), _i(out_choff), _i(N), _i(H), _i(W), _i(dtype_code(flow_fw.dtype)),
+                             _stream()), "pp_fb_check")
+    return out
+
+
+def img_prop_step(x_prop, m_prop, x_cur, m_cur, flow_prop, flow_check, x_out, m_out, mode="nearest"):
+    """planar NCHW tensors: x [N,C,H,W], m [N,1,H,W], flows [N,2,H,W]."""
+    N, Cc, H, W = x_cur.shape
+    for t in (x_prop, m_prop, x_cur, m_cur, flow_prop, flow_check, x_out, m_out):
+        assert t.is_contiguous() and t.dtype == x_cur.dtype
+    _check(lib().pp_img_prop_step(_p(x_prop), _p(m_prop), _p(x_cur), _p(m_cur), _p(flow_prop), _p(flow_check),
+                                  _p(x_out), _p(m_out), _i(N), _i(Cc), _i(H), _i(W),
+                                  _i(1 if mode == "nearest" else 0), _i(dtype_code(x_cur.dtype)), _stream()),
+           "pp_img_prop_step")
+
+
+def corr_avgpool(x, M, H, W):
+    out = torch.empty((M, H // 2, W // 2), dtype=torch.float32, device=x.device)
+    _check(lib().pp_corr_avgpool(_p(x), _p(out), C.c_int64(M), _i(H), _i(W), _stream()), "pp_corr_avgpool")
+    return out
+
+
+def corr_lookup(levels, coords, out):
+    """levels: 4 fp32 tensors [B*h*w, Hl, Wl]; coords fp32 [B,h,w,2]; out NHWC [B,h,w,Cpad>=324]."""
+    B, h, w, _ = coords.shape
+    assert coords.dtype == torch.float32 and coords.is_contiguous() and out.is_contiguous()
+    _check(lib().pp_corr_lookup(_p(levels[0]), _p(levels[1]), _p(levels[2]), _p(levels[3]), _p(coords), _p(out),
+                                _i(out.shape[-1]), _i(out.shape[-1]), _i(B), _i(h), _i(w), _i(dtype_code(out.dtype)),
+                                _stream()), "pp_corr_lookup")
+    return out
+
+
+def convex_upsample(flow, mask):
+    """flow fp32 [B,h,w,2]; mask NHWC [B,h,w,576(+)] -> fp32 [B,2,8h,8w]."""
+    B, h, w, _ = flow.shape
+    out = torch.empty((B, 2, 8 * h, 8 * w), dtype=torch.float32, device=flow.device)
+    assert flow.dtype == torch.float32 and flow.is_contiguous() and mask.is_contiguous()
+    _check(lib().pp_convex_upsample(_p(flow), _p(mask), _i(mask.shape[-1]), _i(dtype_code(mask.dtype)), _p(out),
+                                    _i(B), _i(h), _i(w), _stream()), "pp_convex_upsample")
+    return out
+
+
+def window_mask(mask, wh=5, ww=9):
+    """mask [B,Lt,Hp,Wp] -> fp32 [B, nW]."""
+    B, Lt, Hp, Wp = mask.shape
+    out = torch.empty((B, (Hp // wh) * (Wp // ww)), dtype=torch.float32, device=mask.device)
+    assert mask.is_contiguous()
+    _check(lib().pp_window_mask(_p(mask), _p(out), _i(B), _i(Lt), _i(Hp), _i(Wp), _i(wh), _i(ww),
+                                _i(dtype_code(mask.dtype)), _stream()), "pp_window_mask")
+    return out
+
+
+def sparse_window_attention(q, k, v, pk, pv, own, rolled, tind, wmask, heads=4, wh=5, ww=9, qkv_cstride=None,
+                            pkv_cstride=None, C_=None, impl=0):
+    """q/k/v: [B,T,Hp,Wp,*] token grids (possibly channel windows of one fused buffer: pass cstride);
+    pk/pv: [B,T,P,*]; returns [B,T,Hp,Wp,C]."""
+    B, T, Hp, Wp = q.shape[:4]
+    C_ = q.shape[-1] if C_ is None else C_
+    a = AttnArgs()
+    a.dtype = dtype_code(q.dtype)
+    a.B, a.T, a.Hp, a.Wp, a.C, a.heads, a.wh, a.ww = B, T, Hp, Wp, C_, heads, wh, ww
+    a.n_rolled = rolled.shape[1]
+    a.P = pk.shape[2] if pk is not None else 0
+    a.n_tind = tind.numel()
+    a.q, a.k, a.v = q.data_ptr(), k.data_ptr(), v.data_ptr()
+    a.qkv_cstride = qkv_cstride if qkv_cstride is not None else q.shape[-1]
+    a.pk = pk.data_ptr() if pk is not None else None
+    a.pv = pv.data_ptr() if pv is not None else None
+    a.pkv_cstride = pkv_cstride if pkv_cstride is not None else (pk.shape[-1] if pk is not None else 0)
+    a.own, a.rolled, a.tind, a.wmask = own.data_ptr(), rolled.data_ptr(), tind.data_ptr(), wmask.data_ptr()
+    out = torch.empty((B, T, Hp, Wp, C_), dtype=q.dtype, device=q.device)
+    a.out = out.data_ptr()
+    a.impl = impl
+    for t in (q, k, v, own, rolled, tind, wmask):
+        if not t.is_cuda:
+            raise RuntimeError("sparse_window_attention needs GPU tensors")
+    assert own.dtype == torch.int32 and rolled.dtype == torch.int32 and tind.dtype == torch.int32
+    _check(lib().pp_sparse_window_attention(C.byref(a), _stream()), "pp_sparse_window_attention")
+    return out
+
+
+def fold_tokens(tokens, BT, fh, fw, Cc, H, W, normalize=False, act=ACT_NONE):
+    """tokens [BT, fh*fw, Cc*49] -> NHWC [BT,H,W,Cc]."""
+    out = torch.empty((BT, H, W, Cc), dtype=tokens.dtype, device=tokens.device)
+    assert tokens.is_contiguous()
+    _check(lib().pp_fold_tokens(_p(tokens), _p(out), _i(BT), _i(fh), _i(fw), _i(Cc), _i(H), _i(W),
+                                _i(1 if normalize else 0), _i(act), _i(dtype_code(tokens.dtype)), _stream()),
+           "pp_fold_tokens")
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    """x [..., C] contiguous; gamma/beta fp32."""
+    Cc = x.shape[-1]
+    out = torch.empty_like(x)
+    assert x.is_contiguous() and gamma.dtype == torch.float32 and beta.dtype == torch.float32
+    _check(lib().pp_layernorm(_p(x), _p(gamma), _p(beta), _p(out), C.c_int64(x.numel() // Cc), _i(Cc),
+                              C.c_float(eps), _i(dtype_code(x.dtype)), _stream()), "pp_layernorm")
+    return out
+
+
+def depthwise_pool(x, weight, bias, k=4):
+    """x NHWC [N,H,W,C]; weight fp32 [C,k,k]; bias fp32 [C]."""
+    N, H, W, Cc = x.shape
+    out = torch.empty((N, H // k, W // k, Cc), dtype=x.dtype, device=x.device)
+    assert x.is_contiguous() and weight.dtype == torch.float32
+    _check(lib().pp_depthwise_pool(_p(x), _p(weight), _p(bias), _p(out), _i(N), _i(H), _i(W), _i(Cc), _i(k),
+                                   _i(dtype_code(x.dtype)), _stream()), "pp_depthwise_pool")
+    return out
+
+
+def instance_norm(x, relu=False, eps=1e-5, out=None):
+    N, H, W, Cc = x.shape
+    out = torch.empty_like(x) if out is None else out
+    ws = torch.empty((N * Cc * 2,), dtype=torch.float32, device=x.device)
+    assert x.is_contiguous()
+    _check(lib().pp_instance_norm(_p(x), _p(out), _p(ws), _i(N), _i(H), _i(W), _i(Cc), C.c_float(eps),
+                                  _i(1 if relu else 0), _i(dtype_code(x.dtype)), _stream()), "pp_instance_norm")
+    return out
+
+
+def upsample2x(x):
+    N, H, W, Cc = x.shape
+    out = torch.empty((N, 2 * H, 2 * W, Cc), dtype=x.dtype, device=x.device)
+    assert x.is_contiguous()
+    _check(lib().pp_upsample2x(_p(x), _p(out), _i(N), _i(H), _i(W), _i(Cc), _i(dtype_code(x.dtype)), _stream()),
+           "pp_upsample2x")
+    return out
+
+
+def dcn_offset_mask_act(offmask, mag, flow=None, fl_choff=0):
+    """in place on NHWC [N,H,W,432(+pad)]."""
+    npix = offmask.numel() // offmask.shape[-1]
+    assert offmask.is_contiguous() and (flow is None or (flow.is_contiguous() and flow.dtype == offmask.dtype))
+    _check(lib().pp_dcn_offset_mask_act(_p(offmask), _i(offmask.shape[-1]), _p(flow),
+                                        _i(flow.shape[-1] if flow is not None else 0), _i(fl_choff), C.c_float(mag),
+                                        C.c_int64(npix), _i(dtype_code(offmask.dtype)), _stream()),
+           "pp_dcn_offset_mask_act")
+    return offmask
+
+
+def gru_gate(zr, h, h_choff, Cc, out, out_choff, q=None):
+    """mode 0 (q is None): out = r*h with r = zr[..., C:2C]; mode 1: out = (1-z)*h + z*q, z = zr[..., :C]."""
+    npix = zr.numel() // zr.shape[-1]
+    _check(lib().pp_gru_gate(_p(zr), _i(zr.shape[-1]), _p(h), _i(h.shape[-1]), _i(h_choff), _p(q),
+                             _i(q.shape[-1] if q is not None else 0), _p(out), _i(out.shape[-1]), _i(out_choff),
+                             C.c_int64(npix), _i(Cc), _i(0 if q is None else 1), _i(dtype_code(zr.dtype)), _stream()),
+           "pp_gru_gate")
+    return out
+
+
+def nchw_to_nhwc(x, out=None, out_choff=0, out_dtype=None, cpad=None, scale=1.0):
+    """x planar [N,C,H,W] -> NHWC window of `out` (allocated zero-filled [N,H,W,cpad] if None)."""
+    N, Cc, H, W = x.shape
+    if out is None:
+        cpad = cpad or ((Cc + 7) // 8 * 8)
+        dt = out_dtype or x.dtype
+        out = (torch.zeros if cpad != Cc else torch.empty)((N, H, W, cpad), dtype=dt, device=x.device)
+    assert x.is_contiguous() and out.is_contiguous()
+    _check(lib().pp_nchw_to_nhwc(_p(x), _i(dtype_code(x.dtype)), _p(out), _i(dtype_code(out.dtype)),
+                                 _i(out.shape[-1]), _i(out_choff), _i(N), _i(Cc), _i(H), _i(W), C.c_float(scale),
+                                 _stream()), "pp_nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(x, Cc=None, choff=0, out_dtype=None, act=ACT_NONE):
+    N, H, W, Cs = x.shape
+    Cc = Cs if Cc is None else Cc
+    out = torch.empty((N, Cc, H, W), dtype=out_dtype or x.dtype, device=x.device)
+    assert x.is_contiguous()
+    _check(lib().pp_nhwc_to_nchw(_p(x), _i(dtype_code(x.dtype)), _i(Cs), _i(choff), _p(out),
+                                 _i(dtype_code(out.dtype)), _i(N), _i(Cc), _i(H), _i(W), _i(act), _stream()),
+           "pp_nhwc_to_nchw")
+    return out

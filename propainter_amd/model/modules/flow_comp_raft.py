@@ -1,0 +1,224 @@
+"""RAFT optical flow on the MI355X engine, behind the reference's ``RAFT_bi`` interface.
+
+Drop-in for ``model/modules/flow_comp_raft.py:27-55`` (reference): ``RAFT_bi(model_path, device)`` and
+``forward(gt_local_frames[b,l_t,3,h,w], iters=20) -> (flows_f, flows_b)`` each ``[b,l_t-1,2,h,w]``; state-dict keys
+are the reference's (``fix_raft.fnet.conv1.weight`` ...; the checkpoint file carries a ``module.`` prefix,
+``flow_comp_raft.py:18-20``).  Only the configuration the reference instantiates is built
+(small=False, alternate_corr=False; RAFT/raft.py:36-56).
+
+Exact-math savings over the reference call pattern (results unchanged): the feature / context encoders run once
+per frame instead of 3x per pair-direction; the convex-upsampling mask head runs only on the last iteration
+(RAFT/raft.py:143-144 discards the rest); all pair-directions of a clip advance through the GRU as one batch.
+"""
+import torch
+import torch.nn as nn
+
+from ... import hip
+from ...conv import ConvLayer, batched_gemm_nt, fold_batchnorm
+from ...param_tree import ParamTree, conv_entries, norm_entries, populate
+
+
+def _encoder_schema(prefix, out_dim, batchnorm):
+    e = conv_entries(f"{prefix}.conv1", 64, 3, 7)
+    if batchnorm:
+        e += norm_entries(f"{prefix}.norm1", 64, running=True)
+    cin = 64
+    for li, (dim, stride) in enumerate(((64, 1), (96, 2), (128, 2)), start=1):
+        for bi in range(2):
+            p = f"{prefix}.layer{li}.{bi}"
+            s = stride if bi == 0 else 1
+            e += conv_entries(f"{p}.conv1", dim, cin, 3) + conv_entries(f"{p}.conv2", dim, dim, 3)
+            if batchnorm:
+                e += norm_entries(f"{p}.norm1", dim, True) + norm_entries(f"{p}.norm2", dim, True)
+            if s != 1:
+                if batchnorm:
+                    e += norm_entries(f"{p}.norm3", dim, True)
+                e += conv_entries(f"{p}.downsample.0", dim, cin, 1)
+                if batchnorm:
+                    e += norm_entries(f"{p}.downsample.1", dim, True)
+            cin = dim
+    e += conv_entries(f"{prefix}.conv2", out_dim, 128, 1)
+    return e
+
+
+def raft_schema(prefix=""):
+    """Key/shape list of the reference RAFT (RAFT/raft.py:36-56, extractor.py:118-166, update.py:79-125)."""
+    p = prefix
+    e = _encoder_schema(f"{p}fnet", 256, False) + _encoder_schema(f"{p}cnet", 256, True)
+    u = f"{p}update_block"
+    e += conv_entries(f"{u}.encoder.convc1", 256, 324, 1) + conv_entries(f"{u}.encoder.convc2", 192, 256, 3)
+    e += conv_entries(f"{u}.encoder.convf1", 128, 2, 7) + conv_entries(f"{u}.encoder.convf2", 64, 128, 3)
+    e += conv_entries(f"{u}.encoder.conv", 126, 256, 3)
+    for g in "zrq":
+        e += conv_entries(f"{u}.gru.conv{g}1", 128, 384, 1, 5)
+    for g in "zrq":
+        e += conv_entries(f"{u}.gru.conv{g}2", 128, 384, 5, 1)
+    e += conv_entries(f"{u}.flow_head.conv1", 256, 128, 3) + conv_entries(f"{u}.flow_head.conv2", 2, 256, 3)
+    e += conv_entries(f"{u}.mask.0", 256, 128, 3) + conv_entries(f"{u}.mask.2", 576, 256, 1)
+    return e
+
+
+class _RaftEngine:
+    """Packed layers for one (dtype, device)."""
+
+    def __init__(self, sd, dtype, device):
+        self.dtype, self.device = dtype, device
+        mk = lambda w, b, **kw: ConvLayer(w, b, dtype=dtype, device=device, **kw)
+
+        def enc(prefix, bn):
+            def cv(name, norm=None, **kw):
+                w, b = sd[f"{prefix}.{name}.weight"], sd[f"{prefix}.{name}.bias"]
+                if bn and norm is not None:
+                    n = f"{prefix}.{norm}"
+                    w, b = fold_batchnorm(w, b, sd[n + ".weight"], sd[n + ".bias"], sd[n + ".running_mean"],
+                                          sd[n + ".running_var"])
+                return mk(w, b, **kw)
+            L = {"conv1": cv("conv1", "norm1", stride=2, padding=3, src_channels=[3])}
+            for li, stride in ((1, 1), (2, 2), (3, 2)):
+                for bi in range(2):
+                    p = f"layer{li}.{bi}"
+                    s = stride if bi == 0 else 1
+                    L[p + ".conv1"] = cv(p + ".conv1", p + ".norm1", stride=s, padding=1)
+                    L[p + ".conv2"] = cv(p + ".conv2", p + ".norm2", padding=1)
+                    if s != 1:
+                        L[p + ".down"] = cv(p + ".downsample.0", p + ".downsample.1", stride=s)
+            L["conv2"] = cv("conv2")
+            return L
+
+        self.fnet = enc("fnet", False)
+        self.cnet = enc("cnet", True)
+        u = "update_block."
+        g = lambda n: (sd[u + n + ".weight"], sd[u + n + ".bias"])
+        self.convc1 = mk(*g("encoder.convc1"), src_channels=[324])
+        self.convc2 = mk(*g("encoder.convc2"), padding=1)
+        self.convf1 = mk(*g("encoder.convf1"), padding=3, src_channels=[2])
+        self.convf2 = mk(*g("encoder.convf2"), padding=1)
+        self.convm = mk(*g("encoder.conv"), padding=1, src_channels=[192, 64])
+        self.gru = []
+        for s, pad in (("1", (0, 2)), ("2", (2, 0))):
+            wz, bz = g("gru.convz" + s)
+            wr, br = g("gru.convr" + s)
+            zr = mk(torch.cat([wz, wr], 0), torch.cat([bz, br], 0), padding=pad, src_channels=[128, 256])
+            q = mk(*g("gru.convq" + s), padding=pad, src_channels=[128, 256])
+            self.gru.append((zr, q))
+        self.fh1 = mk(*g("flow_head.conv1"), padding=1)
+        self.fh2 = mk(*g("flow_head.conv2"), padding=1)
+        self.mask0 = mk(*g("mask.0"), padding=1)
+        self.mask2 = mk(*g("mask.2"))
+
+    # ---- encoders (RAFT/extractor.py:168-192); x NHWC [n,H,W,8] -> [n,H/8,W/8,256]
+    def encode(self, L, x, instance_norm):
+        def block(x, p, down):
+            if instance_norm:
+                y = hip.instance_norm(L[p + ".conv1"]([x]), relu=True)
+                y = hip.instance_norm(L[p + ".conv2"]([y]), relu=True)
+                if down:
+                    x = hip.instance_norm(L[p + ".down"]([x]), relu=False)
+                return torch.relu_(y.add_(x))
+            y = L[p + ".conv1"]([x], act="relu")
+            if down:
+                x = L[p + ".down"]([x])
+            return L[p + ".conv2"]([y], act="relu", residual=x, act2="relu")
+        if instance_norm:
+            x = hip.instance_norm(L["conv1"]([x]), relu=True)
+        else:
+            x = L["conv1"]([x], act="relu")
+        for li in (1, 2, 3):
+            x = block(x, f"layer{li}.0", li > 1)
+            x = block(x, f"layer{li}.1", False)
+        return L["conv2"]([x])
+
+    # ---- iterative update for a batch of pair-directions
+    def refine(self, f1, f2, ctx, iters):
+        """f1, f2, ctx: NHWC [P,h,w,256].  Returns fp32 flow_up [P,2,8h,8w]."""
+        P, h, w, _ = f1.shape
+        dev, dt = f1.device, self.dtype
+        n8 = h * w
+        # all-pairs correlation volume + pyramid (RAFT/corr.py:13-27,52-60), fp32
+        vol = batched_gemm_nt(f1.view(P, n8, 256), f2.view(P, n8, 256), out_scale=1.0 / 16.0)
+        levels = [vol.view(P * n8, h, w)]
+        hh, ww = h, w
+        for _ in range(3):
+            levels.append(hip.corr_avgpool(levels[-1], P * n8, hh, ww))
+            hh, ww = hh // 2, ww // 2
+        net = torch.tanh(ctx[..., :128]).contiguous()
+        xbuf = torch.empty((P, h, w, 256), dtype=dt, device=dev)           # [inp | motion(126) | flow(2)]
+        xbuf[..., :128] = torch.relu(ctx[..., 128:])
+        ys, xs = torch.meshgrid(torch.arange(h, device=dev, dtype=torch.float32),
+                                torch.arange(w, device=dev, dtype=torch.float32), indexing="ij")
+        coords0 = torch.stack([xs, ys], -1)[None].expand(P, h, w, 2).contiguous()
+        coords1 = coords0.clone()
+        corr = torch.empty((P, h, w, 328), dtype=dt, device=dev)
+        flow8 = torch.zeros((P, h, w, 8), dtype=dt, device=dev)
+        zr = torch.empty((P, h, w, 256), dtype=dt, device=dev)
+        rh = torch.empty((P, h, w, 128), dtype=dt, device=dev)
+        delta = torch.zeros((P, h, w, 8), dtype=torch.float32, device=dev)
+        for it in range(iters):
+            hip.corr_lookup(levels, coords1, corr)
+            flow = coords1 - coords0
+            flow8[..., :2] = flow
+            xbuf[..., 254:] = flow
+            cor = self.convc2([self.convc1([corr], act="relu")], act="relu")
+            flo = self.convf2([self.convf1([flow8], act="relu")], act="relu")
+            self.convm([cor, flo], out=xbuf, out_choff=128, act="relu")
+            for zr_l, q_l in self.gru:                                   # SepConvGRU (RAFT/update.py:45-60)
+                zr_l([net, xbuf], out=zr, act="sigmoid")
+                hip.gru_gate(zr, net, 0, 128, rh, 0)
+                q = q_l([rh, xbuf], act="tanh")
+                hip.gru_gate(zr, net, 0, 128, net, 0, q=q)
+            self.fh2([self.fh1([net], act="relu")], out=delta, out_dtype=torch.float32)
+            coords1 = coords1 + delta[..., :2]
+        mask = self.mask2([self.mask0([net], act="relu")], out_scale=0.25)
+        return hip.convex_upsample((coords1 - coords0).contiguous(), mask)
+
+
+class RAFT_bi(nn.Module):
+    """Bidirectional RAFT flow of consecutive frame pairs (reference: model/modules/flow_comp_raft.py:27-55)."""
+
+    def __init__(self, model_path='weights/raft-things.pth', device='cuda', compute_dtype=None, max_pairs=None):
+        super().__init__()
+        self.fix_raft = ParamTree()
+        populate(self.fix_raft, raft_schema())
+        if model_path is not None:
+            ckpt = torch.load(model_path, map_location='cpu')
+            ckpt = {(k[len('module.'):] if k.startswith('module.') else k): v for k, v in ckpt.items()}
+            self.fix_raft.load_state_dict(ckpt, strict=True)
+        for p in self.parameters():
+            p.requires_grad = False
+        self.compute_dtype = compute_dtype     # None: follow the input dtype (the reference keeps RAFT in fp32)
+        self.max_pairs = max_pairs
+        self._engine = None
+        self.to(device)
+        self.eval()
+
+    def _get_engine(self, dtype, device):
+        key = (dtype, str(device), sum(p._version for p in self.parameters()))
+        if self._engine is None or self._engine[0] != key:
+            sd = {k: v.detach().float().cpu() for k, v in self.fix_raft.state_dict().items()}
+            self._engine = (key, _RaftEngine(sd, dtype, device))
+        return self._engine[1]
+
+    @torch.no_grad()
+    def forward(self, gt_local_frames, iters=20):
+        b, l_t, c, h, w = gt_local_frames.size()
+        hip.require_gpu(gt_local_frames, "RAFT_bi")
+        if h % 8 or w % 8 or h < 128 or w < 128:
+            raise ValueError(f"RAFT needs H, W multiples of 8 and >= 128 (got {h}x{w}; RAFT/utils/utils.py:61-62)")
+        dt = self.compute_dtype or gt_local_frames.dtype
+        eng = self._get_engine(dt, gt_local_frames.device)
+        x = hip.nchw_to_nhwc(gt_local_frames.reshape(b * l_t, c, h, w).contiguous(), out_dtype=dt, cpad=8)
+        fmap = eng.encode(eng.fnet, x, True).view(b, l_t, h // 8, w // 8, 256)
+        ctx = eng.encode(eng.cnet, x, False).view(b, l_t, h // 8, w // 8, 256)
+        a_f, a_b = fmap[:, :-1].reshape(-1, h // 8, w // 8, 256), fmap[:, 1:].reshape(-1, h // 8, w // 8, 256)
+        c_f, c_b = ctx[:, :-1].reshape(-1, h // 8, w // 8, 256), ctx[:, 1:].reshape(-1, h // 8, w // 8, 256)
+        f1 = torch.cat([a_f, a_b], 0)
+        f2 = torch.cat([a_b, a_f], 0)
+        cx = torch.cat([c_f, c_b], 0)
+        P = f1.shape[0]
+        n8 = (h // 8) * (w // 8)
+        chunk = self.max_pairs or max(1, int(24e9 // (n8 * n8 * 4 * 1.34)))
+        ups = [eng.refine(f1[i:i + chunk].contiguous(), f2[i:i + chunk].contiguous(), cx[i:i + chunk].contiguous(), iters)
+               for i in range(0, P, chunk)]
+        up = torch.cat(ups, 0).to(gt_local_frames.dtype)
+        half = P // 2
+        return up[:half].view(b, l_t - 1, 2, h, w), up[half:].view(b, l_t - 1, 2, h, w)

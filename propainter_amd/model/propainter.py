@@ -1,0 +1,363 @@
+"""ProPainter generator on the MI355X engine, behind the reference's ``InpaintGenerator`` interface.
+
+Drop-in for ``model/propainter.py:256-372`` (reference): ``InpaintGenerator(init_weights=True, model_path=None)``,
+``img_propagation(masked_frames, completed_flows, masks, interpolation='nearest')`` and
+``forward(masked_frames, completed_flows, masks_in, masks_updated, num_local_frames, interpolation='bilinear',
+t_dilation=2)``; identical state-dict keys (incl. the ``valid_ind_rolled`` buffers).
+
+Engine notes (all algebraically identical to the reference, see oracle/propainter_oracle.py):
+  * SoftSplit = unfold(7,3,3) + Linear  ==  one 7x7/stride-3 implicit-GEMM convolution (no 1.45 GB unfold);
+  * FusionFeedForward: fc1 GEMM -> fused fold/normalise/GELU gather -> fc2 as a 7x7/stride-3 convolution over the
+    40-channel folded map (GELU commutes with the zero-padded unfold);
+  * sparse window attention gathers rolled / pooled keys through index tables instead of materialising them, and
+    reads the masked-window flags on the device (no nonzero() host sync);
+  * q/k/v (and pooled k/v) projections are single fused GEMMs; every torch.cat of the reference is a multi-source
+    convolution; forward-backward consistency checks of all propagation steps run as one batched launch.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import hip
+from ..conv import ConvLayer
+from ..param_tree import ParamTree, conv_entries, linear_entries, populate
+
+WIN = (5, 9)
+HEADS = 4
+HIDDEN = 512
+DEPTH = 8
+
+
+def token_grid(n):
+    """model/modules/sparse_transformer.py:20-23 (kernel 7, stride 3, padding 3)."""
+    return int((n + 2 * 3 - 6 - 1) / 3 + 1)
+
+
+def generator_schema():
+    e = []
+    enc = ((0, 64, 5), (2, 64, 64), (4, 128, 64), (6, 256, 128), (8, 384, 256), (10, 512, 640 // 2), (12, 384, 768 // 4),
+           (14, 256, 640 // 8), (16, 128, 512))
+    for idx, cout, cin in enc:
+        e += conv_entries(f"encoder.layers.{idx}", cout, cin, 3)
+    e += conv_entries("decoder.0.conv", 128, 128, 3) + conv_entries("decoder.2", 64, 128, 3)
+    e += conv_entries("decoder.4.conv", 64, 64, 3) + conv_entries("decoder.6", 3, 64, 3)
+    e += linear_entries("ss.embedding", HIDDEN, 128 * 49)
+    e += linear_entries("sc.embedding", 128 * 49, HIDDEN) + conv_entries("sc.bias_conv", 128, 128, 3)
+    fp = "feat_prop_module"
+    for m in ("backward_1", "forward_1"):
+        d = f"{fp}.deform_align.{m}"
+        e += [(f"{d}.weight", (128, 128, 3, 3), "w"), (f"{d}.bias", (128,), "b")]
+        e += conv_entries(f"{d}.conv_offset.0", 128, 2 * 128 + 2 + 1 + 2, 3)
+        e += conv_entries(f"{d}.conv_offset.2", 128, 128, 3) + conv_entries(f"{d}.conv_offset.4", 128, 128, 3)
+        e += conv_entries(f"{d}.conv_offset.6", 432, 128, 3)
+        e += conv_entries(f"{fp}.backbone.{m}.0", 128, 258, 3) + conv_entries(f"{fp}.backbone.{m}.2", 128, 128, 3)
+    e += conv_entries(f"{fp}.fuse.0", 128, 258, 3) + conv_entries(f"{fp}.fuse.2", 128, 128, 3)
+    for i in range(DEPTH):
+        t = f"transformers.transformer.{i}"
+        for n in ("key", "query", "value", "proj"):
+            e += linear_entries(f"{t}.attention.{n}", HIDDEN, HIDDEN)
+        e += [(f"{t}.attention.pool_layer.weight", (HIDDEN, 1, 4, 4), "w"), (f"{t}.attention.pool_layer.bias", (HIDDEN,), "b")]
+        e += [(f"{t}.norm1.weight", (HIDDEN,), "one"), (f"{t}.norm1.bias", (HIDDEN,), "zero"),
+              (f"{t}.norm2.weight", (HIDDEN,), "one"), (f"{t}.norm2.bias", (HIDDEN,), "zero")]
+        e += linear_entries(f"{t}.mlp.fc1.0", 1960, HIDDEN) + linear_entries(f"{t}.mlp.fc2.1", HIDDEN, 1960)
+    return e
+
+
+class _GenEngine:
+    def __init__(self, sd, dtype, device):
+        self.dtype, self.device = dtype, device
+        mk = lambda w, b, **kw: ConvLayer(w, b, dtype=dtype, device=device, **kw)
+        g = lambda n: (sd[n + ".weight"], sd[n + ".bias"])
+        E = "encoder.layers."
+        self.enc = [mk(*g(E + "0"), stride=2, padding=1, src_channels=[5]), mk(*g(E + "2"), padding=1),
+                    mk(*g(E + "4"), stride=2, padding=1), mk(*g(E + "6"), padding=1), mk(*g(E + "8"), padding=1)]
+        # grouped layers consume the group-wise interleave of x0 (256 ch) and the running feature (:226-230)
+        self.enc_g = []
+        prev_c = 384
+        for idx, groups in ((10, 2), (12, 4), (14, 8), (16, 1)):
+            w, b = g(E + str(idx))
+            self.enc_g.append(mk(w, b, padding=1, groups=groups, src_channels=[256 // groups, prev_c // groups]))
+            prev_c = w.shape[0]
+        self.dec = [mk(*g("decoder.0.conv"), padding=1), mk(*g("decoder.2"), padding=1),
+                    mk(*g("decoder.4.conv"), padding=1), mk(*g("decoder.6"), padding=1)]
+        self.ss = mk(sd["ss.embedding.weight"].view(HIDDEN, 128, 7, 7), sd["ss.embedding.bias"], stride=3, padding=3)
+        self.sc_embed = mk(*g("sc.embedding"))
+        self.sc_bias = mk(*g("sc.bias_conv"), padding=1)
+        fp = "feat_prop_module."
+        self.prop = {}
+        for m in ("backward_1", "forward_1"):
+            d = fp + f"deform_align.{m}"
+            self.prop[m] = dict(
+                off0=mk(*g(d + ".conv_offset.0"), padding=1, src_channels=[128, 128, 5]),
+                off2=mk(*g(d + ".conv_offset.2"), padding=1),
+                off4=mk(*g(d + ".conv_offset.4"), padding=1),
+                off6=mk(*g(d + ".conv_offset.6"), padding=1),
+                dcn=mk(sd[d + ".weight"], sd[d + ".bias"], padding=1, dcn_groups=16),
+                bb0=mk(*g(fp + f"backbone.{m}.0"), padding=1, src_channels=[128, 128, 2]),
+                bb2=mk(*g(fp + f"backbone.{m}.2"), padding=1))
+        self.fuse0 = mk(*g(fp + "fuse.0"), padding=1, src_channels=[128, 128, 2])
+        self.fuse2 = mk(*g(fp + "fuse.2"), padding=1)
+        self.blocks = []
+        f32 = lambda t: t.float().to(device).contiguous()
+        for i in range(DEPTH):
+            t = f"transformers.transformer.{i}."
+            a = t + "attention."
+            qkv_w = torch.cat([sd[a + "query.weight"], sd[a + "key.weight"], sd[a + "value.weight"]], 0)
+            qkv_b = torch.cat([sd[a + "query.bias"], sd[a + "key.bias"], sd[a + "value.bias"]], 0)
+            kv_w = torch.cat([sd[a + "key.weight"], sd[a + "value.weight"]], 0)
+            kv_b = torch.cat([sd[a + "key.bias"], sd[a + "value.bias"]], 0)
+            self.blocks.append(dict(
+                n1=(f32(sd[t + "norm1.weight"]), f32(sd[t + "norm1.bias"])),
+                n2=(f32(sd[t + "norm2.weight"]), f32(sd[t + "norm2.bias"])),
+                qkv=mk(qkv_w, qkv_b), kv=mk(kv_w, kv_b), proj=mk(*g(a + "proj")),
+                pool_w=f32(sd[a + "pool_layer.weight"].view(HIDDEN, 4, 4)), pool_b=f32(sd[a + "pool_layer.bias"]),
+                fc1=mk(*g(t + "mlp.fc1.0")),
+                fc2=mk(sd[t + "mlp.fc2.1.weight"].view(HIDDEN, 40, 7, 7), sd[t + "mlp.fc2.1.bias"], stride=3, padding=3)))
+        self._win_cache = {}
+
+    # ------------------------------------------------------------------ encoder / decoder
+    def encode(self, x):
+        """Encoder.forward (:218-232); x NHWC [n,H,W,8] -> [n,H/4,W/4,128]."""
+        for layer in self.enc[:4]:
+            x = layer([x], act="lrelu", act_param=0.2)
+        x0 = x
+        out = self.enc[4]([x0], act="lrelu", act_param=0.2)
+        for layer in self.enc_g:
+            out = layer([x0, out], act="lrelu", act_param=0.2)
+        return out
+
+    def decode(self, x):
+        """decoder (:266-273) + tanh (:370); x [n,h,w,128] -> planar [n,3,4h,4w]."""
+        x = self.dec[0]([hip.upsample2x(x)], act="lrelu", act_param=0.2)
+        x = self.dec[1]([x], act="lrelu", act_param=0.2)
+        x = self.dec[2]([hip.upsample2x(x)], act="lrelu", act_param=0.2)
+        x = self.dec[3]([x], act="tanh")
+        return hip.nhwc_to_nchw(x, 3)
+
+    # ------------------------------------------------------------------ feature propagation (:104-190, learnable)
+    def feature_propagation(self, x, flows_f, flows_b, mask2):
+        """x [t,h,w,128]; flows_* [t-1,h,w,2] NHWC (1/4-res, already /4); mask2 [t,h,w,2] -> fused [t,h,w,128]."""
+        t, h, w, c = x.shape
+        dev, dt = x.device, self.dtype
+        mk8 = torch.zeros((t, h, w, 8), dtype=dt, device=dev)
+        mk8[..., :2] = mask2
+        feats = {"input": x}
+        prev_name = "input"
+        for name in ("backward_1", "forward_1"):
+            L = self.prop[name]
+            if name == "backward_1":
+                order = list(range(t - 1, -1, -1))
+                fidx = order                               # flow index of step i (i >= 1) is order[i]
+                f_prop, f_chk = flows_f, flows_b
+            else:
+                order = list(range(t))
+                fidx = [None] + list(range(0, t - 1))
+                f_prop, f_chk = flows_b, flows_f
+            cur_all = feats[prev_name]
+            outs = torch.empty((t, h, w, c), dtype=dt, device=dev)
+            if t > 1:
+                # aux[i-1] = [flow_prop(2) | valid(1) | mask_cur(2) | 0 0 0] for step i; all fb checks in one launch
+                sel_f = torch.tensor([fidx[i] for i in range(1, t)], device=dev)
+                sel_m = torch.tensor([order[i] for i in range(1, t)], device=dev)
+                aux = torch.zeros((t - 1, h, w, 8), dtype=dt, device=dev)
+                aux[..., :2] = f_prop[sel_f]
+                aux[..., 3:5] = mask2[sel_m]
+                chk = f_chk[sel_f].contiguous()
+                hip.fb_check(aux, chk, out=aux, out_choff=2)
+            prop = None
+            for i, idx in enumerate(order):
+                cur = cur_all[idx:idx + 1]
+                if i == 0:
+                    prop = cur
+                else:
+                    ax = aux[i - 1:i]
+                    warped = hip.flow_warp(prop, ax, mode="bilinear")
+                    o = L["off0"]([cur, warped, ax], act="lrelu", act_param=0.1)
+                    o = L["off2"]([o], act="lrelu", act_param=0.1)
+                    o = L["off4"]([o], act="lrelu", act_param=0.1)
+                    om = L["off6"]([o])
+                    hip.dcn_offset_mask_act(om, 3.0, flow=ax)
+                    prop = L["dcn"]([prop], dcn_offmask=om)
+                y = L["bb0"]([cur, prop, mk8[idx:idx + 1]], act="lrelu", act_param=0.2)
+                L["bb2"]([y], out=outs[idx:idx + 1], residual=prop)
+                prop = outs[idx:idx + 1]
+            feats[name] = outs
+            prev_name = name
+        y = self.fuse0([feats["backward_1"], feats["forward_1"], mk8], act="lrelu", act_param=0.2)
+        return self.fuse2([y], residual=x)
+
+    # ------------------------------------------------------------------ transformer
+    def _window_tables(self, Hp, Wp):
+        key = (Hp, Wp)
+        if key not in self._win_cache:
+            own, rolled = hip.window_tables(Hp, Wp, *WIN)
+            self._win_cache[key] = (torch.from_numpy(own).to(self.device), torch.from_numpy(rolled).to(self.device))
+        return self._win_cache[key]
+
+    def transformer(self, tok, size, token_mask, t_dilation=2):
+        """TemporalSparseTransformerBlock (:328-344); tok [t,fh,fw,512]; token_mask [l_t,fh,fw] -> [t,fh,fw,512]."""
+        t, fh, fw, c = tok.shape
+        h, w = size
+        dev, dt = tok.device, self.dtype
+        Hp, Wp = math.ceil(fh / WIN[0]) * WIN[0], math.ceil(fw / WIN[1]) * WIN[1]
+        padded = (Hp, Wp) != (fh, fw)
+        own, rolled = self._window_tables(Hp, Wp)
+        mpad = torch.zeros((1, token_mask.shape[0], Hp, Wp), dtype=dt, device=dev)
+        mpad[0, :, :fh, :fw] = token_mask
+        wmask = hip.window_mask(mpad, *WIN)
+        tinds = [torch.arange(i, t, t_dilation, dtype=torch.int32, device=dev) for i in range(t_dilation)]
+        ypad = torch.zeros((t, Hp, Wp, c), dtype=dt, device=dev) if padded else None
+        x = tok
+        n_tok = t * fh * fw
+        for i, B in enumerate(self.blocks):
+            y = hip.layernorm(x, *B["n1"])
+            if padded:
+                ypad[:, :fh, :fw] = y          # zero pad AFTER LayerNorm (:169-171): pad tokens' q/k/v = bias
+                y = ypad
+            qkv = B["qkv"]([y.view(1, 1, t * Hp * Wp, c)]).view(1, t, Hp, Wp, 3 * c)
+            pooled = hip.depthwise_pool(y, B["pool_w"], B["pool_b"], 4)
+            P = pooled.shape[1] * pooled.shape[2]
+            pkv = B["kv"]([pooled.view(1, 1, t * P, c)]).view(1, t, P, 2 * c)
+            att = hip.sparse_window_attention(
+                qkv, qkv[..., c:], qkv[..., 2 * c:], pkv, pkv[..., c:], own, rolled, tinds[i % t_dilation], wmask,
+                heads=HEADS, wh=WIN[0], ww=WIN[1], qkv_cstride=3 * c, pkv_cstride=2 * c, C_=c)
+            att = att[0]
+            if padded:
+                att = att[:, :fh, :fw].contiguous()
+            x = B["proj"]([att.view(1, 1, n_tok, c)], residual=x.view(1, 1, n_tok, c)).view(t, fh, fw, c)
+            y = hip.layernorm(x, *B["n2"])
+            hid = B["fc1"]([y.view(1, 1, n_tok, c)])                      # [1,1,n_tok,1960]
+            folded = hip.fold_tokens(hid.view(t, fh * fw, 1960), t, fh, fw, 40, h, w, normalize=True, act=hip.ACT_GELU)
+            x = B["fc2"]([folded], residual=x)
+        return x
+
+    # ------------------------------------------------------------------ whole forward (:319-372)
+    def forward(self, masked_frames, flows_bi, masks_in, masks_updated, l_t, interpolation, t_dilation):
+        b, t, _, H, W = masked_frames.shape
+        assert b == 1, "the inference path runs one clip per call (inference_propainter.py always has b == 1)"
+        dt, dev = self.dtype, masked_frames.device
+        x = torch.zeros((t, H, W, 8), dtype=dt, device=dev)
+        hip.nchw_to_nhwc(masked_frames[0].contiguous(), out=x, out_choff=0)
+        hip.nchw_to_nhwc(masks_in[0].contiguous(), out=x, out_choff=3)
+        hip.nchw_to_nhwc(masks_updated[0].contiguous(), out=x, out_choff=4)
+        enc = self.encode(x)                                              # [t,h,w,128]
+        h, w = enc.shape[1], enc.shape[2]
+        # 1/4-res flows (bilinear, align_corners=False, /4) and masks (nearest) — tiny host-side glue (:338-342)
+        dsf = F.interpolate(flows_bi[0][0], scale_factor=1 / 4, mode="bilinear", align_corners=False) / 4.0
+        dsb = F.interpolate(flows_bi[1][0], scale_factor=1 / 4, mode="bilinear", align_corners=False) / 4.0
+        dsf = dsf.permute(0, 2, 3, 1).contiguous()
+        dsb = dsb.permute(0, 2, 3, 1).contiguous()
+        dm_in = masks_in[0, :l_t, :, ::4, ::4]
+        dm_up = masks_updated[0, :l_t, :, ::4, ::4]
+        mask2 = torch.cat([dm_in, dm_up], 1).permute(0, 2, 3, 1).contiguous()          # [l_t,h,w,2]
+        token_mask = F.max_pool2d(dm_in, 7, 3, 3)[:, 0]                               # [l_t,fh,fw]
+        local = self.feature_propagation(enc[:l_t].contiguous(), dsf, dsb, mask2) if interpolation == "bilinear" else None
+        if local is None:
+            raise NotImplementedError("feature propagation uses bilinear warping (reference default)")
+        enc = torch.cat([local, enc[l_t:]], 0) if t > l_t else local
+        tok = self.ss([enc])                                               # SoftSplit as one convolution
+        tok = self.transformer(tok, (h, w), token_mask, t_dilation)
+        fh, fw = tok.shape[1], tok.shape[2]
+        emb = self.sc_embed([tok.view(1, 1, t * fh * fw, HIDDEN)])          # [1,1,n,6272]
+        folded = hip.fold_tokens(emb.view(t, fh * fw, 128 * 49), t, fh, fw, 128, h, w, normalize=False)
+        enc2 = self.sc_bias([folded], residual=enc)                        # bias_conv + (enc_feat + trans_feat)
+        out = self.decode(enc2[:l_t].contiguous())
+        return out.view(1, l_t, 3, H, W)
+
+    # ------------------------------------------------------------------ image propagation (:104-190, non-learnable)
+    def img_propagation(self, frames, flows_f, flows_b, masks, interpolation):
+        b, t, c, H, W = frames.shape
+        assert b == 1
+        fr, mk = frames[0].contiguous(), masks[0].contiguous()
+        ff, fb = flows_f[0].contiguous(), flows_b[0].contiguous()
+        cur_x, cur_m = fr, mk
+        for name in ("backward", "forward"):
+            out_x, out_m = torch.empty_like(fr), torch.empty_like(mk)
+            if name == "backward":
+                order = list(range(t - 1, -1, -1))
+                fidx = order
+                f_prop, f_chk = ff, fb
+            else:
+                order = list(range(t))
+                fidx = [None] + list(range(0, t - 1))
+                f_prop, f_chk = fb, ff
+            for i, idx in enumerate(order):
+                if i == 0:
+                    out_x[idx].copy_(cur_x[idx])
+                    out_m[idx].copy_(cur_m[idx])
+                else:
+                    pidx = order[i - 1]
+                    hip.img_prop_step(out_x[pidx:pidx + 1], out_m[pidx:pidx + 1], cur_x[idx:idx + 1], cur_m[idx:idx + 1],
+                                      f_prop[fidx[i]:fidx[i] + 1], f_chk[fidx[i]:fidx[i] + 1], out_x[idx:idx + 1],
+                                      out_m[idx:idx + 1], mode=interpolation)
+            cur_x, cur_m = out_x, out_m
+        return cur_x.view(1, t, c, H, W), cur_m.view(1, t, 1, H, W)
+
+
+class InpaintGenerator(nn.Module):
+    def __init__(self, init_weights=True, model_path=None):
+        super().__init__()
+        tree = ParamTree()
+        # init_weights=True -> N(0, 0.02) weights, zero biases (reference BaseNetwork.init_weights); pool_layer 1/16
+        populate(tree, generator_schema(), std=0.02 if init_weights else None)
+        for name, child in tree._modules.items():
+            self.add_module(name, child)
+        for i in range(DEPTH):
+            att = self.transformers.transformer._modules[str(i)].attention
+            if not init_weights:
+                att.pool_layer.weight.data.fill_(1.0 / 16)
+            att.register_buffer("valid_ind_rolled", self._valid_ind_rolled())
+        for m in ("backward_1", "forward_1"):      # DeformableAlignment.init_offset (:53-54)
+            d = self.feat_prop_module.deform_align._modules[m].conv_offset._modules["6"]
+            if not init_weights:
+                d.weight.data.zero_()
+        if model_path is not None:
+            print('Pretrained ProPainter has loaded...')
+            ckpt = torch.load(model_path, map_location='cpu')
+            self.load_state_dict(ckpt, strict=True)
+        self._engine = None
+
+    @staticmethod
+    def _valid_ind_rolled():
+        """Indices kept from the four rolled windows (sparse_transformer.py:142-153) — kept as a buffer only for
+        state-dict compatibility; the engine derives the same set in pp_window_tables."""
+        wh, ww = WIN
+        eh, ew = (wh + 1) // 2, (ww + 1) // 2
+        keep = []
+        for k in range(4):
+            for i in range(wh):
+                for j in range(ww):
+                    zr = (i < wh - eh) if k < 2 else (i >= eh)
+                    zc = (j < ww - ew) if k % 2 == 0 else (j >= ew)
+                    if not (zr and zc):
+                        keep.append(k * wh * ww + i * ww + j)
+        return torch.tensor(keep, dtype=torch.long)
+
+    def _get_engine(self, dtype, device):
+        key = (dtype, str(device), sum(p._version for p in self.parameters()))
+        if self._engine is None or self._engine[0] != key:
+            sd = {k: v.detach().float().cpu() for k, v in self.state_dict().items() if v.is_floating_point()}
+            self._engine = (key, _GenEngine(sd, dtype, device))
+        return self._engine[1]
+
+    @torch.no_grad()
+    def img_propagation(self, masked_frames, completed_flows, masks, interpolation='nearest'):
+        hip.require_gpu(masked_frames, "InpaintGenerator")
+        eng = self._get_engine(masked_frames.dtype, masked_frames.device)
+        dt = masked_frames.dtype
+        return eng.img_propagation(masked_frames, completed_flows[0].to(dt), completed_flows[1].to(dt), masks.to(dt),
+                                   interpolation)
+
+    @torch.no_grad()
+    def forward(self, masked_frames, completed_flows, masks_in, masks_updated, num_local_frames,
+                interpolation='bilinear', t_dilation=2):
+        hip.require_gpu(masked_frames, "InpaintGenerator")
+        if self.training:
+            raise NotImplementedError("training is outside the inference hot path; call .eval()")
+        assert DEPTH % t_dilation == 0, 'wrong t_dilation input.'
+        dt = masked_frames.dtype
+        eng = self._get_engine(dt, masked_frames.device)
+        return eng.forward(masked_frames, (completed_flows[0].to(dt), completed_flows[1].to(dt)), masks_in.to(dt),
+                           masks_updated.to(dt), num_local_frames, interpolation, t_dilation)

@@ -1,0 +1,174 @@
+"""Clip-level orchestration of the inference path (what ``inference_propainter.py:298-452`` of the reference
+does between "tensors on the device" and "composited uint8 frames"): RAFT in short clips, flow completion and
+image propagation in overlapped sub-videos, sliding-window generator calls and the ordered 0.5/0.5 blend.
+
+The chunk boundaries are part of the result (chunked != unchunked), so they follow the reference exactly; they are
+also the shard boundaries of the multi-GPU path (``propainter_amd/sharding.py``).  Unlike the reference, the
+uint8 composite/blend stays on the GPU (one device->host copy per clip instead of one per window).
+"""
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+
+@dataclass
+class InferenceConfig:
+    """Mirrors the CLI flags of inference_propainter.py:181-217 that shape the computation."""
+    raft_iter: int = 20
+    subvideo_length: int = 80
+    neighbor_length: int = 10
+    ref_stride: int = 10
+    fp16: bool = False
+
+
+def get_ref_index(mid_neighbor_id, neighbor_ids, length, ref_stride=10, ref_num=-1):
+    """Reference frames of a window (inference_propainter.py:159-173)."""
+    if ref_num == -1:
+        return [i for i in range(0, length, ref_stride) if i not in neighbor_ids]
+    ref_index = []
+    lo = max(0, mid_neighbor_id - ref_stride * (ref_num // 2))
+    hi = min(length, mid_neighbor_id + ref_stride * (ref_num // 2))
+    for i in range(lo, hi, ref_stride):
+        if i in neighbor_ids:
+            continue
+        if len(ref_index) > ref_num:      # sic: up to ref_num + 1 references
+            break
+        ref_index.append(i)
+    return ref_index
+
+
+def raft_clip_length(width):
+    """inference_propainter.py:302-309."""
+    if width <= 640:
+        return 12
+    if width <= 720:
+        return 8
+    if width <= 1280:
+        return 4
+    return 2
+
+
+def subvideo_chunks(total, length, pad):
+    """[(s, e, pad_s, pad_e)] of the overlapped chunks used for flow completion (pad 5, :341-364) and image
+    propagation (pad 10, :373-398): chunk f covers [f, f+length) extended by `pad` on both sides."""
+    out = []
+    for f in range(0, total, length):
+        s = max(0, f - pad)
+        e = min(total, f + length + pad)
+        out.append((s, e, f - s, e - min(total, f + length)))
+    return out
+
+
+def window_schedule(video_length, neighbor_length, ref_stride, subvideo_length):
+    """[(neighbor_ids, ref_ids)] for every generator call (:410-426)."""
+    ns = neighbor_length // 2
+    ref_num = subvideo_length // ref_stride if video_length > subvideo_length else -1
+    sched = []
+    for f in range(0, video_length, ns):
+        nb = list(range(max(0, f - ns), min(video_length, f + ns + 1)))
+        sched.append((nb, get_ref_index(f, nb, video_length, ref_stride, ref_num)))
+    return sched
+
+
+def compute_flows(fix_raft, frames, raft_iter):
+    """Stage A (:302-330): RAFT (fp32 input like the reference) in clips of raft_clip_length with 1 frame overlap."""
+    L = frames.size(1)
+    sl = raft_clip_length(frames.size(-1))
+    if L <= sl:
+        return fix_raft(frames, iters=raft_iter)
+    ff, fb = [], []
+    for f in range(0, L, sl):
+        e = min(L, f + sl)
+        a, b = fix_raft(frames[:, (f if f == 0 else f - 1):e], iters=raft_iter)
+        ff.append(a)
+        fb.append(b)
+    return torch.cat(ff, 1), torch.cat(fb, 1)
+
+
+def complete_flows(fix_flow_complete, gt_flows_bi, flow_masks, subvideo_length):
+    """Stage B (:341-368)."""
+    fl = gt_flows_bi[0].size(1)
+    if fl <= subvideo_length:
+        pred, _ = fix_flow_complete.forward_bidirect_flow(gt_flows_bi, flow_masks)
+        return fix_flow_complete.combine_flow(gt_flows_bi, pred, flow_masks)
+    pf, pb = [], []
+    for s, e, ps, pe in subvideo_chunks(fl, subvideo_length, 5):
+        sub = (gt_flows_bi[0][:, s:e], gt_flows_bi[1][:, s:e])
+        pred, _ = fix_flow_complete.forward_bidirect_flow(sub, flow_masks[:, s:e + 1])
+        pred = fix_flow_complete.combine_flow(sub, pred, flow_masks[:, s:e + 1])
+        pf.append(pred[0][:, ps:e - s - pe])
+        pb.append(pred[1][:, ps:e - s - pe])
+    return torch.cat(pf, 1), torch.cat(pb, 1)
+
+
+def propagate_images(model, frames, masks_dilated, pred_flows_bi, subvideo_length):
+    """Stage C (:372-404). Returns (updated_frames [1,L,3,H,W], updated_masks [1,L,1,H,W])."""
+    L = frames.size(1)
+    masked = frames * (1 - masks_dilated)
+    sv = min(100, subvideo_length)
+    if L <= sv:
+        prop, upd_m = model.img_propagation(masked, pred_flows_bi, masks_dilated, 'nearest')
+        return frames * (1 - masks_dilated) + prop * masks_dilated, upd_m
+    uf, um = [], []
+    for s, e, ps, pe in subvideo_chunks(L, sv, 10):
+        sub_flows = (pred_flows_bi[0][:, s:e - 1], pred_flows_bi[1][:, s:e - 1])
+        prop, upd_m = model.img_propagation(masked[:, s:e], sub_flows, masks_dilated[:, s:e], 'nearest')
+        upd_f = frames[:, s:e] * (1 - masks_dilated[:, s:e]) + prop * masks_dilated[:, s:e]
+        uf.append(upd_f[:, ps:e - s - pe])
+        um.append(upd_m[:, ps:e - s - pe])
+    return torch.cat(uf, 1), torch.cat(um, 1)
+
+
+class Compositor:
+    """Ordered uint8 composite + 0.5/0.5 blend of overlapping windows (:435-450), on the device.
+    ``(pred+1)/2*255`` truncated to uint8, pasted inside the dilated mask over the original frame; a frame already
+    produced by an earlier window becomes ``uint8(0.5*old + 0.5*new)`` — order dependent, so windows must be
+    fed in increasing f."""
+
+    def __init__(self, frames_u8, masks_dilated):
+        self.ori = frames_u8                                          # uint8 [L,H,W,3] on device
+        self.bin = masks_dilated[0].permute(0, 2, 3, 1).to(torch.uint8)  # [L,H,W,1] {0,1}
+        self.comp = torch.zeros_like(frames_u8)
+        self.done = [False] * frames_u8.shape[0]
+
+    def add(self, neighbor_ids, pred_img):
+        """pred_img [l_t,3,H,W] in [-1,1]."""
+        img = ((pred_img.float() + 1) / 2).permute(0, 2, 3, 1) * 255
+        img = img.to(torch.uint8)
+        for i, idx in enumerate(neighbor_ids):
+            m = self.bin[idx]
+            cur = img[i] * m + self.ori[idx] * (1 - m)
+            if self.done[idx]:
+                cur = (self.comp[idx].float() * 0.5 + cur.float() * 0.5).to(torch.uint8)
+            self.comp[idx] = cur
+            self.done[idx] = True
+
+
+@torch.no_grad()
+def run_clip(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg: InferenceConfig, device, return_stages=False):
+    """Whole path for one clip.  frames_u8 [L,H,W,3] uint8, masks [L,H,W] uint8 {0,255} (numpy or tensors).
+    models = (RAFT_bi, RecurrentFlowCompleteNet, InpaintGenerator).  Returns uint8 tensor [L,H,W,3] on `device`."""
+    fix_raft, fix_flow_complete, model = models
+    to_t = lambda a: a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))
+    fr_u8 = to_t(frames_u8).to(device)
+    frames = fr_u8.permute(0, 3, 1, 2).float().div(255)[None] * 2 - 1          # [1,L,3,H,W] in [-1,1] (:264)
+    flow_masks = to_t(flow_masks_u8).to(device).float().div(255)[None, :, None]
+    masks_dilated = to_t(masks_dilated_u8).to(device).float().div(255)[None, :, None]
+    L = frames.size(1)
+    gt_flows_bi = compute_flows(fix_raft, frames, cfg.raft_iter)
+    if cfg.fp16:                                                               # (:333-337)
+        frames, flow_masks, masks_dilated = frames.half(), flow_masks.half(), masks_dilated.half()
+        gt_flows_bi = (gt_flows_bi[0].half(), gt_flows_bi[1].half())
+    pred_flows_bi = complete_flows(fix_flow_complete, gt_flows_bi, flow_masks, cfg.subvideo_length)
+    updated_frames, updated_masks = propagate_images(model, frames, masks_dilated, pred_flows_bi, cfg.subvideo_length)
+    comp = Compositor(fr_u8, masks_dilated)
+    for nb, ref in window_schedule(L, cfg.neighbor_length, cfg.ref_stride, cfg.subvideo_length):
+        ids = nb + ref
+        pred = model(updated_frames[:, ids], (pred_flows_bi[0][:, nb[:-1]], pred_flows_bi[1][:, nb[:-1]]),
+                     masks_dilated[:, ids], updated_masks[:, ids], len(nb))
+        comp.add(nb, pred[0])
+    if return_stages:
+        return comp.comp, dict(gt_flows=gt_flows_bi, pred_flows=pred_flows_bi, updated_frames=updated_frames,
+                               updated_masks=updated_masks)
+    return comp.comp

@@ -1,0 +1,231 @@
+"""TEST-ONLY emulation of the libpropainter_hip device ops with plain PyTorch on the CPU.
+
+Purpose: validate the *host-side engine graphs* (channel windows, multi-source convolutions, packed weights and
+K-chunk tables, fused q/k/v GEMMs, fold rewrites, scheduling) against the reference goldens without a GPU.
+Every emulated op consumes exactly the arguments the HIP kernel would get (same packed weights, same tables), so
+only the kernels themselves remain to be proven on the GPU.  Never imported by the product.
+"""
+import contextlib
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import propainter_oracle as O
+from oracle.deform_conv_ref import bilinear_zeros
+from propainter_amd import conv as pconv
+from propainter_amd import hip
+
+_ACT = {hip.ACT_NONE: lambda v, p: v, hip.ACT_RELU: lambda v, p: F.relu(v), hip.ACT_LRELU: lambda v, p: F.leaky_relu(v, p),
+        hip.ACT_SIGMOID: lambda v, p: torch.sigmoid(v), hip.ACT_TANH: lambda v, p: torch.tanh(v),
+        hip.ACT_GELU: lambda v, p: F.gelu(v)}
+
+
+def _conv_call(self, srcs, out=None, out_choff=0, act=None, act_param=0.0, out_scale=1.0, residual=None, res_choff=0,
+               act2=None, out_dtype=None, dcn_offmask=None, out_hw=None):
+    srcs = [(s, 0) if torch.is_tensor(s) else s for s in srcs]
+    x0 = srcs[0][0]
+    N, H, W = x0.shape[:3]
+    OH, OW = out_hw if out_hw is not None else self.out_hw(H, W)
+    if out is None:
+        cp = pconv.pad8(self.cout)
+        out = torch.zeros((N, OH, OW, cp), dtype=out_dtype or self.dtype)
+    kt = self.ktable.cpu().numpy()
+    oy = torch.arange(OH).view(1, OH, 1) * self.stride[0] - self.padding[0]
+    ox = torch.arange(OW).view(1, 1, OW) * self.stride[1] - self.padding[1]
+    nidx = torch.arange(N).view(N, 1, 1)
+    for g in range(self.groups):
+        A = torch.zeros(N, OH, OW, self.K)
+        for kc, (dy, dx, code, choff) in enumerate(kt):
+            s = int(code) & 0xff
+            if s == 255:
+                continue
+            src, so = srcs[s]
+            cb = so + (g * self.src_channels[s] if self.groups > 1 else 0) + int(choff)
+            srcf = src.float()
+            if dcn_offmask is None:
+                iy, ix = oy + int(dy), ox + int(dx)
+                if self.pad_mode == 1:
+                    ok = torch.ones(1, OH, OW, dtype=torch.bool)
+                    iy, ix = iy.clamp(0, H - 1), ix.clamp(0, W - 1)
+                else:
+                    ok = (iy >= 0) & (iy < H) & (ix >= 0) & (ix < W)
+                v = srcf[nidx, iy.clamp(0, H - 1).expand(N, OH, OW), ix.clamp(0, W - 1).expand(N, OH, OW), cb:cb + 8]
+                A[..., kc * 8:kc * 8 + 8] = v * ok[..., None]
+            else:
+                grp, tap = (int(code) >> 8) & 0xff, (int(code) >> 16) & 0xff
+                om = dcn_offmask.float()
+                py = (oy + int(dy)).float() + om[..., 2 * (grp * 9 + tap)]
+                px = (ox + int(dx)).float() + om[..., 2 * (grp * 9 + tap) + 1]
+                smp = bilinear_zeros(srcf[..., cb:cb + 8].permute(0, 3, 1, 2).contiguous(), py, px)   # [N,8,OH,OW]
+                A[..., kc * 8:kc * 8 + 8] = smp.permute(0, 2, 3, 1) * om[..., 288 + grp * 9 + tap][..., None]
+        if self.dtype == torch.float16:
+            A = A.half().float()
+        y = A @ self.weight[g, :self.cout_g].float().t()
+        if self.bias is not None:
+            y = y + self.bias[g * self.cout_g:(g + 1) * self.cout_g]
+        y = y * out_scale
+        y = _ACT[pconv.ACTS[act]](y, act_param)
+        c0 = out_choff + g * self.cout_g
+        if residual is not None:
+            y = y + residual.float()[..., res_choff + g * self.cout_g: res_choff + (g + 1) * self.cout_g].reshape(y.shape)
+        if pconv.ACTS[act2] == hip.ACT_RELU:
+            y = F.relu(y)
+        out.view(N, OH, OW, -1)[..., c0:c0 + self.cout_g] = y.to(out.dtype)
+    return out
+
+
+def _batched_gemm_nt(a, bt, out_scale=1.0):
+    return torch.matmul(a.float(), bt.float().transpose(1, 2)) * out_scale
+
+
+def _flow_warp(x, flow, out=None, mode="bilinear", x_choff=0, C_=None, fl_choff=0, out_choff=0):
+    C_ = x.shape[-1] if C_ is None else C_
+    xs = x[..., x_choff:x_choff + C_].permute(0, 3, 1, 2).float()
+    y = O.flow_warp(xs, flow[..., fl_choff:fl_choff + 2].float(), mode).permute(0, 2, 3, 1)
+    if out is None:
+        return y.to(x.dtype).contiguous()
+    out[..., out_choff:out_choff + C_] = y.to(out.dtype)
+    return out
+
+
+def _fb_check(fw, bw, out=None, out_choff=0):
+    v = O.fb_consistency_check(fw[..., :2].permute(0, 3, 1, 2).float(), bw[..., :2].permute(0, 3, 1, 2).float())[:, 0]
+    if out is None:
+        return v[..., None].to(fw.dtype)
+    out[..., out_choff] = v.to(out.dtype)
+    return out
+
+
+def _img_prop_step(x_prop, m_prop, x_cur, m_cur, f_prop, f_chk, x_out, m_out, mode="nearest"):
+    fp = f_prop.float()
+    valid = O.fb_consistency_check(fp, f_chk.float())
+    warped = O.flow_warp(x_prop.float(), fp.permute(0, 2, 3, 1), mode)
+    mpv = O.binarize(O.flow_warp(m_prop.float(), fp.permute(0, 2, 3, 1)))
+    u = O.binarize(m_cur.float() * valid * (1 - mpv))
+    x_out.copy_((u * warped + (1 - u) * x_cur.float()).to(x_out.dtype))
+    m_out.copy_(O.binarize(m_cur.float() * (1 - valid * (1 - mpv))).to(m_out.dtype))
+
+
+def _corr_avgpool(x, M, H, W):
+    return F.avg_pool2d(x.view(M, 1, H, W), 2, 2)[:, 0].contiguous()
+
+
+def _corr_lookup(levels, coords, out):
+    ref = O.corr_lookup([l[:, None] for l in levels], coords.permute(0, 3, 1, 2))
+    out[..., :324] = ref.permute(0, 2, 3, 1).to(out.dtype)
+    out[..., 324:] = 0
+    return out
+
+
+def _convex_upsample(flow, mask):
+    return O.convex_upsample(flow.permute(0, 3, 1, 2), mask[..., :576].permute(0, 3, 1, 2).float())
+
+
+def _window_mask(mask, wh=5, ww=9):
+    B, Lt = mask.shape[:2]
+    return F.max_pool2d(mask.float(), (wh, ww), (wh, ww)).view(B, Lt, -1).sum(1)
+
+
+def _attention(q, k, v, pk, pv, own, rolled, tind, wmask, heads=4, wh=5, ww=9, qkv_cstride=None, pkv_cstride=None,
+               C_=None, impl=0):
+    from tests.test_ops_gpu import _attention_reference
+    C_ = q.shape[-1] if C_ is None else C_
+    out = _attention_reference(q[..., :C_].float(), k[..., :C_].float(), v[..., :C_].float(), pk[..., :C_].float(),
+                               pv[..., :C_].float(), own.long(), rolled.long(), tind.long(), wmask, heads)
+    return out.to(q.dtype)
+
+
+def _fold_tokens(tokens, BT, fh, fw, Cc, H, W, normalize=False, act=hip.ACT_NONE):
+    t = tokens.float().view(BT, fh * fw, Cc * 49).permute(0, 2, 1)
+    y = F.fold(t, (H, W), 7, 1, 3, 3)
+    if normalize:
+        y = y / F.fold(torch.ones_like(t), (H, W), 7, 1, 3, 3)
+    return _ACT[act](y, 0.0).permute(0, 2, 3, 1).contiguous().to(tokens.dtype)
+
+
+def _layernorm(x, gamma, beta, eps=1e-5):
+    return F.layer_norm(x.float(), (x.shape[-1],), gamma, beta, eps).to(x.dtype)
+
+
+def _depthwise_pool(x, weight, bias, k=4):
+    y = F.conv2d(x.float().permute(0, 3, 1, 2), weight[:, None], bias, k, 0, 1, x.shape[-1])
+    return y.permute(0, 2, 3, 1).contiguous().to(x.dtype)
+
+
+def _instance_norm(x, relu=False, eps=1e-5, out=None):
+    y = F.instance_norm(x.float().permute(0, 3, 1, 2), eps=eps)
+    y = (F.relu(y) if relu else y).permute(0, 2, 3, 1).contiguous().to(x.dtype)
+    return y
+
+
+def _upsample2x(x):
+    y = F.interpolate(x.float().permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=True)
+    return y.permute(0, 2, 3, 1).contiguous().to(x.dtype)
+
+
+def _dcn_act(om, mag, flow=None, fl_choff=0):
+    v = om.float()
+    off = mag * torch.tanh(v[..., :288])
+    if flow is not None:
+        f = flow.float()
+        off[..., 0::2] += f[..., fl_choff + 1:fl_choff + 2]
+        off[..., 1::2] += f[..., fl_choff:fl_choff + 1]
+    om[..., :288] = off.to(om.dtype)
+    om[..., 288:432] = torch.sigmoid(v[..., 288:432]).to(om.dtype)
+    return om
+
+
+def _gru_gate(zr, h, h_choff, Cc, out, out_choff, q=None):
+    hv = h[..., h_choff:h_choff + Cc].float()
+    if q is None:
+        y = zr[..., Cc:2 * Cc].float() * hv
+    else:
+        z = zr[..., :Cc].float()
+        y = (1 - z) * hv + z * q[..., :Cc].float()
+    out[..., out_choff:out_choff + Cc] = y.to(out.dtype)
+    return out
+
+
+def _nchw_to_nhwc(x, out=None, out_choff=0, out_dtype=None, cpad=None, scale=1.0):
+    N, Cc, H, W = x.shape
+    if out is None:
+        out = torch.zeros((N, H, W, cpad or (Cc + 7) // 8 * 8), dtype=out_dtype or x.dtype)
+    out[..., out_choff:out_choff + Cc] = (x.float() * scale).permute(0, 2, 3, 1).to(out.dtype)
+    return out
+
+
+def _nhwc_to_nchw(x, Cc=None, choff=0, out_dtype=None, act=hip.ACT_NONE):
+    Cc = x.shape[-1] if Cc is None else Cc
+    return _ACT[act](x[..., choff:choff + Cc].float(), 0.0).permute(0, 3, 1, 2).contiguous().to(out_dtype or x.dtype)
+
+
+@contextlib.contextmanager
+def emulated_device_ops():
+    """Patches propainter_amd.hip / ConvLayer with the CPU emulations for the duration of the block."""
+    patches = {
+        "flow_warp": _flow_warp, "fb_check": _fb_check, "img_prop_step": _img_prop_step, "corr_avgpool": _corr_avgpool,
+        "corr_lookup": _corr_lookup, "convex_upsample": _convex_upsample, "window_mask": _window_mask,
+        "sparse_window_attention": _attention, "fold_tokens": _fold_tokens, "layernorm": _layernorm,
+        "depthwise_pool": _depthwise_pool, "instance_norm": _instance_norm, "upsample2x": _upsample2x,
+        "dcn_offset_mask_act": _dcn_act, "gru_gate": _gru_gate, "nchw_to_nhwc": _nchw_to_nhwc, "nhwc_to_nchw": _nhwc_to_nchw,
+    }
+    patches["require_gpu"] = lambda t, who: None
+    saved = {k: getattr(hip, k) for k in patches}
+    saved_call, saved_gemm = pconv.ConvLayer.__call__, pconv.batched_gemm_nt
+    import propainter_amd.model.modules.flow_comp_raft as fr
+    saved_fr_gemm = fr.batched_gemm_nt
+    try:
+        for k, f in patches.items():
+            setattr(hip, k, f)
+        pconv.ConvLayer.__call__ = _conv_call
+        pconv.batched_gemm_nt = _batched_gemm_nt
+        fr.batched_gemm_nt = _batched_gemm_nt
+        yield
+    finally:
+        for k, f in saved.items():
+            setattr(hip, k, f)
+        pconv.ConvLayer.__call__ = saved_call
+        pconv.batched_gemm_nt = saved_gemm
+        fr.batched_gemm_nt = saved_fr_gemm

@@ -1,0 +1,155 @@
+"""Host-side logic that needs no GPU: state-dict schemas, C-ABI exports, index tables, weight packing / K-table
+emulation, chunk scheduling."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import propainter_oracle as O
+from propainter_amd import build as pbuild
+from propainter_amd import hip, pipeline
+from propainter_amd.conv import pack_weight
+from tests.helpers import GOLDEN, seeded_models
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_state_dict_schemas_match_reference():
+    ref = json.load(open(os.path.join(GOLDEN, "state_dict_schema.json")))
+    raft, fc, gen = seeded_models("cpu")
+    for name, mod in (("raft", raft.fix_raft), ("fc", fc), ("gen", gen)):
+        mine = {k: list(v.shape) for k, v in mod.state_dict().items()}
+        assert mine == ref[name], (name, set(mine) ^ set(ref[name]))
+    assert all(k.startswith("fix_raft.") for k in raft.state_dict())
+
+
+def test_cabi_exports_every_declared_symbol():
+    lib = ctypes.CDLL(pbuild.build(verbose=False))
+    header = open(os.path.join(ROOT, "include", "propainter_hip.h")).read()
+    names = set(re.findall(r"\b(pp_[a-z0-9_]+)\s*\(", header))
+    assert len(names) >= 24
+    for n in names:
+        assert hasattr(lib, n), n
+    assert lib.pp_version() >= 100
+    assert lib.pp_sizeof_conv_args() == ctypes.sizeof(hip.ConvArgs)
+    assert lib.pp_sizeof_attn_args() == ctypes.sizeof(hip.AttnArgs)
+
+
+def test_cabi_argument_errors_are_reported():
+    L = hip.lib()
+    a = hip.ConvArgs()
+    a.dtype = 7
+    assert L.pp_conv2d(ctypes.byref(a), None) == -2           # PP_ERR_DTYPE before any launch
+    assert b"dtype" in L.pp_last_error_string()
+    with pytest.raises(RuntimeError):
+        hip.flow_warp(torch.zeros(1, 4, 4, 8), torch.zeros(1, 4, 4, 2))   # CPU tensors: no fallback
+
+
+@pytest.mark.parametrize("grid", [(20, 36), (10, 9), (60, 108), (5, 18)])
+def test_window_tables_match_reference_roll_semantics(grid):
+    own, rolled = hip.window_tables(*grid)
+    o2, r2 = O.window_key_index(*grid)
+    assert np.array_equal(own, o2.numpy()) and np.array_equal(rolled, r2.numpy()) and rolled.shape[1] == 148
+
+
+def _emulate_conv(srcs, layer_w, bias, stride, pad, dil, groups, src_channels, pad_mode="zeros"):
+    """numpy/torch emulation of the kernel's table-driven gather + packed-weight GEMM (validates pack_weight and
+    pp_conv_build_ktable against F.conv2d)."""
+    packed, K, cout_g = pack_weight(layer_w, src_channels, groups)
+    kh, kw = layer_w.shape[2:]
+    taps = [(ky * dil, kx * dil) for ky in range(kh) for kx in range(kw)]
+    kt = hip.build_ktable(taps, [(c + 7) // 8 * 8 for c in src_channels])
+    N, H, W, _ = srcs[0].shape
+    OH = (H + 2 * pad - dil * (kh - 1) - 1) // stride + 1
+    OW = (W + 2 * pad - dil * (kw - 1) - 1) // stride + 1
+    out = torch.zeros(N, OH, OW, groups * cout_g)
+    for g in range(groups):
+        A = torch.zeros(N, OH, OW, K)
+        for kc, (dy, dx, s, choff) in enumerate(kt):
+            s &= 0xff
+            if s == 255:
+                continue
+            src = srcs[s]
+            cb = g * src_channels[s] if groups > 1 else 0
+            for oy in range(OH):
+                for ox in range(OW):
+                    iy, ix = oy * stride - pad + dy, ox * stride - pad + dx
+                    if pad_mode == "replicate":
+                        iy, ix = min(max(iy, 0), H - 1), min(max(ix, 0), W - 1)
+                    elif not (0 <= iy < H and 0 <= ix < W):
+                        continue
+                    A[:, oy, ox, kc * 8:kc * 8 + 8] = src[:, iy, ix, cb + choff:cb + choff + 8]
+        out[..., g * cout_g:(g + 1) * cout_g] = A @ packed[g, :cout_g].t()
+    return out + bias
+
+
+@pytest.mark.parametrize("cfg", [dict(cin=[5], cout=12, k=3, stride=2, pad=1, dil=1, groups=1),
+                                 dict(cin=[16, 3], cout=10, k=3, stride=1, pad=2, dil=2, groups=1),
+                                 dict(cin=[8, 24], cout=16, k=3, stride=1, pad=1, dil=1, groups=2)])
+def test_weight_packing_and_ktable_reproduce_conv2d(cfg):
+    torch.manual_seed(0)
+    N, H, W = 1, 6, 7
+    groups = cfg["groups"]
+    per_group = cfg["cin"]
+    w = torch.randn(cfg["cout"], sum(per_group), cfg["k"], cfg["k"])
+    b = torch.randn(cfg["cout"])
+    # sources in NHWC with channel padding to 8 (zeros); grouped sources hold groups * per-group channels
+    srcs, nchw_groups = [], [[] for _ in range(groups)]
+    for c in per_group:
+        real = torch.randn(N, groups * c, H, W)
+        cp = (c + 7) // 8 * 8 if groups == 1 else c
+        t = torch.zeros(N, H, W, max(cp, groups * c))
+        t[..., :groups * c] = real.permute(0, 2, 3, 1)
+        srcs.append(t)
+        for g in range(groups):
+            nchw_groups[g].append(real[:, g * c:(g + 1) * c])
+    x = torch.cat([torch.cat(parts, 1) for parts in nchw_groups], 1)
+    ref = F.conv2d(x, w, b, cfg["stride"], cfg["pad"], cfg["dil"], groups).permute(0, 2, 3, 1)
+    got = _emulate_conv(srcs, w, b, cfg["stride"], cfg["pad"], cfg["dil"], groups, per_group)
+    assert (got - ref).abs().max() < 1e-4
+
+
+def test_softsplit_and_ffn_rewrites_are_exact():
+    """SoftSplit == 7x7/s3 conv; fc2(gelu(unfold(fold(h)/n))) == conv7x7/s3(gelu(fold(h)/n))  (engine rewrites)."""
+    torch.manual_seed(1)
+    x = torch.randn(2, 16, 12, 21)
+    wt, bs = torch.randn(32, 16 * 49), torch.randn(32)
+    ref = F.linear(F.unfold(x, 7, 1, 3, 3).permute(0, 2, 1), wt, bs)
+    got = F.conv2d(x, wt.view(32, 16, 7, 7), bs, 3, 3).flatten(2).permute(0, 2, 1)
+    assert (ref - got).abs().max() < 1e-4
+    fh, fw = O.token_grid(12), O.token_grid(21)
+    hdn = torch.randn(2, fh * fw, 5 * 49)
+    w2, b2 = torch.randn(8, 5 * 49), torch.randn(8)
+    folded = F.fold(hdn.permute(0, 2, 1), (12, 21), 7, 1, 3, 3)
+    norm = F.fold(torch.ones_like(hdn).permute(0, 2, 1), (12, 21), 7, 1, 3, 3)
+    ref = F.linear(F.gelu(F.unfold(folded / norm, 7, 1, 3, 3).permute(0, 2, 1)), w2, b2)
+    got = F.conv2d(F.gelu(folded / norm), w2.view(8, 5, 7, 7), b2, 3, 3).flatten(2).permute(0, 2, 1)
+    assert (ref - got).abs().max() < 1e-4
+
+
+def test_schedule_matches_oracle_driver():
+    for L, sub, nl, rs in ((80, 80, 10, 10), (10, 6, 4, 3), (170, 80, 10, 10), (23, 20, 6, 5)):
+        ns = nl // 2
+        ref_num = sub // rs if L > sub else -1
+        sched = pipeline.window_schedule(L, nl, rs, sub)
+        for f, (nb, ref) in zip(range(0, L, ns), sched):
+            nb2 = list(range(max(0, f - ns), min(L, f + ns + 1)))
+            assert nb == nb2 and ref == O.get_ref_index(f, nb2, L, rs, ref_num)
+    assert pipeline.subvideo_chunks(170, 80, 5) == [(0, 85, 0, 5), (75, 165, 5, 5), (155, 170, 5, 0)]
+    assert [pipeline.raft_clip_length(w) for w in (432, 720, 1280, 1920)] == [12, 8, 4, 2]
+
+
+def test_models_refuse_cpu_tensors():
+    raft, fc, gen = seeded_models("cpu")
+    with pytest.raises(RuntimeError):
+        raft(torch.zeros(1, 2, 3, 128, 128))
+    with pytest.raises(RuntimeError):
+        fc(torch.zeros(1, 2, 2, 64, 64), torch.zeros(1, 2, 1, 64, 64))
+    with pytest.raises(RuntimeError):
+        gen(torch.zeros(1, 2, 3, 64, 64), (torch.zeros(1, 1, 2, 64, 64),) * 2, torch.zeros(1, 2, 1, 64, 64),
+            torch.zeros(1, 2, 1, 64, 64), 2)

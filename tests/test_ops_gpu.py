@@ -1,0 +1,369 @@
+"""Parity of every HIP kernel (called through the C-ABI) against plain PyTorch fp32 references / the CPU oracle.
+Tolerances: fp32 kernels 1e-4 relative to the reference's max magnitude (fp32 MFMA == fmaf chain); fp16 kernels
+(fp16 storage, fp32 accumulation) 1e-2 relative unless stated."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import propainter_oracle as O
+from oracle.deform_conv_ref import deform_conv2d
+from tests.helpers import report
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.float16]
+
+
+def tol(dt, scale=1.0):
+    return (2e-4 if dt == torch.float32 else 1e-2) * scale
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from propainter_amd import hip
+    hip.lib()
+    return torch.device("cuda:0")
+
+
+def nhwc(x, dt, cpad=None):
+    """NCHW fp32 CPU -> NHWC device tensor with zero channel padding."""
+    n, c, h, w = x.shape
+    cp = cpad or (c + 7) // 8 * 8
+    out = torch.zeros(n, h, w, cp, dtype=dt, device="cuda")
+    out[..., :c] = x.permute(0, 2, 3, 1).to("cuda", dt)
+    return out
+
+
+def check(name, got, ref, rtol):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    err = (got - ref).abs().max().item()
+    lim = rtol * max(ref.abs().max().item(), 1e-3)
+    assert math.isfinite(err) and err <= lim, report(name, got, ref) + f" limit {lim:.3e}"
+
+
+CONV_CASES = [
+    dict(name="3x3", cin=[128], cout=128, k=(3, 3), stride=1, pad=1),
+    dict(name="7x7s2_c3", cin=[3], cout=64, k=(7, 7), stride=2, pad=3),
+    dict(name="1x1_c324", cin=[324], cout=256, k=(1, 1), stride=1, pad=0),
+    dict(name="two_src", cin=[192, 64], cout=126, k=(3, 3), stride=1, pad=1, act="relu"),
+    dict(name="three_src_small", cin=[128, 128, 5], cout=128, k=(3, 3), stride=1, pad=1, act="lrelu"),
+    dict(name="grouped", cin=[32, 48], cout=256, k=(3, 3), stride=1, pad=1, groups=8, act="lrelu"),
+    dict(name="dilated", cin=[128], cout=128, k=(3, 3), stride=1, pad=3, dil=3),
+    dict(name="replicate5x5s2", cin=[3], cout=32, k=(5, 5), stride=2, pad=2, pad_mode="replicate"),
+    dict(name="cout2_f32out", cin=[256], cout=2, k=(3, 3), stride=1, pad=1, out_f32=True),
+    dict(name="cout3_tanh", cin=[64], cout=3, k=(3, 3), stride=1, pad=1, act="tanh"),
+    dict(name="1x5", cin=[128, 256], cout=256, k=(1, 5), stride=1, pad=(0, 2), act="sigmoid"),
+    dict(name="temporal3x1", cin=[64], cout=64, k=(3, 1), stride=1, pad=(2, 0), dil=(2, 1)),
+    dict(name="residual_relu2", cin=[96], cout=96, k=(3, 3), stride=1, pad=1, act="relu", residual=True, act2="relu"),
+    dict(name="7x7s3_c40", cin=[40], cout=512, k=(7, 7), stride=3, pad=3, residual=True),
+    dict(name="cout48", cin=[64], cout=48, k=(3, 3), stride=2, pad=1),
+    dict(name="cout432", cin=[128], cout=432, k=(3, 3), stride=1, pad=1),
+]
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "f16"])
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c["name"] for c in CONV_CASES])
+def test_conv2d(dev, case, dt):
+    from propainter_amd.conv import ConvLayer
+    g = torch.Generator().manual_seed(100 + [c["name"] for c in CONV_CASES].index(case["name"]))
+    groups = case.get("groups", 1)
+    cin = case["cin"]
+    kh, kw = case["k"]
+    N, H, W = 2, 19, 23
+    w = torch.randn(case["cout"], sum(cin), kh, kw, generator=g) / math.sqrt(sum(cin) * kh * kw)
+    b = torch.randn(case["cout"], generator=g) * 0.1
+    srcs_nchw = [torch.randn(N, groups * c, H, W, generator=g) for c in cin]
+    # grouped reference input: per group, concatenate the group's slice of every source
+    x = torch.cat([torch.cat([s[:, gi * c:(gi + 1) * c] for s, c in zip(srcs_nchw, cin)], 1) for gi in range(groups)], 1)
+    dil = case.get("dil", 1)
+    if case.get("pad_mode") == "replicate":
+        p = case["pad"]
+        ref = F.conv2d(F.pad(x, (p, p, p, p), mode="replicate"), w, b, case["stride"], 0, dil, groups)
+    else:
+        ref = F.conv2d(x, w, b, case["stride"], case["pad"], dil, groups)
+    act = case.get("act")
+    if act == "relu": ref = F.relu(ref)
+    elif act == "lrelu": ref = F.leaky_relu(ref, 0.1)
+    elif act == "sigmoid": ref = torch.sigmoid(ref)
+    elif act == "tanh": ref = torch.tanh(ref)
+    res = None
+    if case.get("residual"):
+        res = torch.randn(ref.shape, generator=g)
+        ref = ref + res
+        if case.get("act2") == "relu":
+            ref = F.relu(ref)
+    layer = ConvLayer(w, b, stride=case["stride"], padding=case["pad"], dilation=dil, groups=groups, src_channels=cin,
+                      pad_mode=case.get("pad_mode", "zeros"), dtype=dt, device=dev)
+    srcs = [nhwc(s, dt) for s in srcs_nchw]
+    out = layer(srcs, act=act, act_param=0.1, residual=None if res is None else nhwc(res, dt), act2=case.get("act2"),
+                out_dtype=torch.float32 if case.get("out_f32") else None)
+    torch.cuda.synchronize()
+    assert out.dtype == (torch.float32 if case.get("out_f32") else dt)
+    check(case["name"], out[..., :case["cout"]].permute(0, 3, 1, 2), ref, tol(dt))
+    if out.shape[-1] > case["cout"]:
+        assert (out[..., case["cout"]:] == 0).all(), "channel padding must stay zero"
+
+
+def test_conv2d_output_window_and_large_m(dev):
+    """writes into a channel window of a wider buffer; M not a multiple of the tile; asymmetric data (transposes)."""
+    from propainter_amd.conv import ConvLayer
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(1, 64, 37, 41, generator=g)
+    w = torch.randn(126, 64, 3, 3, generator=g) / 24
+    layer = ConvLayer(w, None, padding=1, dtype=torch.float16, device=dev)
+    buf = torch.full((1, 37, 41, 256), 7.0, dtype=torch.float16, device=dev)
+    layer([nhwc(x, torch.float16)], out=buf, out_choff=128)
+    torch.cuda.synchronize()
+    check("window", buf[..., 128:254].permute(0, 3, 1, 2), F.conv2d(x, w, None, 1, 1), 1e-2)
+    assert (buf[..., :128] == 7).all() and (buf[..., 254:] == 7).all()
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "f16"])
+def test_batched_gemm_nt(dev, dt):
+    from propainter_amd.conv import batched_gemm_nt
+    g = torch.Generator().manual_seed(3)
+    a, b = torch.randn(3, 150, 256, generator=g), torch.randn(3, 150, 256, generator=g)
+    out = batched_gemm_nt(a.to(dev, dt), b.to(dev, dt), out_scale=1 / 16)
+    torch.cuda.synchronize()
+    ref = torch.matmul(a.to(dt).float(), b.to(dt).float().transpose(1, 2)) / 16
+    check("gemm", out, ref, 2e-4 if dt == torch.float32 else 2e-3)
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "f16"])
+@pytest.mark.parametrize("cin", [[128], [128, 128]], ids=["gen", "fc"])
+def test_deform_conv(dev, dt, cin):
+    """offset/mask head activation vs torch, then the deformable implicit GEMM vs the oracle restatement fed with
+    the device-produced (dtype-rounded) offsets and masks."""
+    from propainter_amd import hip
+    from propainter_amd.conv import ConvLayer
+    g = torch.Generator().manual_seed(5)
+    N, H, W = 1, 17, 21
+    ctot = sum(cin)
+    x = torch.randn(N, ctot, H, W, generator=g)
+    w = torch.randn(128, ctot, 3, 3, generator=g) / math.sqrt(ctot * 9)
+    b = torch.randn(128, generator=g) * 0.1
+    raw = torch.randn(N, 432, H, W, generator=g)
+    gen = len(cin) == 1
+    mag = 3.0 if gen else 5.0
+    flow = None
+    if gen:
+        flow = torch.randn(N, 2, H, W, generator=g) * 2
+        flow[:, :, 0, 0] = 40.0                    # whole neighbourhood far outside -> zero columns
+    else:
+        raw[:, :288, 0, 1] = 100.0                 # saturated tanh: offsets exactly +5
+    rq = raw.to(dt).float()
+    offset = mag * torch.tanh(rq[:, :288])
+    if gen:
+        offset = offset + flow.to(dt).float().flip(1).repeat(1, 144, 1, 1)
+    mask = torch.sigmoid(rq[:, 288:])
+    om = nhwc(raw, dt)
+    hip.dcn_offset_mask_act(om, mag, flow=nhwc(flow, dt) if gen else None)
+    torch.cuda.synchronize()
+    check("offmask_act_off", om[..., :288].permute(0, 3, 1, 2), offset, tol(dt, 2))
+    check("offmask_act_mask", om[..., 288:432].permute(0, 3, 1, 2), mask, tol(dt, 2))
+    omc = om.float().cpu().permute(0, 3, 1, 2)
+    ref = deform_conv2d(x.to(dt).float(), omc[:, :288].contiguous(), w.to(dt).float(), b, 1, 1, 1, omc[:, 288:432].contiguous())
+    layer = ConvLayer(w, b, padding=1, src_channels=cin, dcn_groups=16, dtype=dt, device=dev)
+    srcs, off = [], 0
+    for c in cin:
+        srcs.append(nhwc(x[:, off:off + c], dt))
+        off += c
+    out = layer(srcs, dcn_offmask=om)
+    torch.cuda.synchronize()
+    check("deform", out.permute(0, 3, 1, 2), ref, tol(dt, 2))
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "f16"])
+@pytest.mark.parametrize("mode", ["bilinear", "nearest"])
+@pytest.mark.parametrize("c", [128, 1, 2])
+def test_flow_warp(dev, dt, mode, c):
+    from propainter_amd import hip
+    g = torch.Generator().manual_seed(9)
+    N, H, W = 2, 24, 33
+    x = torch.randn(N, c, H, W, generator=g)
+    flow = torch.randn(N, H, W, 2, generator=g) * 3
+    flow[0, 0, :5] = torch.tensor([0.5, 0.0]); flow[0, 1, :5] = torch.tensor([1.5, 2.5])      # ties
+    flow[0, 2, :5] = torch.tensor([-40.0, 3.0])                                              # out of bounds
+    xq, fq = x.to(dt).float(), flow.to(dt).float()
+    ref = O.flow_warp(xq, fq, mode)
+    out = hip.flow_warp(nhwc(x, dt) if c % 8 == 0 else x.permute(0, 2, 3, 1).contiguous().to(dev, dt),
+                        flow.to(dev, dt).contiguous(), mode=mode)
+    torch.cuda.synchronize()
+    check(f"warp_{mode}_{c}", out.permute(0, 3, 1, 2), ref, tol(dt))
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "f16"])
+def test_fb_check(dev, dt):
+    from propainter_amd import hip
+    g = torch.Generator().manual_seed(10)
+    N, H, W = 2, 30, 40
+    fw = torch.randn(N, 2, H, W, generator=g) * 1.5
+    bw = -fw + torch.randn(N, 2, H, W, generator=g) * 0.6
+    fwq, bwq = fw.to(dt).float(), bw.to(dt).float()
+    ref = O.fb_consistency_check(fwq, bwq)
+    aux = torch.zeros(N, H, W, 8, dtype=dt, device=dev)
+    aux[..., :2] = fw.permute(0, 2, 3, 1).to(dev, dt)
+    hip.fb_check(aux, bw.permute(0, 2, 3, 1).contiguous().to(dev, dt), out=aux, out_choff=2)
+    torch.cuda.synchronize()
+    got = aux[..., 2].float().cpu()
+    mism = (got != ref[:, 0]).float().mean().item()
+    assert mism <= (0.0 if dt == torch.float32 else 5e-3) + 2e-3, f"fb_check mismatch fraction {mism}"
+    assert 0.2 < ref.mean() < 0.98
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "f16"])
+def test_corr_pyramid_and_lookup(dev, dt):
+    from propainter_amd import hip
+    from propainter_amd.conv import batched_gemm_nt
+    g = torch.Generator().manual_seed(12)
+    P, h, w = 2, 16, 24
+    f1, f2 = torch.randn(P, 256, h, w, generator=g), torch.randn(P, 256, h, w, generator=g)
+    f1q, f2q = f1.to(dt).float(), f2.to(dt).float()
+    pyr = O.corr_pyramid(f1q, f2q)
+    n8 = h * w
+    vol = batched_gemm_nt(f1.permute(0, 2, 3, 1).reshape(P, n8, 256).to(dev, dt).contiguous(),
+                          f2.permute(0, 2, 3, 1).reshape(P, n8, 256).to(dev, dt).contiguous(), out_scale=1 / 16)
+    levels = [vol.view(P * n8, h, w)]
+    hh, ww = h, w
+    for _ in range(3):
+        levels.append(hip.corr_avgpool(levels[-1], P * n8, hh, ww))
+        hh, ww = hh // 2, ww // 2
+    torch.cuda.synchronize()
+    for l in range(4):
+        check(f"pyr{l}", levels[l], pyr[l][:, 0], 3e-4 if dt == torch.float32 else 3e-3)
+    coords = O.coords_grid(P, h, w) + torch.randn(P, 2, h, w, generator=g) * 4
+    coords[0, :, 0, 0] = torch.tensor([-3.3, 2.2]); coords[0, :, 0, 1] = torch.tensor([30.0, 20.5])
+    ref = O.corr_lookup(pyr, coords)
+    out = torch.empty(P, h, w, 328, dtype=dt, device=dev)
+    hip.corr_lookup(levels, coords.permute(0, 2, 3, 1).contiguous().to(dev), out)
+    torch.cuda.synchronize()
+    check("lookup", out[..., :324].permute(0, 3, 1, 2), ref, 3e-4 if dt == torch.float32 else 5e-3)
+    assert (out[..., 324:] == 0).all()
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "f16"])
+def test_convex_upsample(dev, dt):
+    from propainter_amd import hip
+    g = torch.Generator().manual_seed(13)
+    B, h, w = 2, 9, 11
+    flow, mask = torch.randn(B, 2, h, w, generator=g) * 3, torch.randn(B, 576, h, w, generator=g)
+    ref = O.convex_upsample(flow, mask.to(dt).float())
+    out = hip.convex_upsample(flow.permute(0, 2, 3, 1).contiguous().to(dev), nhwc(mask, dt))
+    torch.cuda.synchronize()
+    check("convex", out, ref, 2e-4)
+
+
+def _attention_reference(q, k, v, pk, pv, own, rolled, tind, wmask, heads=4):
+    """torch fp32 restatement on explicit index sets (same math as oracle.sparse_window_attention)."""
+    B, T, Hp, Wp, C = q.shape
+    ch = C // heads
+    qf, kf, vf = (a.reshape(B, T, Hp * Wp, heads, ch) for a in (q, k, v))
+    out = torch.zeros_like(qf)
+    for b in range(B):
+        for w in range(own.shape[0]):
+            qi = qf[b][:, own[w]]
+            if wmask[b, w] > 0:
+                idx = torch.cat([own[w], rolled[w]])
+                kk = torch.cat([kf[b][tind][:, idx], pk[b][tind].reshape(len(tind), -1, heads, ch)], 1).reshape(-1, heads, ch)
+                vv = torch.cat([vf[b][tind][:, idx], pv[b][tind].reshape(len(tind), -1, heads, ch)], 1).reshape(-1, heads, ch)
+                a = torch.softmax(torch.einsum("qhc,khc->hqk", qi.reshape(-1, heads, ch), kk) / math.sqrt(ch), -1)
+                y = torch.einsum("hqk,khc->qhc", a, vv).reshape(T, -1, heads, ch)
+            else:
+                a = torch.softmax(torch.einsum("tqhc,tkhc->thqk", qi, kf[b][:, own[w]]) / math.sqrt(ch), -1)
+                y = torch.einsum("thqk,tkhc->tqhc", a, vf[b][:, own[w]])
+            out[b][:, own[w]] = y
+    return out.reshape(B, T, Hp, Wp, C)
+
+
+@pytest.mark.parametrize("variant", ["ref_f32", "ref_f16", "mfma_f16"])
+def test_sparse_window_attention(dev, variant):
+    from propainter_amd import hip
+    dt = torch.float32 if variant == "ref_f32" else torch.float16
+    g = torch.Generator().manual_seed(14)
+    B, T, Hp, Wp, C = 1, 5, 10, 18, 512
+    q, k, v = (torch.randn(B, T, Hp, Wp, C, generator=g) for _ in range(3))
+    q = q * 2.0
+    P = (Hp // 4) * (Wp // 4)
+    pk, pv = torch.randn(B, T, P, C, generator=g), torch.randn(B, T, P, C, generator=g)
+    own_np, rolled_np = hip.window_tables(Hp, Wp)
+    own, rolled = torch.from_numpy(own_np).long(), torch.from_numpy(rolled_np).long()
+    wmask = torch.tensor([[0.0, 2.0, 1.0, 0.0]])
+    tind = torch.tensor([1, 3])
+    cast = lambda a: a.to(dt).float()
+    ref = _attention_reference(cast(q), cast(k), cast(v), cast(pk), cast(pv), own, rolled, tind, wmask)
+    # fused buffers exercise the cstride path
+    qkv = torch.cat([q, k, v], -1).to(dev, dt).contiguous()
+    pkv = torch.cat([pk, pv], -1).to(dev, dt).contiguous()
+    out = hip.sparse_window_attention(qkv, qkv[..., C:], qkv[..., 2 * C:], pkv, pkv[..., C:], torch.from_numpy(own_np).to(dev),
+                                      torch.from_numpy(rolled_np).to(dev), tind.to(dev, torch.int32), wmask.to(dev),
+                                      qkv_cstride=3 * C, pkv_cstride=2 * C, C_=C, impl=0 if variant == "mfma_f16" else 1)
+    torch.cuda.synchronize()
+    check(variant, out, ref, 2e-4 if dt == torch.float32 else 6e-3)
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "f16"])
+def test_token_ops(dev, dt):
+    from propainter_amd import hip
+    g = torch.Generator().manual_seed(15)
+    BT, H, W, C = 2, 16, 24, 40
+    fh, fw = O.token_grid(H), O.token_grid(W)
+    tok = torch.randn(BT, fh * fw, C * 49, generator=g)
+    tq = tok.to(dt).float()
+    folded = F.fold(tq.permute(0, 2, 1), (H, W), 7, 1, 3, 3)
+    norm = F.fold(torch.ones_like(tq).permute(0, 2, 1), (H, W), 7, 1, 3, 3)
+    out = hip.fold_tokens(tok.to(dev, dt), BT, fh, fw, C, H, W, normalize=True, act=hip.ACT_GELU)
+    out2 = hip.fold_tokens(tok.to(dev, dt), BT, fh, fw, C, H, W, normalize=False)
+    torch.cuda.synchronize()
+    check("fold_norm_gelu", out.permute(0, 3, 1, 2), F.gelu(folded / norm), tol(dt))
+    check("fold", out2.permute(0, 3, 1, 2), folded, tol(dt))
+    x = torch.randn(3, 7, 512, generator=g) * 2 + 0.5
+    gam, bet = torch.rand(512, generator=g) + 0.5, torch.randn(512, generator=g)
+    ln = hip.layernorm(x.to(dev, dt), gam.to(dev), bet.to(dev))
+    torch.cuda.synchronize()
+    check("layernorm", ln, F.layer_norm(x.to(dt).float(), (512,), gam, bet), tol(dt))
+    xp = torch.randn(2, 512, 8, 12, generator=g)
+    pw, pb = torch.randn(512, 1, 4, 4, generator=g) / 16, torch.randn(512, generator=g) * 0.1
+    dp = hip.depthwise_pool(nhwc(xp, dt), pw.view(512, 4, 4).to(dev).contiguous(), pb.to(dev), 4)
+    torch.cuda.synchronize()
+    check("pool", dp.permute(0, 3, 1, 2), F.conv2d(xp.to(dt).float(), pw, pb, 4, 0, 1, 512), tol(dt))
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "f16"])
+def test_elementwise_ops(dev, dt):
+    from propainter_amd import hip
+    g = torch.Generator().manual_seed(16)
+    x = torch.randn(2, 96, 13, 17, generator=g) * 2 + 0.3
+    xq = x.to(dt).float()
+    out = hip.instance_norm(nhwc(x, dt), relu=True)
+    torch.cuda.synchronize()
+    check("instance_norm", out.permute(0, 3, 1, 2), F.relu(F.instance_norm(xq)), tol(dt, 2))
+    up = hip.upsample2x(nhwc(x, dt))
+    torch.cuda.synchronize()
+    check("upsample2x", up.permute(0, 3, 1, 2), F.interpolate(xq, scale_factor=2, mode="bilinear", align_corners=True), tol(dt))
+    zr = torch.rand(2, 256, 5, 6, generator=g)
+    h, q = torch.randn(2, 128, 5, 6, generator=g), torch.randn(2, 128, 5, 6, generator=g)
+    rh = torch.empty(2, 5, 6, 128, dtype=dt, device=dev)
+    hip.gru_gate(nhwc(zr, dt), nhwc(h, dt), 0, 128, rh, 0)
+    hn = nhwc(h, dt)
+    hip.gru_gate(nhwc(zr, dt), hn, 0, 128, hn, 0, q=nhwc(q, dt))
+    torch.cuda.synchronize()
+    zq, hq, qq = zr.to(dt).float(), h.to(dt).float(), q.to(dt).float()
+    check("gru_rh", rh.permute(0, 3, 1, 2), zq[:, 128:] * hq, tol(dt))
+    check("gru_h", hn.permute(0, 3, 1, 2), (1 - zq[:, :128]) * hq + zq[:, :128] * qq, tol(dt))
+    y = torch.randn(2, 3, 9, 10, generator=g)
+    buf = torch.zeros(2, 9, 10, 8, dtype=dt, device=dev)
+    hip.nchw_to_nhwc(y.to(dev), out=buf, out_choff=2)
+    back = hip.nhwc_to_nchw(buf, 3, choff=2, out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    check("layout_roundtrip", back, y, tol(dt))
+    assert (buf[..., :2] == 0).all() and (buf[..., 5:] == 0).all()
+    mask = (torch.rand(1, 3, 10, 18, generator=g) > 0.97).float()
+    wm = hip.window_mask(mask.to(dev, dt))
+    torch.cuda.synchronize()
+    ref = F.max_pool2d(mask, (5, 9), (5, 9)).view(1, 3, -1).sum(1)
+    assert torch.equal(wm.cpu(), ref)

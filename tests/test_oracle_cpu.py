@@ -1,0 +1,94 @@
+"""Pins the oracle (CPU restatement) against known answers, the committed golden vectors produced by the REAL
+reference, and — where /root/reference exists — the real reference itself."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import propainter_oracle as O
+from oracle.deform_conv_ref import deform_conv2d
+from oracle.ref_shims import reference_available
+from tests.helpers import load_golden, seeded_sds
+
+
+@pytest.fixture(scope="module")
+def sds():
+    return seeded_sds()
+
+
+def test_deform_conv_known_answers():
+    torch.manual_seed(0)
+    x, w, b = torch.randn(2, 32, 9, 11), torch.randn(8, 32, 3, 3), torch.randn(8)
+    off, m = torch.zeros(2, 288, 9, 11), torch.ones(2, 144, 9, 11)
+    assert (deform_conv2d(x, off, w, b, 1, 1, 1, m) - F.conv2d(x, w, b, 1, 1)).abs().max() < 1e-4
+    off[:, 0::2], off[:, 1::2] = 1.0, -2.0           # integer offsets == shifted convolution
+    xs = F.pad(x, (4, 4, 4, 4))[:, :, 4:4 + 11, 1:1 + 13]
+    assert (deform_conv2d(x, off, w, b, 1, 1, 1, m) - F.conv2d(xs, w, b, 1, 0)).abs().max() < 1e-4
+    m2 = torch.rand(2, 144, 9, 11)                    # modulation scales columns of the matching (group, tap)
+    y = deform_conv2d(x, torch.zeros_like(off), w, None, 1, 1, 1, m2)
+    cols = F.unfold(x, 3, 1, 1).view(2, 16, 2, 9, 99) * m2.view(2, 16, 1, 9, 99)
+    ref = (w.view(1, 8, -1) @ cols.reshape(2, 288, 99)).view(2, 8, 9, 11)
+    assert (y - ref).abs().max() < 1e-4
+
+
+def test_flow_warp_known_answers():
+    x = torch.arange(2 * 3 * 5 * 9, dtype=torch.float32).view(2, 3, 5, 9)     # W-1 = 8: exact grid round trip
+    z = torch.zeros(2, 5, 9, 2)
+    assert torch.allclose(O.flow_warp(x, z), x, atol=1e-4)
+    s = z.clone(); s[..., 0] = 1.0                    # sample x+1 -> shift left, zeros enter on the right
+    y = O.flow_warp(x, s)
+    assert torch.allclose(y[..., :-1], x[..., 1:]) and (y[..., -1] == 0).all()
+    hv = z.clone(); hv[..., 0] = 0.5                  # nearest: round-half-to-even
+    y = O.flow_warp(x, hv, "nearest")
+    assert torch.equal(y[0, 0, 0], torch.tensor([0., 2., 2., 4., 4., 6., 6., 8., 8.]))
+
+
+def test_oracle_matches_golden_raft(sds):
+    g = load_golden("raft_128x192.npz")
+    fr = torch.from_numpy(g["frames_u8"]).permute(0, 3, 1, 2).float().div(255)[None] * 2 - 1
+    ff, fb = O.raft_bi(sds["raft"], fr, int(g["iters"]))
+    assert (ff[0] - torch.from_numpy(g["flows_f"])).abs().max() < 1e-3
+    assert (fb[0] - torch.from_numpy(g["flows_b"])).abs().max() < 1e-3
+
+
+def test_oracle_matches_golden_fc(sds):
+    g = load_golden("fc_64x96.npz")
+    fl = (torch.from_numpy(g["flows_f"]), torch.from_numpy(g["flows_b"]))
+    m = torch.from_numpy(g["masks"])
+    pf, pb = O.fc_forward_bidirect(sds["fc"], fl, m)
+    assert (pf - torch.from_numpy(g["pred_f"])).abs().max() < 1e-4
+    assert (pb - torch.from_numpy(g["pred_b"])).abs().max() < 1e-4
+    cf, cb = O.fc_combine(fl, (pf, pb), m)
+    assert (cf - torch.from_numpy(g["comb_f"])).abs().max() < 1e-4
+
+
+def test_oracle_matches_golden_generator(sds):
+    g = load_golden("gen_64x96.npz")
+    fr, mk, mu = (torch.from_numpy(g[k]) for k in ("frames", "masks_in", "masks_upd"))
+    out = O.generator_forward(sds["gen"], fr * (1 - mk), (torch.from_numpy(g["flows_f"]), torch.from_numpy(g["flows_b"])),
+                              mk, mu, int(g["lt"]))
+    assert (out - torch.from_numpy(g["out"])).abs().max() < 2e-4
+    pi, pm = O.image_propagation(fr * (1 - mk), torch.from_numpy(g["ip_flows_f"]), torch.from_numpy(g["ip_flows_b"]), mk)
+    assert torch.equal(pi, torch.from_numpy(g["ip_frames"])) and torch.equal(pm, torch.from_numpy(g["ip_masks"]))
+
+
+@pytest.mark.skipif(not reference_available(), reason="/root/reference only exists in the authoring container")
+def test_oracle_matches_real_reference(sds):
+    from oracle.ref_shims import build_reference_raft, load_reference
+    ns = load_reference()
+    torch.manual_seed(3)
+    raft = build_reference_raft(); raft.load_state_dict(sds["raft"])
+    a, b = torch.rand(1, 3, 128, 192) * 2 - 1, torch.rand(1, 3, 128, 192) * 2 - 1
+    with torch.no_grad():
+        lo, up = raft(a, b, iters=3, test_mode=True)
+        lo2, up2 = O.raft_forward(sds["raft"], a, b, 3)
+    assert (up - up2).abs().max() < 1e-4
+    gen = ns.InpaintGenerator().eval(); gen.load_state_dict(sds["gen"])
+    H, W, t, lt = 64, 96, 4, 3
+    fr = torch.rand(1, t, 3, H, W) * 2 - 1
+    mk = torch.zeros(1, t, 1, H, W); mk[..., 10:30, 50:80] = 1
+    fl = (torch.randn(1, lt - 1, 2, H, W), torch.randn(1, lt - 1, 2, H, W))
+    with torch.no_grad():
+        y = gen(fr * (1 - mk), fl, mk, mk, lt)
+        y2 = O.generator_forward(sds["gen"], fr * (1 - mk), fl, mk, mk, lt)
+    assert (y - y2).abs().max() < 2e-4
