@@ -131,7 +131,7 @@ class ConvLayer:
             assert self.dcn and dcn_offmask.dtype == self.dtype and dcn_offmask.is_contiguous()
             a.dcn_offmask, a.dcn_cstride, a.dcn_mask_off = dcn_offmask.data_ptr(), dcn_offmask.shape[-1], 288
         self._keep = (srcs, out, residual, dcn_offmask)
-        hip.conv2d_raw(a)
+        hip.conv2d_raw(a, cin_read=sum(self.src_cpad) * self.groups)
         return out
 
 
@@ -160,5 +160,5 @@ def batched_gemm_nt(a, bt, out_scale=1.0):
     g.out_dtype = hip.PP_F32
     g.out, g.out_cstride, g.out_choff, g.out_cgroup = out.data_ptr(), Nn, 0, 0
     g.src_gstride, g.out_gstride = M * K, M * Nn
-    hip.conv2d_raw(g)
+    hip.conv2d_raw(g, cin_read=K * B)
     return out

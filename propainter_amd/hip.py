@@ -79,6 +79,57 @@ def _check(rc, what):
         raise RuntimeError(f"{what} failed (code {rc}): {msg}")
 
 
+class KernelProfiler:
+    """Per-kernel-class HIP-event timing of the C-ABI launches (used by bench.py for the roofline figures).
+
+    While installed (``with KernelProfiler() as kp``) every launch that goes through ``timed()`` is bracketed by a
+    pair of HIP events recorded on the stream the kernel is launched on (torch's current stream) and tagged with its
+    algorithmic FLOPs / bytes.  ``summary()`` synchronises and aggregates per class."""
+
+    def __init__(self):
+        self.records = []          # (name, flops, bytes, ev0, ev1)
+
+    def __enter__(self):
+        global _profiler
+        self._prev, _profiler = _profiler, self
+        return self
+
+    def __exit__(self, *exc):
+        global _profiler
+        _profiler = self._prev
+        return False
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, fl, by, e0, e1 in self.records:
+            a = agg.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            a["launches"] += 1
+            a["ms"] += e0.elapsed_time(e1)
+            a["flops"] += fl
+            a["bytes"] += by
+        return agg
+
+
+_profiler = None
+
+
+def _nbytes(t):
+    return t.numel() * t.element_size()
+
+
+def timed(name, flops, nbytes, fn):
+    """Runs ``fn()`` (one kernel launch); records HIP events around it when a KernelProfiler is installed."""
+    if _profiler is None:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn()
+    e1.record()
+    _profiler.records.append((name, float(flops), float(nbytes), e0, e1))
+    return r
+
+
 def dtype_code(dt):
     if dt == torch.float32:
         return PP_F32
@@ -150,8 +201,23 @@ def window_tables(Hp, Wp, wh=5, ww=9):
 # ----------------------------------------------------------------------------------------------
 # device ops
 # ----------------------------------------------------------------------------------------------
-def conv2d_raw(args: ConvArgs):
-    _check(lib().pp_conv2d(C.byref(args), _stream()), "pp_conv2d")
+def conv2d_raw(args: ConvArgs, cin_read=None):
+    """cin_read: channels read per input pixel (for the profiler's byte model; defaults to K per group x groups)."""
+    if _profiler is None:
+        _check(lib().pp_conv2d(C.byref(args), _stream()), "pp_conv2d")
+        return
+    # algorithmic work of this launch: 2*M*Cout*K FLOPs; bytes = sources read once + weights + output written once
+    M = args.N * args.OH * args.OW
+    K = args.kchunks * 8
+    esz = 2 if args.dtype == PP_F16 else 4
+    osz = 2 if args.out_dtype == PP_F16 else 4
+    flops = 2.0 * M * args.cout_g * K * args.groups
+    cin = cin_read if cin_read is not None else K * args.groups
+    nbytes = args.N * args.H * args.W * cin * esz + args.groups * args.cout_pad * K * esz + M * args.cout_g * args.groups * osz
+    if args.dcn_offmask:
+        nbytes += M * 432 * esz
+    name = "conv_gemm_dcn" if args.dcn_offmask else ("conv_gemm_f16" if args.dtype == PP_F16 else "conv_gemm_f32")
+    timed(name, flops, nbytes, lambda: _check(lib().pp_conv2d(C.byref(args), _stream()), "pp_conv2d"))
 
 
 def flow_warp(x, flow, out=None, mode="bilinear", x_choff=0, C_=None, fl_choff=0, out_choff=0):
@@ -161,9 +227,10 @@ def flow_warp(x, flow, out=None, mode="bilinear", x_choff=0, C_=None, fl_choff=0
     if out is None:
         out = torch.empty((N, H, W, C_), dtype=x.dtype, device=x.device)
     assert x.is_contiguous() and flow.is_contiguous() and out.is_contiguous() and flow.dtype == x.dtype
-    _check(lib().pp_flow_warp(_p(x), _i(Cx), _i(x_choff), _p(flow), _i(flow.shape[-1]), _i(fl_choff), _p(out),
+    timed("flow_warp", 0, _nbytes(out) * 2 + _nbytes(flow), lambda: _check(lib().pp_flow_warp(_p(x), _i(Cx), _i(x_choff), _p(flow), _i(flow.shape[-1]), _i(fl_choff), _p(out),
                               _i(out.shape[-1]), _i(out_choff), _i(N), _i(H), _i(W), _i(C_),
-                              _i(1 if mode == "nearest" else 0), _i(dtype_code(x.dtype)), _stream()), "pp_flow_warp")
+                              _i(1 if mode == "nearest" else 0), _i(dtype_code(x.dtype)), _stream()),
+           "pp_flow_warp"))
     return out
 
 
@@ -173,9 +240,10 @@ def fb_check(flow_fw, flow_bw, out=None, out_choff=0):
     if out is None:
         out = torch.empty((N, H, W, 1), dtype=flow_fw.dtype, device=flow_fw.device)
     assert flow_fw.is_contiguous() and flow_bw.is_contiguous() and out.is_contiguous()
-    _check(lib().pp_fb_check(_p(flow_fw), _i(flow_fw.shape[-1]), _p(flow_bw), _i(flow_bw.shape[-1]), _p(out),
+    timed("fb_check", 0, _nbytes(flow_fw) * 3, lambda: _check(lib().pp_fb_check(_p(flow_fw), _i(flow_fw.shape[-1]), _p(flow_bw), _i(flow_bw.shape[-1]), _p(out),
                              _i(out.shape[-1]), _i(out_choff), _i(N), _i(H), _i(W), _i(dtype_code(flow_fw.dtype)),
-                             _stream()), "pp_fb_check")
+                             _stream()),
+           "pp_fb_check"))
     return out
 
 
@@ -184,15 +252,16 @@ def img_prop_step(x_prop, m_prop, x_cur, m_cur, flow_prop, flow_check, x_out, m_
     N, Cc, H, W = x_cur.shape
     for t in (x_prop, m_prop, x_cur, m_cur, flow_prop, flow_check, x_out, m_out):
         assert t.is_contiguous() and t.dtype == x_cur.dtype
-    _check(lib().pp_img_prop_step(_p(x_prop), _p(m_prop), _p(x_cur), _p(m_cur), _p(flow_prop), _p(flow_check),
+    timed("img_prop_step", 0, _nbytes(x_prop) + _nbytes(m_prop) + _nbytes(x_cur) + _nbytes(m_cur) + _nbytes(flow_prop) + _nbytes(flow_check) + _nbytes(x_out) + _nbytes(m_out), lambda: _check(lib().pp_img_prop_step(_p(x_prop), _p(m_prop), _p(x_cur), _p(m_cur), _p(flow_prop), _p(flow_check),
                                   _p(x_out), _p(m_out), _i(N), _i(Cc), _i(H), _i(W),
                                   _i(1 if mode == "nearest" else 0), _i(dtype_code(x_cur.dtype)), _stream()),
-           "pp_img_prop_step")
+           "pp_img_prop_step"))
 
 
 def corr_avgpool(x, M, H, W):
     out = torch.empty((M, H // 2, W // 2), dtype=torch.float32, device=x.device)
-    _check(lib().pp_corr_avgpool(_p(x), _p(out), C.c_int64(M), _i(H), _i(W), _stream()), "pp_corr_avgpool")
+    timed("corr_avgpool", 0, _nbytes(out) * 5, lambda: _check(lib().pp_corr_avgpool(_p(x), _p(out), C.c_int64(M), _i(H), _i(W), _stream()),
+           "pp_corr_avgpool"))
     return out
 
 
@@ -200,9 +269,10 @@ def corr_lookup(levels, coords, out):
     """levels: 4 fp32 tensors [B*h*w, Hl, Wl]; coords fp32 [B,h,w,2]; out NHWC [B,h,w,Cpad>=324]."""
     B, h, w, _ = coords.shape
     assert coords.dtype == torch.float32 and coords.is_contiguous() and out.is_contiguous()
-    _check(lib().pp_corr_lookup(_p(levels[0]), _p(levels[1]), _p(levels[2]), _p(levels[3]), _p(coords), _p(out),
+    timed("corr_lookup", 0, B * h * w * 4 * 100 * 4 + _nbytes(out), lambda: _check(lib().pp_corr_lookup(_p(levels[0]), _p(levels[1]), _p(levels[2]), _p(levels[3]), _p(coords), _p(out),
                                 _i(out.shape[-1]), _i(out.shape[-1]), _i(B), _i(h), _i(w), _i(dtype_code(out.dtype)),
-                                _stream()), "pp_corr_lookup")
+                                _stream()),
+           "pp_corr_lookup"))
     return out
 
 
@@ -211,8 +281,9 @@ def convex_upsample(flow, mask):
     B, h, w, _ = flow.shape
     out = torch.empty((B, 2, 8 * h, 8 * w), dtype=torch.float32, device=flow.device)
     assert flow.dtype == torch.float32 and flow.is_contiguous() and mask.is_contiguous()
-    _check(lib().pp_convex_upsample(_p(flow), _p(mask), _i(mask.shape[-1]), _i(dtype_code(mask.dtype)), _p(out),
-                                    _i(B), _i(h), _i(w), _stream()), "pp_convex_upsample")
+    timed("convex_upsample", 0, _nbytes(flow) + _nbytes(mask) + _nbytes(out), lambda: _check(lib().pp_convex_upsample(_p(flow), _p(mask), _i(mask.shape[-1]), _i(dtype_code(mask.dtype)), _p(out),
+                                    _i(B), _i(h), _i(w), _stream()),
+           "pp_convex_upsample"))
     return out
 
 
@@ -221,8 +292,9 @@ def window_mask(mask, wh=5, ww=9):
     B, Lt, Hp, Wp = mask.shape
     out = torch.empty((B, (Hp // wh) * (Wp // ww)), dtype=torch.float32, device=mask.device)
     assert mask.is_contiguous()
-    _check(lib().pp_window_mask(_p(mask), _p(out), _i(B), _i(Lt), _i(Hp), _i(Wp), _i(wh), _i(ww),
-                                _i(dtype_code(mask.dtype)), _stream()), "pp_window_mask")
+    timed("window_mask", 0, _nbytes(mask) + _nbytes(out), lambda: _check(lib().pp_window_mask(_p(mask), _p(out), _i(B), _i(Lt), _i(Hp), _i(Wp), _i(wh), _i(ww),
+                                _i(dtype_code(mask.dtype)), _stream()),
+           "pp_window_mask"))
     return out
 
 
@@ -251,7 +323,19 @@ def sparse_window_attention(q, k, v, pk, pv, own, rolled, tind, wmask, heads=4, 
         if not t.is_cuda:
             raise RuntimeError("sparse_window_attention needs GPU tensors")
     assert own.dtype == torch.int32 and rolled.dtype == torch.int32 and tind.dtype == torch.int32
-    _check(lib().pp_sparse_window_attention(C.byref(a), _stream()), "pp_sparse_window_attention")
+    if _profiler is None:
+        _check(lib().pp_sparse_window_attention(C.byref(a), _stream()), "pp_sparse_window_attention")
+        return out
+    # algorithmic work (profiling only; reads the window flags back): QK^T + PV = 4 FLOP per (query, key, channel)
+    nmask = int((wmask > 0).sum().item())
+    nW = wmask.numel()
+    wsz = wh * ww
+    keys_m = a.n_tind * (wsz + a.n_rolled + a.P)
+    flops = 4.0 * C_ * (nmask * (T * wsz) * keys_m + (nW - nmask) * T * wsz * wsz)
+    esz = q.element_size()
+    nbytes = (3 * B * T * Hp * Wp * C_ + 2 * B * T * a.P * C_ + B * T * Hp * Wp * C_) * esz
+    timed("sparse_window_attention", flops, nbytes,
+          lambda: _check(lib().pp_sparse_window_attention(C.byref(a), _stream()), "pp_sparse_window_attention"))
     return out
 
 
@@ -259,9 +343,9 @@ def fold_tokens(tokens, BT, fh, fw, Cc, H, W, normalize=False, act=ACT_NONE):
     """tokens [BT, fh*fw, Cc*49] -> NHWC [BT,H,W,Cc]."""
     out = torch.empty((BT, H, W, Cc), dtype=tokens.dtype, device=tokens.device)
     assert tokens.is_contiguous()
-    _check(lib().pp_fold_tokens(_p(tokens), _p(out), _i(BT), _i(fh), _i(fw), _i(Cc), _i(H), _i(W),
+    timed("fold_tokens", 0, _nbytes(tokens) + _nbytes(out), lambda: _check(lib().pp_fold_tokens(_p(tokens), _p(out), _i(BT), _i(fh), _i(fw), _i(Cc), _i(H), _i(W),
                                 _i(1 if normalize else 0), _i(act), _i(dtype_code(tokens.dtype)), _stream()),
-           "pp_fold_tokens")
+           "pp_fold_tokens"))
     return out
 
 
@@ -270,8 +354,9 @@ def layernorm(x, gamma, beta, eps=1e-5):
     Cc = x.shape[-1]
     out = torch.empty_like(x)
     assert x.is_contiguous() and gamma.dtype == torch.float32 and beta.dtype == torch.float32
-    _check(lib().pp_layernorm(_p(x), _p(gamma), _p(beta), _p(out), C.c_int64(x.numel() // Cc), _i(Cc),
-                              C.c_float(eps), _i(dtype_code(x.dtype)), _stream()), "pp_layernorm")
+    timed("layernorm", 0, _nbytes(x) + _nbytes(out), lambda: _check(lib().pp_layernorm(_p(x), _p(gamma), _p(beta), _p(out), C.c_int64(x.numel() // Cc), _i(Cc),
+                              C.c_float(eps), _i(dtype_code(x.dtype)), _stream()),
+           "pp_layernorm"))
     return out
 
 
@@ -280,8 +365,9 @@ def depthwise_pool(x, weight, bias, k=4):
     N, H, W, Cc = x.shape
     out = torch.empty((N, H // k, W // k, Cc), dtype=x.dtype, device=x.device)
     assert x.is_contiguous() and weight.dtype == torch.float32
-    _check(lib().pp_depthwise_pool(_p(x), _p(weight), _p(bias), _p(out), _i(N), _i(H), _i(W), _i(Cc), _i(k),
-                                   _i(dtype_code(x.dtype)), _stream()), "pp_depthwise_pool")
+    timed("depthwise_pool", 0, _nbytes(x) + _nbytes(out), lambda: _check(lib().pp_depthwise_pool(_p(x), _p(weight), _p(bias), _p(out), _i(N), _i(H), _i(W), _i(Cc), _i(k),
+                                   _i(dtype_code(x.dtype)), _stream()),
+           "pp_depthwise_pool"))
     return out
 
 
@@ -290,8 +376,9 @@ def instance_norm(x, relu=False, eps=1e-5, out=None):
     out = torch.empty_like(x) if out is None else out
     ws = torch.empty((N * Cc * 2,), dtype=torch.float32, device=x.device)
     assert x.is_contiguous()
-    _check(lib().pp_instance_norm(_p(x), _p(out), _p(ws), _i(N), _i(H), _i(W), _i(Cc), C.c_float(eps),
-                                  _i(1 if relu else 0), _i(dtype_code(x.dtype)), _stream()), "pp_instance_norm")
+    timed("instance_norm", 0, _nbytes(x) * 2 + _nbytes(out), lambda: _check(lib().pp_instance_norm(_p(x), _p(out), _p(ws), _i(N), _i(H), _i(W), _i(Cc), C.c_float(eps),
+                                  _i(1 if relu else 0), _i(dtype_code(x.dtype)), _stream()),
+           "pp_instance_norm"))
     return out
 
 
@@ -299,8 +386,8 @@ def upsample2x(x):
     N, H, W, Cc = x.shape
     out = torch.empty((N, 2 * H, 2 * W, Cc), dtype=x.dtype, device=x.device)
     assert x.is_contiguous()
-    _check(lib().pp_upsample2x(_p(x), _p(out), _i(N), _i(H), _i(W), _i(Cc), _i(dtype_code(x.dtype)), _stream()),
-           "pp_upsample2x")
+    timed("upsample2x", 0, _nbytes(x) + _nbytes(out), lambda: _check(lib().pp_upsample2x(_p(x), _p(out), _i(N), _i(H), _i(W), _i(Cc), _i(dtype_code(x.dtype)), _stream()),
+           "pp_upsample2x"))
     return out
 
 
@@ -308,20 +395,20 @@ def dcn_offset_mask_act(offmask, mag, flow=None, fl_choff=0):
     """in place on NHWC [N,H,W,432(+pad)]."""
     npix = offmask.numel() // offmask.shape[-1]
     assert offmask.is_contiguous() and (flow is None or (flow.is_contiguous() and flow.dtype == offmask.dtype))
-    _check(lib().pp_dcn_offset_mask_act(_p(offmask), _i(offmask.shape[-1]), _p(flow),
+    timed("dcn_offset_mask_act", 0, _nbytes(offmask) * 2, lambda: _check(lib().pp_dcn_offset_mask_act(_p(offmask), _i(offmask.shape[-1]), _p(flow),
                                         _i(flow.shape[-1] if flow is not None else 0), _i(fl_choff), C.c_float(mag),
                                         C.c_int64(npix), _i(dtype_code(offmask.dtype)), _stream()),
-           "pp_dcn_offset_mask_act")
+           "pp_dcn_offset_mask_act"))
     return offmask
 
 
 def gru_gate(zr, h, h_choff, Cc, out, out_choff, q=None):
     """mode 0 (q is None): out = r*h with r = zr[..., C:2C]; mode 1: out = (1-z)*h + z*q, z = zr[..., :C]."""
     npix = zr.numel() // zr.shape[-1]
-    _check(lib().pp_gru_gate(_p(zr), _i(zr.shape[-1]), _p(h), _i(h.shape[-1]), _i(h_choff), _p(q),
+    timed("gru_gate", 0, npix * Cc * 4 * zr.element_size(), lambda: _check(lib().pp_gru_gate(_p(zr), _i(zr.shape[-1]), _p(h), _i(h.shape[-1]), _i(h_choff), _p(q),
                              _i(q.shape[-1] if q is not None else 0), _p(out), _i(out.shape[-1]), _i(out_choff),
                              C.c_int64(npix), _i(Cc), _i(0 if q is None else 1), _i(dtype_code(zr.dtype)), _stream()),
-           "pp_gru_gate")
+           "pp_gru_gate"))
     return out
 
 
@@ -333,9 +420,10 @@ def nchw_to_nhwc(x, out=None, out_choff=0, out_dtype=None, cpad=None, scale=1.0)
         dt = out_dtype or x.dtype
         out = (torch.zeros if cpad != Cc else torch.empty)((N, H, W, cpad), dtype=dt, device=x.device)
     assert x.is_contiguous() and out.is_contiguous()
-    _check(lib().pp_nchw_to_nhwc(_p(x), _i(dtype_code(x.dtype)), _p(out), _i(dtype_code(out.dtype)),
+    timed("nchw_to_nhwc", 0, _nbytes(x) * 2, lambda: _check(lib().pp_nchw_to_nhwc(_p(x), _i(dtype_code(x.dtype)), _p(out), _i(dtype_code(out.dtype)),
                                  _i(out.shape[-1]), _i(out_choff), _i(N), _i(Cc), _i(H), _i(W), C.c_float(scale),
-                                 _stream()), "pp_nchw_to_nhwc")
+                                 _stream()),
+           "pp_nchw_to_nhwc"))
     return out
 
 
@@ -344,7 +432,7 @@ def nhwc_to_nchw(x, Cc=None, choff=0, out_dtype=None, act=ACT_NONE):
     Cc = Cs if Cc is None else Cc
     out = torch.empty((N, Cc, H, W), dtype=out_dtype or x.dtype, device=x.device)
     assert x.is_contiguous()
-    _check(lib().pp_nhwc_to_nchw(_p(x), _i(dtype_code(x.dtype)), _i(Cs), _i(choff), _p(out),
+    timed("nhwc_to_nchw", 0, _nbytes(out) * 2, lambda: _check(lib().pp_nhwc_to_nchw(_p(x), _i(dtype_code(x.dtype)), _i(Cs), _i(choff), _p(out),
                                  _i(dtype_code(out.dtype)), _i(N), _i(Cc), _i(H), _i(W), _i(act), _stream()),
-           "pp_nhwc_to_nchw")
+           "pp_nhwc_to_nchw"))
     return out

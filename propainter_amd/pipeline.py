@@ -146,9 +146,12 @@ class Compositor:
 
 
 @torch.no_grad()
-def run_clip(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg: InferenceConfig, device, return_stages=False):
+def run_clip(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg: InferenceConfig, device, return_stages=False,
+             stage_hook=None):
     """Whole path for one clip.  frames_u8 [L,H,W,3] uint8, masks [L,H,W] uint8 {0,255} (numpy or tensors).
-    models = (RAFT_bi, RecurrentFlowCompleteNet, InpaintGenerator).  Returns uint8 tensor [L,H,W,3] on `device`."""
+    models = (RAFT_bi, RecurrentFlowCompleteNet, InpaintGenerator).  Returns uint8 tensor [L,H,W,3] on `device`.
+    ``stage_hook(name)`` (optional) is called at every stage boundary (bench.py records HIP events there)."""
+    mark = stage_hook or (lambda name: None)
     fix_raft, fix_flow_complete, model = models
     to_t = lambda a: a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))
     fr_u8 = to_t(frames_u8).to(device)
@@ -156,18 +159,23 @@ def run_clip(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg: InferenceC
     flow_masks = to_t(flow_masks_u8).to(device).float().div(255)[None, :, None]
     masks_dilated = to_t(masks_dilated_u8).to(device).float().div(255)[None, :, None]
     L = frames.size(1)
+    mark('start')
     gt_flows_bi = compute_flows(fix_raft, frames, cfg.raft_iter)
+    mark('raft')
     if cfg.fp16:                                                               # (:333-337)
         frames, flow_masks, masks_dilated = frames.half(), flow_masks.half(), masks_dilated.half()
         gt_flows_bi = (gt_flows_bi[0].half(), gt_flows_bi[1].half())
     pred_flows_bi = complete_flows(fix_flow_complete, gt_flows_bi, flow_masks, cfg.subvideo_length)
+    mark('flow_completion')
     updated_frames, updated_masks = propagate_images(model, frames, masks_dilated, pred_flows_bi, cfg.subvideo_length)
+    mark('image_propagation')
     comp = Compositor(fr_u8, masks_dilated)
     for nb, ref in window_schedule(L, cfg.neighbor_length, cfg.ref_stride, cfg.subvideo_length):
         ids = nb + ref
         pred = model(updated_frames[:, ids], (pred_flows_bi[0][:, nb[:-1]], pred_flows_bi[1][:, nb[:-1]]),
                      masks_dilated[:, ids], updated_masks[:, ids], len(nb))
         comp.add(nb, pred[0])
+    mark('generator')
     if return_stages:
         return comp.comp, dict(gt_flows=gt_flows_bi, pred_flows=pred_flows_bi, updated_frames=updated_frames,
                                updated_masks=updated_masks)

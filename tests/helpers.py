@@ -13,18 +13,7 @@ def load_golden(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
 
 
-def seeded_models(device="cpu", raft_dtype=None):
-    """Our three modules with the repo-wide seeded weights (same values the goldens were generated with)."""
-    from propainter_amd.model.modules.flow_comp_raft import RAFT_bi
-    from propainter_amd.model.propainter import InpaintGenerator
-    from propainter_amd.model.recurrent_flow_completion import RecurrentFlowCompleteNet
-    raft = RAFT_bi(model_path=None, device="cpu", compute_dtype=raft_dtype)
-    raft.fix_raft.load_state_dict(seeded_weights("raft", raft.fix_raft.state_dict()), strict=True)
-    fc = RecurrentFlowCompleteNet()
-    fc.load_state_dict(seeded_weights("fc", fc.state_dict()), strict=True)
-    gen = InpaintGenerator(init_weights=True)
-    gen.load_state_dict(seeded_weights("gen", gen.state_dict()), strict=True)
-    return raft.to(device).eval(), fc.to(device).eval(), gen.to(device).eval()
+from propainter_amd.synthetic import seeded_models  # noqa: E402,F401
 
 
 def seeded_sds():
