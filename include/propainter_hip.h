@@ -81,10 +81,11 @@ typedef struct {
   int32_t groups;                /* grid.z; also used as the batch count of a batched GEMM     */
   int32_t cout_g;                /* real output channels per group                             */
   int32_t cout_pad;              /* rows per group present in `weight` (>= cout_g; extra rows 0) */
-  int32_t kchunks;               /* K/8 per group, multiple of 4                               */
+  int32_t kchunks;               /* K/8 per group, multiple of 8 (pp_conv_build_ktable pads)   */
   int32_t nsrc;
   pp_conv_src_t src[PP_CONV_MAX_SRC];
-  const int32_t* ktable;         /* device, kchunks x int4 {dy, dx, src | g<<8 | tap<<16, choff}; src 255 = zero chunk */
+  const int32_t* ktable;         /* device, (kchunks + 1) x int4 {dy, dx, src | g<<8 | tap<<16, choff}; src 255 = zero
+                                    chunk; entry [kchunks] is all-zero (the kernels' 16-byte zero page)            */
   const void* weight;            /* device, packed [groups][cout_pad][kchunks*8], dtype        */
   int64_t weight_gstride;        /* elements between groups in `weight` (cout_pad*K normally)  */
   const float* bias;             /* device fp32 [groups*cout_g] or NULL                        */
@@ -105,12 +106,19 @@ typedef struct {
   const void* dcn_offmask;
   int32_t dcn_cstride;
   int32_t dcn_mask_off;          /* channel index of the first modulation mask (288)           */
+  int32_t impl;                  /* 0 = auto; 1 = force the register-staged kernel; 2 = LDS-DMA kernel without the
+                                    uniform-step fast path; >= 10 = a specific LDS-DMA tile configuration (+100: no
+                                    fast path) (fp16 only; tile sweeps, see csrc/conv_gemm_v2.hip)                */
+  int32_t ktable_uniform;        /* bit mask describing `ktable`: 4 / 8 set when every aligned run of 4 / 8 chunks is one
+                                    (tap, source) with consecutive channel offsets (true when every source has a
+                                    multiple of 32 / 64 channels); 0 = unknown (always correct)                   */
 } pp_conv_args_t;
 
 /* Host helper: fill `out` (kchunks_padded x 4 int32) for `ntaps` taps (dy[i], dx[i] are input
  * offsets added to out*stride - pad) over `nsrc` sources of src_channels[i] channels each (each a
  * multiple of 8).  `dcn_groups` > 0 additionally records the offset-group / tap id of every chunk.
- * Returns the padded chunk count (multiple of 4) or a negative error; call with out == NULL to size. */
+ * Returns the padded chunk count `kchunks` (multiple of 8) or a negative error; call with out == NULL to size.
+ * The buffer must hold kchunks + 1 entries: the last one is written as 16 zero bytes. */
 int pp_conv_build_ktable(int ntaps, const int32_t* dy, const int32_t* dx, int nsrc,
                          const int32_t* src_channels, int dcn_groups, int32_t* out, int out_capacity);
 

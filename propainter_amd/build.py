@@ -7,7 +7,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libpropainter_hip.so")
-SOURCES = ["api.hip", "conv_gemm.hip", "sampling.hip", "raft_ops.hip", "token_ops.hip", "attention.hip"]
+SOURCES = ["api.hip", "conv_gemm.hip", "conv_gemm_v2.hip", "sampling.hip", "raft_ops.hip", "token_ops.hip", "attention.hip"]
 
 
 def _hipcc():
@@ -21,7 +21,7 @@ def needs_build():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.h"),
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_params.h"),
                                                          os.path.join(PKG_DIR, "..", "include", "propainter_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 

@@ -32,7 +32,7 @@ def fold_batchnorm(weight, bias, bn_weight, bn_bias, mean, var, eps=1e-5):
     return w.float(), b.float()
 
 
-def pack_weight(weight, src_channels, groups=1, k_multiple=32):
+def pack_weight(weight, src_channels, groups=1, k_multiple=64):
     """weight [Cout, Cin_g, kh, kw] (any float dtype, CPU or GPU) -> (packed fp32 [groups, cout_pad, K], K, cout_g).
     K order = (ky, kx, source, channel) with every source padded to a multiple of 8 channels."""
     w = weight.detach().float()
@@ -79,10 +79,13 @@ class ConvLayer:
         if taps is None:
             taps = [(ky * self.dilation[0], kx * self.dilation[1]) for ky in range(kh) for kx in range(kw)]
         kt = hip.build_ktable(taps, self.src_cpad, dcn_groups)
-        assert kt.shape[0] * 8 == K, (kt.shape, K)
-        self.kchunks = kt.shape[0]
+        assert (kt.shape[0] - 1) * 8 == K, (kt.shape, K)     # + the trailing zero-page entry
+        self.kchunks = kt.shape[0] - 1
         self.ktable = torch.from_numpy(kt).to(device)
         self.dcn = dcn_groups > 0
+        # K steps of 4 / 8 chunks are (tap, source)-uniform when every source is a multiple of 32 / 64 channels
+        self.ktable_uniform = (4 if all(c % 32 == 0 for c in self.src_cpad) else 0) | (8 if all(c % 64 == 0 for c in self.src_cpad) else 0)
+        self.impl = 0            # pp_conv_args_t.impl: 0 auto, 1 register-staged kernel, >= 10 a specific LDS-DMA tile
 
     def out_hw(self, H, W):
         OH = (H + 2 * self.padding[0] - self.dilation[0] * (self.kh - 1) - 1) // self.stride[0] + 1
@@ -130,6 +133,8 @@ class ConvLayer:
         if dcn_offmask is not None:
             assert self.dcn and dcn_offmask.dtype == self.dtype and dcn_offmask.is_contiguous()
             a.dcn_offmask, a.dcn_cstride, a.dcn_mask_off = dcn_offmask.data_ptr(), dcn_offmask.shape[-1], 288
+        a.impl = self.impl
+        a.ktable_uniform = self.ktable_uniform
         self._keep = (srcs, out, residual, dcn_offmask)
         hip.conv2d_raw(a, cin_read=sum(self.src_cpad) * self.groups)
         return out
@@ -143,7 +148,7 @@ def batched_gemm_nt(a, bt, out_scale=1.0):
     Used for the RAFT all-pairs correlation volume (RAFT/corr.py:52-60)."""
     B, M, K = a.shape
     Bb, Nn, Kb = bt.shape
-    assert B == Bb and K == Kb and K % 32 == 0 and a.dtype == bt.dtype and a.is_contiguous() and bt.is_contiguous()
+    assert B == Bb and K == Kb and K % 64 == 0 and a.dtype == bt.dtype and a.is_contiguous() and bt.is_contiguous()
     key = (K, str(a.device))
     if key not in _gemm_tables:
         _gemm_tables[key] = torch.from_numpy(hip.build_ktable([(0, 0)], [K])).to(a.device)
@@ -158,6 +163,7 @@ def batched_gemm_nt(a, bt, out_scale=1.0):
     g.ktable, g.weight, g.weight_gstride = kt.data_ptr(), bt.data_ptr(), Nn * K
     g.act, g.out_scale, g.act2 = hip.ACT_NONE, float(out_scale), hip.ACT_NONE
     g.out_dtype = hip.PP_F32
+    g.ktable_uniform = 12
     g.out, g.out_cstride, g.out_choff, g.out_cgroup = out.data_ptr(), Nn, 0, 0
     g.src_gstride, g.out_gstride = M * K, M * Nn
     hip.conv2d_raw(g, cin_read=K * B)

@@ -48,15 +48,21 @@ template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ _Float16 from_f32<_Float16>(float v) { return (_Float16)v; }
 
-__device__ __forceinline__ float apply_act(float v, int act, float param) {
+// Transcendental activations live in one out-of-line function so that the (fully unrolled) GEMM epilogues stay small.
+static __device__ __noinline__ float apply_act_special(float v, int act) {
   switch (act) {
-    case PP_ACT_RELU: return v > 0.f ? v : 0.f;
-    case PP_ACT_LRELU: return v > 0.f ? v : v * param;
     case PP_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
     case PP_ACT_TANH: return tanhf(v);
     case PP_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
     default: return v;
   }
+}
+
+__device__ __forceinline__ float apply_act(float v, int act, float param) {
+  // none / relu / leaky-relu share one branch-free form: v > 0 ? v : v * slope
+  const float slope = act == PP_ACT_NONE ? 1.f : (act == PP_ACT_LRELU ? param : 0.f);
+  if (act >= PP_ACT_SIGMOID) return apply_act_special(v, act);
+  return v > 0.f ? v : (act == PP_ACT_RELU ? 0.f : v * slope);
 }
 
 // Loads `n` (<= 8) consecutive elements as fp32.

@@ -13,34 +13,9 @@
 // up with 4 consecutive output channels of one pixel -> 8/16-byte NHWC stores.
 //   fp16: v_mfma_f32_16x16x32_f16 (8 k per lane);  fp32: v_mfma_f32_16x16x4_f32 (exact fp32).
 // LDS rows are padded by 16 bytes (stride 80 B fp16 / 144 B fp32) to spread the ds_read_b128 lanes.
-#include "common.h"
+#include "conv_params.h"
 
 namespace pp {
-
-struct ConvSrc {
-  const char* ptr;
-  int cstride, choff, cgroup;
-};
-
-struct ConvParams {
-  int N, H, W, OH, OW, sh, sw, ph, pw, pad_mode;
-  int cout_g, cout_pad, kchunks, nsrc;
-  ConvSrc src[PP_CONV_MAX_SRC];
-  const int4* ktable;
-  const char* weight;
-  long long weight_gstride;
-  const float* bias;
-  int act;
-  float act_param, out_scale;
-  const char* residual;
-  int res_cstride, res_choff, act2, out_f16;
-  char* out;
-  int out_cstride, out_choff, out_cgroup;
-  long long src_gstride, out_gstride;
-  const char* dcn;
-  int dcn_cstride, dcn_mask_off;
-  long long M;
-};
 
 template <typename T> struct Mma;
 template <> struct Mma<_Float16> {
@@ -362,9 +337,9 @@ extern "C" int pp_conv_build_ktable(int ntaps, const int32_t* dy, const int32_t*
   PP_REQUIRE(dcn_groups == 0 || (ctotal % dcn_groups == 0 && (ctotal / dcn_groups) % 8 == 0), PP_ERR_ARG,
              "pp_conv_build_ktable: %d channels do not split into %d offset groups of 8n", ctotal, dcn_groups);
   const int chunks = ntaps * (ctotal / 8);
-  const int padded = (chunks + 3) / 4 * 4;
+  const int padded = (chunks + 7) / 8 * 8;
   if (out == nullptr) return padded;
-  PP_REQUIRE(out_capacity >= padded, PP_ERR_WORKSPACE, "pp_conv_build_ktable: need %d entries, got %d", padded, out_capacity);
+  PP_REQUIRE(out_capacity >= padded + 1, PP_ERR_WORKSPACE, "pp_conv_build_ktable: need %d entries, got %d", padded + 1, out_capacity);
   int k = 0;
   for (int t = 0; t < ntaps; ++t) {
     int cglobal = 0;
@@ -378,6 +353,7 @@ extern "C" int pp_conv_build_ktable(int ntaps, const int32_t* dy, const int32_t*
       }
   }
   for (; k < padded; ++k) { out[4 * k] = 0; out[4 * k + 1] = 0; out[4 * k + 2] = 255; out[4 * k + 3] = 0; }
+  out[4 * padded] = out[4 * padded + 1] = out[4 * padded + 2] = out[4 * padded + 3] = 0;   // 16 zero bytes: the kernels' zero page
   return padded;
 }
 
@@ -423,7 +399,14 @@ extern "C" int pp_conv2d(const pp_conv_args_t* a, void* stream) {
   p.dcn = (const char*)a->dcn_offmask; p.dcn_cstride = a->dcn_cstride; p.dcn_mask_off = a->dcn_mask_off;
   p.M = (long long)a->N * a->OH * a->OW;
   const bool deform = a->dcn_offmask != nullptr;
+  p.groups = a->groups; p.tiles_m = 0; p.tiles_n = 0; p.ktable_uniform = a->ktable_uniform;
   hipStream_t st = (hipStream_t)stream;
+  if (a->dtype == PP_F16 && !deform && a->impl != 1) {
+    // LDS-DMA kernel family (needs kchunks % 8 == 0 and the trailing all-zero table entry)
+    const int rc = conv_v2_dispatch(p, a->impl >= 10 ? a->impl : (a->impl == 2 ? 100 : 0), st);
+    if (rc != -1000) return rc;
+    PP_REQUIRE(a->impl < 10, PP_ERR_ARG, "pp_conv2d: impl %d not available for this shape", a->impl);
+  }
   if (a->dtype == PP_F16) return dispatch_conv<_Float16>(p, a->groups, deform, st);
   return dispatch_conv<float>(p, a->groups, deform, st);
 }

@@ -1,0 +1,450 @@
+// fp16 implicit-GEMM convolution, second generation: LDS tiles are filled by the LDS-DMA path
+// (global_load_lds_dwordx4, one 16-byte K-chunk per lane) instead of being staged through VGPRs, so
+// the im2col gather costs no ds_write pass and no staging registers.
+//
+//   D[co][px] = sum_k Wp[co][k] * A[px][k]     (same GEMM view, K-chunk table and packed weights as
+//                                               conv_gemm.hip; see include/propainter_hip.h)
+//
+// Tile: BM pixels x BN couts x BK (32 or 64) per step, NW waves, each wave owns WM x WN of the tile as
+// (WM/16) x (WN/16) v_mfma_f32_16x16x32_f16 accumulators.  S LDS stages: the DMA of step k+S-1 is issued right
+// after the single (raw) barrier of step k, and a *counted* s_waitcnt vmcnt((S-2)*G) (G = DMA instructions per
+// lane per step) retires only the stage about to be consumed, so S-2 steps of loads stay in flight across
+// every barrier (L2 / Infinity-Cache latency is ~1-2k cycles, a 16-MFMA step is 256).  The K-chunk table entries of
+// a step are wave-uniform and fetched by scalar loads, so the loop contains no VMEM load besides the DMA (an
+// ordinary vector load, or a ds_read of a table kept in LDS, makes hipcc drain vmcnt to 0).
+// Epilogue: accumulators go through LDS (fp32) so that every lane stores 8 consecutive output channels
+// (16 B fp16 / 32 B fp32) and 8 lanes cover one pixel's 64-cout slice: full-line NHWC stores.
+//
+// LDS image: row-major [row][BK] fp16 (64- or 128-byte rows), A rows (pixels) then B rows (couts).  An
+// LDS-DMA instruction writes 64 lanes x 16 B = 1 KiB *linearly*, i.e. 8 (BK=64) or 16 (BK=32) whole rows,
+// so 8 / 4 adjacent lanes fetch one contiguous 128- / 64-byte piece of an NHWC pixel (coalesced).  Bank
+// conflicts of the fragment reads (ds_read_b128, row = lane&15, chunk = k/8 + lane>>4) are removed by an XOR
+// swizzle of the 16-byte slot inside each row; because the DMA destination is lane-linear the swizzle is
+// applied to the per-lane *source* chunk and again on the read (same involution on both sides):
+//     BK=64:  slot = chunk ^ ((row >> 1) & 7)          BK=32:  slot = chunk ^ G[(row >> 2) & 3], G = {0,3,2,1}
+// Zero padding / K padding: out-of-image taps and padding chunks fetch from the all-zero int4 that
+// pp_conv_build_ktable appends after the last table entry (ktable[kchunks]).
+#include "conv_params.h"
+
+namespace pp {
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int BK> __device__ __forceinline__ int swz_of_row(int row) {
+  if constexpr (BK == 64) return (row >> 1) & 7;
+  else {
+    const int q = (row >> 2) & 3;        // G = {0,3,2,1}
+    return (4 - q) & 3;
+  }
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int S, bool UNI>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_v2_kernel(const ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the body uses device-only types (__amdgpu_buffer_rsrc_t): the host pass only needs the stub
+  typedef _Float16 T;
+  constexpr int NW = WAVES_M * WAVES_N;
+  constexpr int NT = 64 * NW;
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int TM = WM / 16, TN = WN / 16;
+  constexpr int CH = BK / 8;             // 16-byte chunks per row
+  constexpr int RPI = 64 / CH;           // rows written by one LDS-DMA instruction
+  constexpr int ROWB = BK * 2;           // bytes per LDS row
+  constexpr int A_INST = BM / RPI;       // DMA instructions per stage (whole block)
+  constexpr int B_INST = BN / RPI;
+  constexpr int A_PER_WAVE = A_INST / NW;
+  constexpr int B_PER_WAVE = (B_INST + NW - 1) / NW;
+  constexpr bool B_RAGGED = (B_INST % NW) != 0;      // some waves have no weight rows to fetch: they DMA into a dummy pad
+  constexpr int G = A_PER_WAVE + B_PER_WAVE;         // DMA instructions per lane per step (identical for every wave)
+  constexpr int STAGE = (BM + BN) * ROWB;
+  constexpr int EPI_LD = WN + 4;                     // fp32 row stride of the epilogue staging tile
+  constexpr int EPI_BYTES = NW * WM * EPI_LD * 4;
+  constexpr int PIPE_BYTES = S * STAGE + (B_RAGGED ? NW * 1024 : 0);
+  constexpr int LDS_BYTES = PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES;
+  static_assert(BM % RPI == 0 && BN % RPI == 0 && TM >= 1 && TN >= 1 && (NW % 2) == 0, "tile");
+  static_assert(A_INST % NW == 0, "A rows must split evenly over the waves");
+  static_assert(S >= 2 && (S - 2) * G < 64, "pipeline depth");
+  static_assert(WN % 8 == 0 || WN == 16, "epilogue");
+
+  __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  // ---- XCD-aware block order: give each XCD (= linear block id mod 8) a contiguous run of tiles, couts
+  // fastest, so tiles that share pixels (all N-tiles of an M-tile, vertically adjacent M-tiles) hit one L2.
+  int bid = blockIdx.x;
+  {
+    const int nblk = gridDim.x;
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, loc = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int tn = bid % p.tiles_n;
+  const int tmg = bid / p.tiles_n;
+  const int tmi = tmg % p.tiles_m;
+  const int g = tmg / p.tiles_m;
+  const long long m0 = (long long)tmi * BM;   // < 2^31
+  const int n0 = tn * BN;
+
+  // ---- DMA role of this lane: slot (lane % CH) of row (lane / CH) of each of its wave's instructions;
+  // the swizzle term is the same for all of them, so the lane always fetches one logical chunk `lc`.
+  const int slot = lane % CH;
+  const int rin = lane / CH;
+  const int lc = slot ^ swz_of_row<BK>(wave * RPI + rin);     // (q*RPI + rin) has the same swizzle for q = j*NW + wave
+  int a_iy0[A_PER_WAVE], a_ix0[A_PER_WAVE];
+  int a_pix[A_PER_WAVE];                                        // n*H*W (pixels; N*H*W < 2^31 is checked by pp_conv2d)
+  const unsigned Mu = (unsigned)p.M, OWu = (unsigned)p.OW, OHu = (unsigned)p.OH;
+#pragma unroll
+  for (int j = 0; j < A_PER_WAVE; ++j) {
+    unsigned m = (unsigned)m0 + (j * NW + wave) * RPI + rin;
+    if (m >= Mu) m = Mu - 1;                                    // rows past M are computed but never stored
+    const unsigned ox = m % OWu, r = m / OWu;
+    const unsigned oy = r % OHu, n = r / OHu;
+    a_iy0[j] = (int)oy * p.sh - p.ph;
+    a_ix0[j] = (int)ox * p.sw - p.pw;
+    a_pix[j] = (int)(n * (unsigned)(p.H * p.W));
+  }
+  const char* wrow[B_PER_WAVE];
+#pragma unroll
+  for (int j = 0; j < B_PER_WAVE; ++j) {
+    int row = n0 + (j * NW + wave) * RPI + rin;
+    if (row >= p.cout_pad) row = p.cout_pad - 1;                // clamped rows feed accumulators that are never stored
+    wrow[j] = p.weight + ((long long)g * p.weight_gstride + (long long)row * p.kchunks * 8) * 2 + lc * 16;
+  }
+  const char* zero16 = reinterpret_cast<const char*>(p.ktable + p.kchunks);
+  // per-source base pointers (wave-uniform) with the group / batch offsets folded in
+  const char* sbase[PP_CONV_MAX_SRC];
+  int srowb[PP_CONV_MAX_SRC];
+#pragma unroll
+  for (int i = 0; i < PP_CONV_MAX_SRC; ++i) {
+    sbase[i] = p.src[i].ptr + ((long long)g * p.src_gstride + p.src[i].choff + g * p.src[i].cgroup) * 2;
+    srowb[i] = p.src[i].cstride * 2;
+  }
+  const bool replicate = p.pad_mode == 1;
+
+  // The CH table entries of a step are wave-uniform: they are fetched with *scalar* loads (SMEM, tracked by lgkmcnt)
+  // issued by hand -- hipcc turns a uniform `ktable[...]` read inside the loop into a vector global_load, whose use
+  // drains vmcnt to 0 and with it the DMA pipeline -- and every lane then selects the entry of its logical chunk.
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  struct Entries { i32x4 v[CH]; };
+  auto fetch_entries = [&](int ks, Entries& E) {       // asynchronous: complete only after entries_ready()
+    const int4* ptr = p.ktable + ks * CH;
+    asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(E.v[0]) : "s"(ptr));
+    asm volatile("s_load_dwordx4 %0, %1, 0x10" : "=s"(E.v[1]) : "s"(ptr));
+    asm volatile("s_load_dwordx4 %0, %1, 0x20" : "=s"(E.v[2]) : "s"(ptr));
+    asm volatile("s_load_dwordx4 %0, %1, 0x30" : "=s"(E.v[3]) : "s"(ptr));
+    if constexpr (CH == 8) {
+      asm volatile("s_load_dwordx4 %0, %1, 0x40" : "=s"(E.v[4]) : "s"(ptr));
+      asm volatile("s_load_dwordx4 %0, %1, 0x50" : "=s"(E.v[5]) : "s"(ptr));
+      asm volatile("s_load_dwordx4 %0, %1, 0x60" : "=s"(E.v[6]) : "s"(ptr));
+      asm volatile("s_load_dwordx4 %0, %1, 0x70" : "=s"(E.v[7]) : "s"(ptr));
+    }
+  };
+  auto entries_ready = [&](Entries& E) {
+    if constexpr (CH == 8)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(E.v[0]), "+s"(E.v[1]), "+s"(E.v[2]), "+s"(E.v[3]), "+s"(E.v[4]), "+s"(E.v[5]),
+                   "+s"(E.v[6]), "+s"(E.v[7])::"memory");
+    else
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(E.v[0]), "+s"(E.v[1]), "+s"(E.v[2]), "+s"(E.v[3])::"memory");
+  };
+  auto issue = [&](int ks, int buf, const Entries& E) {
+    // ---- A: gathered pixels (branch-free: invalid taps / padding chunks read the zero page)
+    int4 e = make_int4(E.v[0][0], E.v[0][1], E.v[0][2], E.v[0][3]);
+#pragma unroll
+    for (int i = 1; i < CH; ++i) {
+      const bool m = lc == i;
+      e.x = m ? E.v[i][0] : e.x; e.y = m ? E.v[i][1] : e.y; e.z = m ? E.v[i][2] : e.z; e.w = m ? E.v[i][3] : e.w;
+    }
+    const int s = e.z & 0xff;
+    const char* sp = s == 0 ? sbase[0] : s == 1 ? sbase[1] : s == 2 ? sbase[2] : sbase[3];
+    const int rowbytes = s == 0 ? srowb[0] : s == 1 ? srowb[1] : s == 2 ? srowb[2] : srowb[3];
+    sp += e.w * 2;
+    const bool live = s != 255;
+    char* abase = lds + buf * STAGE;
+#pragma unroll
+    for (int j = 0; j < A_PER_WAVE; ++j) {
+      int iy = a_iy0[j] + e.x, ix = a_ix0[j] + e.y;
+      const bool inside = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+      iy = min(max(iy, 0), p.H - 1);
+      ix = min(max(ix, 0), p.W - 1);
+      const bool ok = live & (inside | replicate);
+      const char* cand = sp + (long long)(a_pix[j] + iy * p.W + ix) * rowbytes;
+      const char* src = ok ? cand : zero16;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(abase + (j * NW + wave) * 1024), 16, 0, 0);
+    }
+    // ---- B: packed weights (dense rows)
+    char* bbase = lds + buf * STAGE + BM * ROWB;
+#pragma unroll
+    for (int j = 0; j < B_PER_WAVE; ++j) {
+      if (!B_RAGGED || (j * NW + wave) < B_INST) {
+        __builtin_amdgcn_global_load_lds((gptr_t)(wrow[j] + (long long)ks * BK * 2), (lptr_t)(bbase + (j * NW + wave) * 1024), 16, 0, 0);
+      } else {   // keep the per-wave DMA count uniform (the counted vmcnt relies on it): fetch zeros into a private pad
+        __builtin_amdgcn_global_load_lds((gptr_t)zero16, (lptr_t)(lds + S * STAGE + wave * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  // ---- UNI (uniform-step) fast path: the host guarantees that the CH chunks of every K step belong to one
+  // (tap, source) with consecutive channel offsets (all sources are multiples of BK channels), so ONE scalar table
+  // entry describes the step, the source select is scalar, and the gather uses buffer_load ... lds with a 32-bit
+  // per-lane offset: out-of-image taps get an offset past num_records and the hardware range check returns zeros
+  // (no zero page, no 64-bit address math, no divergent control flow).
+  int u_rowpix[A_PER_WAVE];
+  int u_wvoff[B_PER_WAVE];
+  __amdgpu_buffer_rsrc_t u_rs[PP_CONV_MAX_SRC];
+  __amdgpu_buffer_rsrc_t u_rw;
+  if constexpr (UNI) {
+#pragma unroll
+    for (int j = 0; j < A_PER_WAVE; ++j) u_rowpix[j] = a_pix[j] + a_iy0[j] * p.W + a_ix0[j];
+#pragma unroll
+    for (int j = 0; j < B_PER_WAVE; ++j) {
+      int row = n0 + (j * NW + wave) * RPI + rin;
+      if (row >= p.cout_pad) row = p.cout_pad - 1;
+      u_wvoff[j] = row * p.kchunks * 16 + lc * 16;
+    }
+    const int nrec = (int)min((long long)p.N * p.H * p.W, (long long)0x7fffffff);   // pixels; bytes = nrec * rowbytes < 2^31 (checked on the host)
+#pragma unroll
+    for (int i = 0; i < PP_CONV_MAX_SRC; ++i)
+      u_rs[i] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(sbase[i]), 0, nrec * srowb[i], 0x00020000);
+    u_rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.weight + (long long)g * p.weight_gstride * 2), 0,
+                                             p.cout_pad * p.kchunks * 16, 0x00020000);
+  }
+  typedef int i32x4u __attribute__((ext_vector_type(4)));
+  auto fetch_entry = [&](int ks, i32x4u& e) {            // asynchronous scalar load; complete after entry_ready()
+    const int4* ptr = p.ktable + ks * CH;
+    asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(e) : "s"(ptr));
+  };
+  auto entry_ready = [&](i32x4u& e) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(e)::"memory"); };
+  auto issue_uni = [&](int ks, int buf, const i32x4u e) {
+    const int dy = e[0], dx = e[1], s = e[2] & 0xff;
+    const __amdgpu_buffer_rsrc_t rs = s == 1 ? u_rs[1] : s == 2 ? u_rs[2] : s == 3 ? u_rs[3] : u_rs[0];
+    const int rowbytes = s == 1 ? srowb[1] : s == 2 ? srowb[2] : s == 3 ? srowb[3] : srowb[0];
+    const bool live = s != 255;
+    const int tapoff = dy * p.W + dx;
+    const int coff = e[3] * 2 + lc * 16;
+    char* abase = lds + buf * STAGE;
+#pragma unroll
+    for (int j = 0; j < A_PER_WAVE; ++j) {
+      const int iy = a_iy0[j] + dy, ix = a_ix0[j] + dx;
+      const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W) & live;
+      const int voff = ok ? (u_rowpix[j] + tapoff) * rowbytes + coff : (int)0x80000000;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(abase + (j * NW + wave) * 1024), 16, voff, 0, 0, 0);
+    }
+    char* bbase = lds + buf * STAGE + BM * ROWB;
+    const int wso = ks * BK * 2;
+#pragma unroll
+    for (int j = 0; j < B_PER_WAVE; ++j) {
+      if (!B_RAGGED || (j * NW + wave) < B_INST)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(u_rw, (lptr_t)(bbase + (j * NW + wave) * 1024), 16, u_wvoff[j], wso, 0, 0);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(u_rw, (lptr_t)(lds + S * STAGE + wave * 1024), 16, (int)0x80000000, 0, 0, 0);
+    }
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment read offsets: row = base + t*16 + (lane&15); slot = (kk*4 + (lane>>4)) ^ swz(row)
+  const int frow = lane & 15;
+  const int fswz = swz_of_row<BK>(frow);
+  const int a_off = (wm * WM + frow) * ROWB;
+  const int b_off = (BM + wn * WN + frow) * ROWB;
+
+  const int nk = p.kchunks / CH;
+#pragma unroll
+  for (int s = 0; s < S - 1; ++s)
+    if (s < nk) {
+      if constexpr (UNI) {
+        i32x4u e;
+        fetch_entry(s, e);
+        entry_ready(e);
+        issue_uni(s, s, e);
+      } else {
+        Entries E;
+        fetch_entries(s, E);
+        entries_ready(E);
+        issue(s, s, E);
+      }
+    }
+  int buf = 0, nbuf = S - 1;                          // stage consumed at step ks / stage filled for step ks+S-1
+  for (int ks = 0; ks < nk; ++ks) {
+    // retire the DMA of stage `buf` only: the up-to S-2 younger steps stay in flight across the barrier
+    const int ahead = min(S - 2, nk - 1 - ks);
+    const bool more = ks + S - 1 < nk;
+    Entries E;
+    i32x4u e1;
+    if (more) {                                        // SMEM latency overlaps the DMA wait + barrier below
+      if constexpr (UNI) fetch_entry(ks + S - 1, e1);
+      else fetch_entries(ks + S - 1, E);
+    }
+    if (S >= 4 && ahead == 2) wait_vmcnt<(S >= 4 ? 2 : 0) * G>();
+    else if (S >= 3 && ahead == 1) wait_vmcnt<(S >= 3 ? 1 : 0) * G>();
+    else if (S >= 5 && ahead == 3) wait_vmcnt<(S >= 5 ? 3 : 0) * G>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();                     // stage `buf` complete for all waves; stage `nbuf` (read at step ks-1) is free
+    if (more) {
+      if constexpr (UNI) {
+        entry_ready(e1);
+        issue_uni(ks + S - 1, nbuf, e1);
+      } else {
+        entries_ready(E);
+        issue(ks + S - 1, nbuf, E);
+      }
+    }
+    const char* sb = lds + buf * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < BK / 32; ++kk) {
+      const int so = ((kk * 4 + (lane >> 4)) ^ fswz) * 16;
+      f16x8 af[TM], bf[TN];
+#pragma unroll
+      for (int t = 0; t < TM; ++t) af[t] = *reinterpret_cast<const f16x8*>(sb + a_off + t * 16 * ROWB + so);
+#pragma unroll
+      for (int t = 0; t < TN; ++t) bf[t] = *reinterpret_cast<const f16x8*>(sb + b_off + t * 16 * ROWB + so);
+#pragma unroll
+      for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[a], af[b], acc[a][b], 0, 0, 0);
+    }
+    buf = buf + 1 == S ? 0 : buf + 1;
+    nbuf = nbuf + 1 == S ? 0 : nbuf + 1;
+  }
+  __syncthreads();                                    // every wave is done with the stages: LDS becomes the epilogue tile
+
+  // ---- epilogue.  Phase 1: accumulators -> this wave's fp32 tile [WM pixels][WN couts] in LDS.
+  float* et = reinterpret_cast<float*>(lds) + wave * (WM * EPI_LD);
+#pragma unroll
+  for (int b = 0; b < TM; ++b)
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+      *reinterpret_cast<f32x4*>(et + (b * 16 + (lane & 15)) * EPI_LD + a * 16 + (lane >> 4) * 4) = acc[a][b];
+  // (wave-private tile: no block barrier needed, the LDS queue is in order within a wave)
+  // Phase 2: each lane owns 8 consecutive couts of one pixel: bias, activation, residual, 16/32-byte stores.
+  constexpr int LPR = WN / 8 > 0 ? WN / 8 : 1;        // lanes per pixel row
+  constexpr int RPP = 64 / LPR;                       // pixel rows per pass
+  const int out_cbase = p.out_choff + g * p.out_cgroup;
+  const int res_cbase = p.res_choff + g * p.out_cgroup;
+  char* outp = p.out + (long long)g * p.out_gstride * (p.out_f16 ? 2 : 4);
+  const int cl = (lane % LPR) * 8;                    // cout offset inside the wave tile
+  const int co = n0 + wn * WN + cl;                   // first of this lane's 8 couts (within the group)
+  const bool vec_ok = ((p.out_cstride | out_cbase) & 7) == 0;
+  const bool res_vec_ok = ((p.res_cstride | res_cbase) & 7) == 0;
+  float bs[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) bs[r] = (p.bias != nullptr && co + r < p.cout_g) ? p.bias[g * p.cout_g + co + r] : 0.f;
+  const int nval = min(8, p.cout_g - co);             // valid couts of this lane (<= 0: nothing to store)
+#pragma unroll 2
+  for (int pass = 0; pass < WM / RPP; ++pass) {
+    const int prow = pass * RPP + lane / LPR;
+    const long long m = m0 + wm * WM + prow;
+    if (m >= p.M || nval <= 0 || (WN < 8 * LPR && cl >= WN)) continue;
+    float v[8];
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(et + prow * EPI_LD + cl);
+    const f32x4 hi = *reinterpret_cast<const f32x4*>(et + prow * EPI_LD + cl + 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { v[r] = lo[r]; v[4 + r] = hi[r]; }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = apply_act((v[r] + bs[r]) * p.out_scale, p.act, p.act_param);
+    if (p.residual != nullptr) {
+      const T* rp = reinterpret_cast<const T*>(p.residual) + m * p.res_cstride + res_cbase + co;
+      if (nval == 8 && res_vec_ok) {
+        float rv[8];
+        load8<T>(rp, rv);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += rv[r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+          if (r < nval) v[r] += to_f32(rp[r]);
+      }
+    }
+    if (p.act2 == PP_ACT_RELU) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+    }
+    const long long oidx = m * p.out_cstride + out_cbase + co;
+    if (p.out_f16) {
+      _Float16* op = reinterpret_cast<_Float16*>(outp) + oidx;
+      if (nval == 8 && vec_ok) store8<_Float16>(op, v);
+      else {
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+          if (r < nval) op[r] = (_Float16)v[r];
+      }
+    } else {
+      float* op = reinterpret_cast<float*>(outp) + oidx;
+      if (nval == 8 && ((p.out_cstride | out_cbase) & 3) == 0) store8<float>(op, v);
+      else {
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+          if (r < nval) op[r] = v[r];
+      }
+    }
+  }
+#endif
+}
+
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int S>
+static int launch_v2(ConvParams p, bool uni, hipStream_t stream) {
+  p.tiles_m = (int)((p.M + BM - 1) / BM);
+  p.tiles_n = (p.cout_g + BN - 1) / BN;
+  const long long nblk = (long long)p.tiles_m * p.tiles_n * p.groups;
+  const dim3 grid((unsigned)nblk), block(64 * WAVES_M * WAVES_N);
+  // the uniform-step fast path needs uniform steps at this BK (flag bit = chunks per step) -- see conv_v2_dispatch
+  if (uni && (p.ktable_uniform & (BK / 8)))
+    hipLaunchKernelGGL((conv_gemm_v2_kernel<BM, BN, BK, WAVES_M, WAVES_N, S, true>), grid, block, 0, stream, p);
+  else
+    hipLaunchKernelGGL((conv_gemm_v2_kernel<BM, BN, BK, WAVES_M, WAVES_N, S, false>), grid, block, 0, stream, p);
+  return launch_status("pp_conv2d(v2)");
+}
+
+// `cfg`: 0 = auto; otherwise a tile configuration id (exposed through pp_conv_args_t.impl for the tile sweep in
+// tools/bench_conv.py; +100 disables the uniform-step fast path).  Returns -1000 when the shape is not supported by
+// this family (caller falls back).
+int conv_v2_dispatch(const ConvParams& p, int cfg, hipStream_t stream) {
+  if (p.kchunks % 8 != 0 || p.M >= (1ll << 31) || (long long)p.N * p.H * p.W >= (1ll << 31)) return -1000;
+  // uniform-step path: zeros padding, 32-bit byte offsets (< 2 GiB per source / weight block)
+  bool uni = p.ktable_uniform != 0 && p.pad_mode == 0 && (long long)p.cout_pad * p.kchunks * 16 < (1ll << 31);
+  for (int i = 0; i < p.nsrc; ++i) uni = uni && (long long)p.N * p.H * p.W * p.src[i].cstride * 2 < (1ll << 31);
+  if (cfg >= 100) { uni = false; cfg -= 100; }
+  if (cfg == 0) {   // measured on MI355X with tools/bench_conv.py (profiles/r1_conv_tile_sweep.txt)
+    if (p.cout_g >= 512) cfg = 13;
+    else if (p.cout_g > 64) cfg = 12;
+    else if (p.cout_g > 32) cfg = 22;
+    else if (p.cout_g > 16) cfg = p.groups > 1 ? 31 : 32;
+    else cfg = 42;
+  }
+  switch (cfg) {
+    //                           BM   BN  BK  WM WN  S
+    case 10: return launch_v2<128, 128, 32, 2, 2, 4>(p, uni, stream);   // 4 waves 64x64, 4 stages: 64 KiB -> 2 blocks/CU
+    case 11: return launch_v2<256, 128, 32, 4, 2, 4>(p, uni, stream);   // 8 waves 64x64, 4 stages: 96 KiB
+    case 12: return launch_v2<128, 128, 64, 2, 2, 2>(p, uni, stream);   // 2 stages, 64 KiB -> 2 blocks/CU
+    case 13: return launch_v2<256, 128, 64, 4, 2, 3>(p, uni, stream);   // 8 waves, BK=64, 3 stages: 144 KiB
+    case 14: return launch_v2<128, 128, 32, 2, 2, 3>(p, uni, stream);   // 48 KiB -> 3 blocks/CU
+    case 15: return launch_v2<128, 128, 64, 2, 2, 3>(p, uni, stream);   // 96 KiB -> 1 block/CU
+    case 16: return launch_v2<256, 128, 32, 2, 2, 4>(p, uni, stream);   // 4 waves 128x64, 96 KiB
+    case 17: return launch_v2<256, 128, 64, 2, 2, 2>(p, uni, stream);   // 4 waves 128x64, 96 KiB
+    case 20: return launch_v2<128, 64, 32, 2, 2, 4>(p, uni, stream);    // wave tile 64x32, 48 KiB -> 3 blocks/CU
+    case 21: return launch_v2<256, 64, 32, 4, 1, 4>(p, uni, stream);    // wave tile 64x64, 80 KiB
+    case 22: return launch_v2<256, 64, 64, 4, 1, 2>(p, uni, stream);    // 80 KiB -> 2 blocks/CU
+    case 30: return launch_v2<256, 32, 32, 4, 1, 4>(p, uni, stream);    // wave tile 64x32, 72 KiB
+    case 31: return launch_v2<256, 32, 32, 4, 1, 3>(p, uni, stream);    // 54 KiB -> 2 blocks/CU
+    case 32: return launch_v2<256, 32, 32, 4, 1, 2>(p, uni, stream);    // 36 KiB
+    case 40: return launch_v2<256, 16, 32, 4, 1, 4>(p, uni, stream);    // wave tile 64x16
+    case 41: return launch_v2<256, 16, 32, 4, 1, 3>(p, uni, stream);
+    case 42: return launch_v2<256, 16, 32, 4, 1, 2>(p, uni, stream);
+    default: return -1000;
+  }
+}
+
+}  // namespace pp

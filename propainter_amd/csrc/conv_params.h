@@ -1,0 +1,38 @@
+// Kernel-side parameter block shared by the two implicit-GEMM convolution families (conv_gemm.hip: register-staged
+// fp32 / fp16 / deformable; conv_gemm_v2.hip: LDS-DMA fp16).  Filled by pp_conv2d from pp_conv_args_t.
+#pragma once
+#include "common.h"
+
+namespace pp {
+
+struct ConvSrc {
+  const char* ptr;
+  int cstride, choff, cgroup;
+};
+
+struct ConvParams {
+  int N, H, W, OH, OW, sh, sw, ph, pw, pad_mode;
+  int cout_g, cout_pad, kchunks, nsrc;
+  ConvSrc src[PP_CONV_MAX_SRC];
+  const int4* ktable;
+  const char* weight;
+  long long weight_gstride;
+  const float* bias;
+  int act;
+  float act_param, out_scale;
+  const char* residual;
+  int res_cstride, res_choff, act2, out_f16;
+  char* out;
+  int out_cstride, out_choff, out_cgroup;
+  long long src_gstride, out_gstride;
+  const char* dcn;
+  int dcn_cstride, dcn_mask_off;
+  long long M;
+  int tiles_m, tiles_n, groups;   // v2 only: 1-D grid decomposition
+  int ktable_uniform;             // v2 only: bit 4 / bit 8 set when every 4- / 8-chunk K step is one (tap, source) run
+};
+
+// conv_gemm_v2.hip; returns -1000 when the shape is outside that family (caller falls back to conv_gemm.hip)
+int conv_v2_dispatch(const ConvParams& p, int cfg, hipStream_t stream);
+
+}  // namespace pp

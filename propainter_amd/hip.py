@@ -33,7 +33,7 @@ class ConvArgs(C.Structure):
         ("res_cstride", C.c_int32), ("res_choff", C.c_int32), ("act2", C.c_int32), ("out_dtype", C.c_int32),
         ("out", C.c_void_p), ("out_cstride", C.c_int32), ("out_choff", C.c_int32), ("out_cgroup", C.c_int32),
         ("src_gstride", C.c_int64), ("out_gstride", C.c_int64), ("dcn_offmask", C.c_void_p),
-        ("dcn_cstride", C.c_int32), ("dcn_mask_off", C.c_int32),
+        ("dcn_cstride", C.c_int32), ("dcn_mask_off", C.c_int32), ("impl", C.c_int32), ("ktable_uniform", C.c_int32),
     ]
 
 
@@ -165,7 +165,7 @@ def require_gpu(t, who):
 # ----------------------------------------------------------------------------------------------
 def build_ktable(taps, src_channels, dcn_groups=0):
     """taps: list of (dy, dx); src_channels: padded (multiple-of-8) channel count per source.
-    Returns int32 numpy array [kchunks, 4]."""
+    Returns int32 numpy array [kchunks + 1, 4] (last row = 16 zero bytes)."""
     L = lib()
     n = len(taps)
     dy = (C.c_int32 * n)(*[int(t[0]) for t in taps])
@@ -174,9 +174,9 @@ def build_ktable(taps, src_channels, dcn_groups=0):
     size = L.pp_conv_build_ktable(n, dy, dx, len(src_channels), sc, int(dcn_groups), None, 0)
     if size < 0:
         _check(size, "pp_conv_build_ktable")
-    out = np.zeros((size, 4), dtype=np.int32)
+    out = np.zeros((size + 1, 4), dtype=np.int32)      # + the trailing all-zero entry (the kernels' zero page)
     rc = L.pp_conv_build_ktable(n, dy, dx, len(src_channels), sc, int(dcn_groups),
-                                out.ctypes.data_as(C.POINTER(C.c_int32)), size)
+                                out.ctypes.data_as(C.POINTER(C.c_int32)), size + 1)
     if rc < 0:
         _check(rc, "pp_conv_build_ktable")
     return out

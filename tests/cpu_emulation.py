@@ -31,7 +31,7 @@ def _conv_call(self, srcs, out=None, out_choff=0, act=None, act_param=0.0, out_s
     if out is None:
         cp = pconv.pad8(self.cout)
         out = torch.zeros((N, OH, OW, cp), dtype=out_dtype or self.dtype)
-    kt = self.ktable.cpu().numpy()
+    kt = self.ktable.cpu().numpy()[:self.kchunks]      # the last row is the kernels' 16-byte zero page
     oy = torch.arange(OH).view(1, OH, 1) * self.stride[0] - self.padding[0]
     ox = torch.arange(OW).view(1, 1, OW) * self.stride[1] - self.padding[1]
     nidx = torch.arange(N).view(N, 1, 1)

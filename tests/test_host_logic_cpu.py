@@ -64,6 +64,9 @@ def _emulate_conv(srcs, layer_w, bias, stride, pad, dil, groups, src_channels, p
     kh, kw = layer_w.shape[2:]
     taps = [(ky * dil, kx * dil) for ky in range(kh) for kx in range(kw)]
     kt = hip.build_ktable(taps, [(c + 7) // 8 * 8 for c in src_channels])
+    assert kt.shape[0] % 8 == 1 and not kt[-1].any(), "kchunks padded to 8 + the trailing 16-byte zero page"
+    kt = kt[:-1]
+    assert kt.shape[0] * 8 == K
     N, H, W, _ = srcs[0].shape
     OH = (H + 2 * pad - dil * (kh - 1) - 1) // stride + 1
     OW = (W + 2 * pad - dil * (kw - 1) - 1) // stride + 1
