@@ -203,9 +203,11 @@ int pp_sparse_window_attention(const pp_attn_args_t* args, void* stream);
 /* ------------------------------------------------------------------------------------------------
  * Token <-> feature-map ops (model/modules/sparse_transformer.py:49-101) and small dense helpers
  * ---------------------------------------------------------------------------------------------- */
-/* F.fold(kernel 7, stride 3, pad 3) of tokens [BT, fh*fw, C*49] (feature index c*49 + ky*7 + kx) into NHWC
- * [BT,H,W,C]; if normalize != 0 the sum is divided by the overlap count (FusionFeedForward :82-95) and
- * `act` is applied (GELU for the FFN, since unfold(gelu(x)) == gelu(unfold(x)) under zero padding). */
+/* F.fold(kernel 7, stride 3, pad 3) of tokens [BT, fh*fw, 49*C] into NHWC [BT,H,W,C].  The token features are in
+ * TAP-MAJOR order (ky*7 + kx)*C + c -- the caller permutes the rows of the producing Linear (fc1 / SoftComp
+ * embedding; the reference order is c*49 + ky*7 + kx) so that the fold reads 16-byte channel runs.  C % 8 == 0.
+ * If normalize != 0 the sum is divided by the overlap count (FusionFeedForward :82-95) and `act` is applied (GELU
+ * for the FFN, since unfold(gelu(x)) == gelu(unfold(x)) under zero padding). */
 int pp_fold_tokens(const void* tokens, void* out, int BT, int fh, int fw, int C, int H, int W, int normalize,
                    int act, int dtype, void* stream);
 

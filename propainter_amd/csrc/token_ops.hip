@@ -11,34 +11,42 @@ static inline int grid_for(long long total, int block = 256) {
 }
 
 // F.fold(7, stride 3, pad 3) as a gather: output pixel (y, x) sums the <= 3x3 patches that cover it.
-// tokens [BT, fh*fw, C*49] with feature index c*49 + ky*7 + kx.  One thread per (pixel, channel);
-// consecutive threads take consecutive channels so the NHWC store is coalesced (the token reads are
-// 98-byte strided by construction of the reference's feature order).
+// tokens [BT, fh*fw, 49*C] in TAP-MAJOR feature order (ky*7 + kx)*C + c: the producing GEMM (fc1 / SoftComp
+// embedding) has its weight rows permuted on the host from the reference's c*49 + ky*7 + kx, so that the 8 channels
+// a lane folds are one 16-byte load and neighbouring pixels of a patch read neighbouring C-element runs (coalesced);
+// every token element is read exactly once.  One thread per (pixel, 8-channel chunk), chunk fastest: full-line
+// NHWC stores.  C must be a multiple of 8.
 template <typename T>
-__global__ void fold_tokens_kernel(const T* __restrict__ tok, T* __restrict__ out, int BT, int fh, int fw, int C, int H, int W,
-                                   int normalize, int act) {
-  const long long total = (long long)BT * H * W * C;
+__global__ __launch_bounds__(256) void fold_tokens_kernel(const T* __restrict__ tok, T* __restrict__ out, int BT, int fh, int fw, int C,
+                                                          int H, int W, int normalize, int act) {
+  const int cch = C / 8;
+  const long long total = (long long)BT * H * W * cch;
   const long long tstride = (long long)C * 49;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
-    const long long pix = i / C;
+    const int cc = (int)(i % cch);
+    const long long pix = i / cch;
     const int x = (int)(pix % W), y = (int)((pix / W) % H);
     const long long n = pix / ((long long)W * H);
-    float acc = 0.f;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int cnt = 0;
     // patches py with 3*py - 3 <= y <= 3*py + 3
     const int py0 = max(0, (y - 3 + 2) / 3), py1 = min(fh - 1, (y + 3) / 3);
     const int px0 = max(0, (x - 3 + 2) / 3), px1 = min(fw - 1, (x + 3) / 3);
+    const T* base = tok + n * fh * fw * tstride + cc * 8;
     for (int py = py0; py <= py1; ++py) {
       const int ky = y + 3 - 3 * py;
       for (int px = px0; px <= px1; ++px) {
         const int kx = x + 3 - 3 * px;
-        acc += to_f32(tok[(n * fh * fw + (long long)py * fw + px) * tstride + c * 49 + ky * 7 + kx]);
+        float v[8];
+        load8<T>(base + ((long long)py * fw + px) * tstride + (ky * 7 + kx) * C, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += v[j];
         ++cnt;
       }
     }
-    if (normalize) acc = acc / (float)cnt;
-    out[i] = from_f32<T>(apply_act(acc, act, 0.f));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = apply_act(normalize ? acc[j] / (float)cnt : acc[j], act, 0.f);
+    store8<T>(out + pix * C + cc * 8, acc);
   }
 }
 
@@ -247,9 +255,11 @@ using namespace pp;
 extern "C" int pp_fold_tokens(const void* tokens, void* out, int BT, int fh, int fw, int C, int H, int W, int normalize,
                               int act, int dtype, void* stream) {
   PP_REQUIRE(tokens && out && BT > 0 && fh > 0 && fw > 0 && C > 0 && H > 0 && W > 0, PP_ERR_ARG, "pp_fold_tokens: bad arguments");
+  PP_REQUIRE(C % 8 == 0 && (uintptr_t)tokens % 16 == 0 && (uintptr_t)out % 16 == 0, PP_ERR_ALIGN,
+             "pp_fold_tokens: C=%d must be a multiple of 8 and the buffers 16-byte aligned", C);
   PP_REQUIRE(dtype == PP_F32 || dtype == PP_F16, PP_ERR_DTYPE, "pp_fold_tokens: dtype %d", dtype);
   PP_REQUIRE(fh == (H + 6 - 7) / 3 + 1 && fw == (W + 6 - 7) / 3 + 1, PP_ERR_ARG, "pp_fold_tokens: token grid %dx%d does not match %dx%d", fh, fw, H, W);
-  const int g = grid_for((long long)BT * H * W * C);
+  const int g = grid_for((long long)BT * H * W * (C / 8));
   PP_DISPATCH_T(dtype, hipLaunchKernelGGL((fold_tokens_kernel<T>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const T*)tokens,
                                           (T*)out, BT, fh, fw, C, H, W, normalize, act);)
   return launch_status("pp_fold_tokens");

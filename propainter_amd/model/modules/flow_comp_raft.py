@@ -186,6 +186,10 @@ class RAFT_bi(nn.Module):
         for p in self.parameters():
             p.requires_grad = False
         self.compute_dtype = compute_dtype     # None: follow the input dtype (the reference keeps RAFT in fp32)
+        # Every pair is computed independently of its batch neighbours (InstanceNorm per sample, BatchNorm folded), so a
+        # clip driver may hand over all frames at once instead of the reference's 12/8/4/2-frame clips
+        # (inference_propainter.py:302-330): identical flows, each frame encoded once, larger GEMMs.
+        self.batch_invariant = True
         self.max_pairs = max_pairs
         self._engine = None
         self.to(device)
@@ -206,9 +210,17 @@ class RAFT_bi(nn.Module):
             raise ValueError(f"RAFT needs H, W multiples of 8 and >= 128 (got {h}x{w}; RAFT/utils/utils.py:61-62)")
         dt = self.compute_dtype or gt_local_frames.dtype
         eng = self._get_engine(dt, gt_local_frames.device)
-        x = hip.nchw_to_nhwc(gt_local_frames.reshape(b * l_t, c, h, w).contiguous(), out_dtype=dt, cpad=8)
-        fmap = eng.encode(eng.fnet, x, True).view(b, l_t, h // 8, w // 8, 256)
-        ctx = eng.encode(eng.cnet, x, False).view(b, l_t, h // 8, w // 8, 256)
+        fr = gt_local_frames.reshape(b * l_t, c, h, w)
+        # encoders once per frame, in frame chunks that keep every activation below 2 GiB (32-bit buffer offsets of the
+        # LDS-DMA gather; InstanceNorm statistics are per frame, so chunking does not change results)
+        fchunk = max(1, (1 << 30) // (h * w * 16 * 4))     # largest activation: [H/2, W/2, 64] per frame, <= 1 GiB in fp32
+        fm, cx_ = [], []
+        for s in range(0, b * l_t, fchunk):
+            x = hip.nchw_to_nhwc(fr[s:s + fchunk].contiguous(), out_dtype=dt, cpad=8)
+            fm.append(eng.encode(eng.fnet, x, True))
+            cx_.append(eng.encode(eng.cnet, x, False))
+        fmap = (fm[0] if len(fm) == 1 else torch.cat(fm, 0)).view(b, l_t, h // 8, w // 8, 256)
+        ctx = (cx_[0] if len(cx_) == 1 else torch.cat(cx_, 0)).view(b, l_t, h // 8, w // 8, 256)
         a_f, a_b = fmap[:, :-1].reshape(-1, h // 8, w // 8, 256), fmap[:, 1:].reshape(-1, h // 8, w // 8, 256)
         c_f, c_b = ctx[:, :-1].reshape(-1, h // 8, w // 8, 256), ctx[:, 1:].reshape(-1, h // 8, w // 8, 256)
         f1 = torch.cat([a_f, a_b], 0)
@@ -216,7 +228,7 @@ class RAFT_bi(nn.Module):
         cx = torch.cat([c_f, c_b], 0)
         P = f1.shape[0]
         n8 = (h // 8) * (w // 8)
-        chunk = self.max_pairs or max(1, int(24e9 // (n8 * n8 * 4 * 1.34)))
+        chunk = self.max_pairs or max(1, int(40e9 // (n8 * n8 * 4 * 1.34)))      # fp32 pyramid bytes per pair-direction
         ups = [eng.refine(f1[i:i + chunk].contiguous(), f2[i:i + chunk].contiguous(), cx[i:i + chunk].contiguous(), iters)
                for i in range(0, P, chunk)]
         up = torch.cat(ups, 0).to(gt_local_frames.dtype)

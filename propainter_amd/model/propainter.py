@@ -83,7 +83,9 @@ class _GenEngine:
         self.dec = [mk(*g("decoder.0.conv"), padding=1), mk(*g("decoder.2"), padding=1),
                     mk(*g("decoder.4.conv"), padding=1), mk(*g("decoder.6"), padding=1)]
         self.ss = mk(sd["ss.embedding.weight"].view(HIDDEN, 128, 7, 7), sd["ss.embedding.bias"], stride=3, padding=3)
-        self.sc_embed = mk(*g("sc.embedding"))
+        # fold kernels read tap-major token features (ky*7+kx)*C + c: permute the producing Linear's rows (exact)
+        tap_major = lambda w, b, c: (w.view(c, 49, -1).permute(1, 0, 2).reshape(c * 49, -1), b.view(c, 49).t().reshape(-1))
+        self.sc_embed = mk(*tap_major(*g("sc.embedding"), 128))
         self.sc_bias = mk(*g("sc.bias_conv"), padding=1)
         fp = "feat_prop_module."
         self.prop = {}
@@ -113,7 +115,7 @@ class _GenEngine:
                 n2=(f32(sd[t + "norm2.weight"]), f32(sd[t + "norm2.bias"])),
                 qkv=mk(qkv_w, qkv_b), kv=mk(kv_w, kv_b), proj=mk(*g(a + "proj")),
                 pool_w=f32(sd[a + "pool_layer.weight"].view(HIDDEN, 4, 4)), pool_b=f32(sd[a + "pool_layer.bias"]),
-                fc1=mk(*g(t + "mlp.fc1.0")),
+                fc1=mk(*tap_major(*g(t + "mlp.fc1.0"), 40)),
                 fc2=mk(sd[t + "mlp.fc2.1.weight"].view(HIDDEN, 40, 7, 7), sd[t + "mlp.fc2.1.bias"], stride=3, padding=3)))
         self._win_cache = {}
 
@@ -234,15 +236,33 @@ class _GenEngine:
         return x
 
     # ------------------------------------------------------------------ whole forward (:319-372)
-    def forward(self, masked_frames, flows_bi, masks_in, masks_updated, l_t, interpolation, t_dilation):
+    def encode_frames(self, masked_frames, masks_in, masks_updated, chunk=16):
+        """Encoder features of every frame of [1,t,3,H,W] / [1,t,1,H,W] inputs -> NHWC [t,H/4,W/4,128].
+        The encoder is per-frame (propainter.py:334-336: cat(frame, mask_in, mask_updated) -> Encoder), so the clip
+        driver computes it once per frame and hands each window its slice instead of re-encoding every frame in every
+        window (17.5 % of the reference's FLOPs); results are identical."""
         b, t, _, H, W = masked_frames.shape
         assert b == 1, "the inference path runs one clip per call (inference_propainter.py always has b == 1)"
         dt, dev = self.dtype, masked_frames.device
-        x = torch.zeros((t, H, W, 8), dtype=dt, device=dev)
-        hip.nchw_to_nhwc(masked_frames[0].contiguous(), out=x, out_choff=0)
-        hip.nchw_to_nhwc(masks_in[0].contiguous(), out=x, out_choff=3)
-        hip.nchw_to_nhwc(masks_updated[0].contiguous(), out=x, out_choff=4)
-        enc = self.encode(x)                                              # [t,h,w,128]
+        outs = []
+        for s in range(0, t, chunk):
+            e = min(t, s + chunk)
+            x = torch.zeros((e - s, H, W, 8), dtype=dt, device=dev)
+            hip.nchw_to_nhwc(masked_frames[0, s:e].contiguous(), out=x, out_choff=0)
+            hip.nchw_to_nhwc(masks_in[0, s:e].contiguous(), out=x, out_choff=3)
+            hip.nchw_to_nhwc(masks_updated[0, s:e].contiguous(), out=x, out_choff=4)
+            outs.append(self.encode(x))
+        return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
+
+    def forward(self, masked_frames, flows_bi, masks_in, masks_updated, l_t, interpolation, t_dilation, enc_feat=None):
+        b, t, _, H, W = masked_frames.shape
+        assert b == 1, "the inference path runs one clip per call (inference_propainter.py always has b == 1)"
+        dt, dev = self.dtype, masked_frames.device
+        if enc_feat is None:
+            enc = self.encode_frames(masked_frames, masks_in, masks_updated)   # [t,h,w,128]
+        else:
+            enc = enc_feat
+            assert enc.shape[0] == t and enc.shape[-1] == 128 and enc.dtype == dt and enc.is_contiguous(), enc.shape
         h, w = enc.shape[1], enc.shape[2]
         # 1/4-res flows (bilinear, align_corners=False, /4) and masks (nearest) — tiny host-side glue (:338-342)
         dsf = F.interpolate(flows_bi[0][0], scale_factor=1 / 4, mode="bilinear", align_corners=False) / 4.0
@@ -351,8 +371,17 @@ class InpaintGenerator(nn.Module):
                                    interpolation)
 
     @torch.no_grad()
+    def encode_frames(self, masked_frames, masks_in, masks_updated):
+        """Engine extension (not in the reference API): per-frame encoder features, NHWC [t,H/4,W/4,128], to be passed
+        to ``forward(..., enc_feat=feat[ids])`` so that a clip driver encodes every frame once."""
+        hip.require_gpu(masked_frames, "InpaintGenerator")
+        dt = masked_frames.dtype
+        eng = self._get_engine(dt, masked_frames.device)
+        return eng.encode_frames(masked_frames, masks_in.to(dt), masks_updated.to(dt))
+
+    @torch.no_grad()
     def forward(self, masked_frames, completed_flows, masks_in, masks_updated, num_local_frames,
-                interpolation='bilinear', t_dilation=2):
+                interpolation='bilinear', t_dilation=2, enc_feat=None):
         hip.require_gpu(masked_frames, "InpaintGenerator")
         if self.training:
             raise NotImplementedError("training is outside the inference hot path; call .eval()")
@@ -360,4 +389,4 @@ class InpaintGenerator(nn.Module):
         dt = masked_frames.dtype
         eng = self._get_engine(dt, masked_frames.device)
         return eng.forward(masked_frames, (completed_flows[0].to(dt), completed_flows[1].to(dt)), masks_in.to(dt),
-                           masks_updated.to(dt), num_local_frames, interpolation, t_dilation)
+                           masks_updated.to(dt), num_local_frames, interpolation, t_dilation, enc_feat=enc_feat)

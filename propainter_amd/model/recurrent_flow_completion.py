@@ -119,31 +119,40 @@ class _FCEngine:
                             residual=x.view(tb, h, w, c))
         return fused.view(t, b, h, w, c)
 
-    def forward(self, masked_flows, masks):
-        b, t, _, H, W = masked_flows.shape
-        dt = self.dtype
-        x = torch.zeros((b * t, H, W, 8), dtype=dt, device=masked_flows.device)
-        hip.nchw_to_nhwc(masked_flows.reshape(b * t, 2, H, W).contiguous(), out=x, out_choff=0)
-        hip.nchw_to_nhwc(masks.reshape(b * t, 1, H, W).contiguous(), out=x, out_choff=2)
+    def _encode(self, masked_flows, masks):
+        """downsample + P3D encoders + dilated mid convs of ONE sequence [t,2,H,W] / [t,1,H,W] (:272-286)."""
+        t, _, H, W = masked_flows.shape
+        x = torch.zeros((t, H, W, 8), dtype=self.dtype, device=masked_flows.device)
+        hip.nchw_to_nhwc(masked_flows.contiguous(), out=x, out_choff=0)
+        hip.nchw_to_nhwc(masks.contiguous(), out=x, out_choff=2)
         x = self.down([x], act="lrelu", act_param=0.2)
         feats = []
         for si, (spatial, temporal) in enumerate(self.p3d):
             x = spatial([x], act="lrelu", act_param=0.2)
-            x = self.temporal(temporal, x, b, t, "lrelu", 0.2)      # P3DBlock conv2, then the Sequential's LeakyReLU
+            x = self.temporal(temporal, x, 1, t, "lrelu", 0.2)      # P3DBlock conv2, then the Sequential's LeakyReLU
             feats.append(x)
-        e1 = feats[1]
         for m in self.mid:
             x = m([x], act="lrelu", act_param=0.2)
-        h8, w8 = x.shape[1], x.shape[2]
-        xt = x.view(b, t, h8, w8, 128).transpose(0, 1).contiguous()
-        p = self.propagate(xt, b, t).transpose(0, 1).contiguous().view(b * t, h8, w8, 128)
+        return x, feats[1]
+
+    def _decode(self, p, e1):
+        """decoder2 / decoder1 / upsample (:288-300) of one sequence; p [t,h8,w8,128] -> planar [t,2,H,W]."""
         y = self.dec2_0([p], act="lrelu", act_param=0.2)
         y = self.dec2_2([hip.upsample2x(y)], act="lrelu", act_param=0.2, residual=e1)
         y = self.dec1_0([y], act="lrelu", act_param=0.2)
         y = self.dec1_2([hip.upsample2x(y)], act="lrelu", act_param=0.2)
         y = self.up_0([y], act="lrelu", act_param=0.2)
         y = self.up_2([hip.upsample2x(y)])
-        return hip.nhwc_to_nchw(y, 2).view(b, t, 2, H, W)
+        return hip.nhwc_to_nchw(y, 2)
+
+    def forward(self, masked_flows, masks):
+        """[b,t,2,H,W], [b,t,1,H,W] -> [b,t,2,H,W].  The feed-forward encoders / decoders run per sequence (their
+        activations are large); the latency-bound recurrent propagation advances all b sequences per step."""
+        b, t, _, H, W = masked_flows.shape
+        enc = [self._encode(masked_flows[i], masks[i]) for i in range(b)]
+        xt = torch.stack([e[0] for e in enc], 1)                                   # [t,b,h8,w8,128] time-major
+        p = self.propagate(xt, b, t)
+        return torch.stack([self._decode(p[:, i].contiguous(), enc[i][1]) for i in range(b)], 0)
 
 
 class RecurrentFlowCompleteNet(nn.Module):
@@ -188,11 +197,15 @@ class RecurrentFlowCompleteNet(nn.Module):
         masks_backward = masks[:, 1:, ...].contiguous()
         masked_flows_forward = masked_flows_bi[0] * (1 - masks_forward)
         masked_flows_backward = masked_flows_bi[1] * (1 - masks_backward)
-        pred_flows_forward, pred_edges_forward = self.forward(masked_flows_forward, masks_forward)
-        pred_flows_backward, pred_edges_backward = self.forward(torch.flip(masked_flows_backward, dims=[1]),
-                                                                torch.flip(masks_backward, dims=[1]))
-        pred_flows_backward = torch.flip(pred_flows_backward, dims=[1])
-        return [pred_flows_forward, pred_flows_backward], [pred_edges_forward, pred_edges_backward]
+        # The reference runs the net twice (forward flows, then the time-flipped backward flows).  The two sequences
+        # are independent samples, so they are stacked along the batch axis: same results, and the 2*t sequential
+        # propagation steps are paid once instead of twice.
+        nb = masked_flows_forward.size(0)
+        pred, pred_edges = self.forward(torch.cat([masked_flows_forward, torch.flip(masked_flows_backward, dims=[1])], 0),
+                                        torch.cat([masks_forward, torch.flip(masks_backward, dims=[1])], 0))
+        pred_flows_forward = pred[:nb]
+        pred_flows_backward = torch.flip(pred[nb:], dims=[1])
+        return [pred_flows_forward, pred_flows_backward], [pred_edges, pred_edges]
 
     def combine_flow(self, masked_flows_bi, pred_flows_bi, masks):
         """reference :340-347."""

@@ -75,7 +75,8 @@ def compute_flows(fix_raft, frames, raft_iter):
     """Stage A (:302-330): RAFT (fp32 input like the reference) in clips of raft_clip_length with 1 frame overlap."""
     L = frames.size(1)
     sl = raft_clip_length(frames.size(-1))
-    if L <= sl:
+    if L <= sl or getattr(fix_raft, "batch_invariant", False):
+        # the reference clips only to bound memory; an engine whose pairs are batch-independent takes the whole clip
         return fix_raft(frames, iters=raft_iter)
     ff, fb = [], []
     for f in range(0, L, sl):
@@ -170,10 +171,13 @@ def run_clip(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg: InferenceC
     updated_frames, updated_masks = propagate_images(model, frames, masks_dilated, pred_flows_bi, cfg.subvideo_length)
     mark('image_propagation')
     comp = Compositor(fr_u8, masks_dilated)
+    # engine extension: encode every frame once (the encoder is per-frame), windows take slices -- same results
+    enc_all = model.encode_frames(updated_frames, masks_dilated, updated_masks) if hasattr(model, "encode_frames") else None
     for nb, ref in window_schedule(L, cfg.neighbor_length, cfg.ref_stride, cfg.subvideo_length):
         ids = nb + ref
+        kw = {} if enc_all is None else {"enc_feat": enc_all[ids]}
         pred = model(updated_frames[:, ids], (pred_flows_bi[0][:, nb[:-1]], pred_flows_bi[1][:, nb[:-1]]),
-                     masks_dilated[:, ids], updated_masks[:, ids], len(nb))
+                     masks_dilated[:, ids], updated_masks[:, ids], len(nb), **kw)
         comp.add(nb, pred[0])
     mark('generator')
     if return_stages:

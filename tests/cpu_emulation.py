@@ -138,7 +138,8 @@ def _attention(q, k, v, pk, pv, own, rolled, tind, wmask, heads=4, wh=5, ww=9, q
 
 
 def _fold_tokens(tokens, BT, fh, fw, Cc, H, W, normalize=False, act=hip.ACT_NONE):
-    t = tokens.float().view(BT, fh * fw, Cc * 49).permute(0, 2, 1)
+    # device layout is tap-major ((ky*7+kx)*C + c); F.fold wants c*49 + ky*7 + kx
+    t = tokens.float().view(BT, fh * fw, 49, Cc).permute(0, 3, 2, 1).reshape(BT, Cc * 49, fh * fw)
     y = F.fold(t, (H, W), 7, 1, 3, 3)
     if normalize:
         y = y / F.fold(torch.ones_like(t), (H, W), 7, 1, 3, 3)

@@ -46,6 +46,35 @@ def test_flow_completion_graph(models):
     assert (out - torch.from_numpy(g["pred_f"])).abs().max() < 1e-3
 
 
+def test_flow_completion_bidirectional_batched_graph(models):
+    """forward_bidirect_flow stacks the forward and the time-flipped backward sequence along the batch axis (the
+    reference runs the net twice, recurrent_flow_completion.py:312-337): both directions must match the goldens."""
+    fc = models[1]
+    g = load_golden("fc_64x96.npz")
+    fl = (torch.from_numpy(g["flows_f"]), torch.from_numpy(g["flows_b"]))
+    m = torch.from_numpy(g["masks"])
+    with emulated_device_ops():
+        (pf, pb), edges = fc.forward_bidirect_flow(fl, m)
+        cf, cb = fc.combine_flow(fl, (pf, pb), m)
+    assert edges == [None, None]
+    assert (pf - torch.from_numpy(g["pred_f"])).abs().max() < 1e-3
+    assert (pb - torch.from_numpy(g["pred_b"])).abs().max() < 1e-3
+    assert (cf - torch.from_numpy(g["comb_f"])).abs().max() < 1e-3
+
+
+def test_generator_cached_encoder_features(models):
+    """encode_frames() once + forward(enc_feat=slice) == forward() (the encoder is per-frame)."""
+    gen = models[2]
+    g = load_golden("gen_64x96.npz")
+    fr, mk, mu = (torch.from_numpy(g[k]) for k in ("frames", "masks_in", "masks_upd"))
+    fl = (torch.from_numpy(g["flows_f"]), torch.from_numpy(g["flows_b"]))
+    with emulated_device_ops():
+        feat = gen.encode_frames(fr * (1 - mk), mk, mu)
+        ids = list(range(fr.shape[1]))
+        out = gen(fr * (1 - mk), fl, mk, mu, int(g["lt"]), enc_feat=feat[ids])
+    assert (out - torch.from_numpy(g["out"])).abs().max() < 1e-3
+
+
 def test_generator_graph(models):
     gen = models[2]
     g = load_golden("gen_64x96.npz")

@@ -316,8 +316,10 @@ def test_token_ops(dev, dt):
     tq = tok.to(dt).float()
     folded = F.fold(tq.permute(0, 2, 1), (H, W), 7, 1, 3, 3)
     norm = F.fold(torch.ones_like(tq).permute(0, 2, 1), (H, W), 7, 1, 3, 3)
-    out = hip.fold_tokens(tok.to(dev, dt), BT, fh, fw, C, H, W, normalize=True, act=hip.ACT_GELU)
-    out2 = hip.fold_tokens(tok.to(dev, dt), BT, fh, fw, C, H, W, normalize=False)
+    # the device op takes tap-major features ((ky*7+kx)*C + c); the reference (F.fold) order is c*49 + ky*7 + kx
+    tok_dev = tok.view(BT, fh * fw, C, 49).transpose(2, 3).contiguous().view(BT, fh * fw, 49 * C).to(dev, dt)
+    out = hip.fold_tokens(tok_dev, BT, fh, fw, C, H, W, normalize=True, act=hip.ACT_GELU)
+    out2 = hip.fold_tokens(tok_dev, BT, fh, fw, C, H, W, normalize=False)
     torch.cuda.synchronize()
     check("fold_norm_gelu", out.permute(0, 3, 1, 2), F.gelu(folded / norm), tol(dt))
     check("fold", out2.permute(0, 3, 1, 2), folded, tol(dt))
