@@ -28,6 +28,25 @@ if ROOT not in sys.path:
 
 PEAK_TFLOPS = {"f16": 2500.0, "f32": 157.3}     # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+# KernelProfiler class -> kernel family of tools/rocprof_summary.py (profiles/*_hbm_traffic.json, PMC passes)
+TRAFFIC_FAMILY = {"conv_gemm_f16": "conv_gemm_f16 (LDS-DMA implicit GEMM)", "conv_gemm_f32": "conv_gemm_f32",
+                  "conv_gemm_dcn": "conv_gemm_f16/dcn (register-staged)", "sparse_window_attention": "sparse_window_attention",
+                  "fold_tokens": "fold_tokens", "corr_lookup": "corr_lookup"}
+
+
+def pmc_traffic(kernel_class):
+    """HBM bytes per launch of a kernel class from the committed rocprofv3 --pmc summary (FETCH_SIZE / WRITE_SIZE in
+    separate passes, gfx950 correction applied by tools/rocprof_summary.py); None when no summary is present."""
+    import glob
+    fam = TRAFFIC_FAMILY.get(kernel_class)
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_traffic*.json")), reverse=True):
+        try:
+            rec = json.load(open(f))["families"].get(fam)
+        except Exception:
+            continue
+        if rec:
+            return rec["hbm_bytes_per_launch"]
+    return None
 
 
 def parse():
@@ -43,12 +62,14 @@ def parse():
     ap.add_argument("--subvideo_length", type=int, default=80)
     ap.add_argument("--raft_iter", type=int, default=20)
     ap.add_argument("--fp32", action="store_true", help="run stages B-D in fp32 instead of fp16")
-    ap.add_argument("--raft-dtype", default="f32", choices=["f32", "f16"],
-                    help="RAFT engine dtype: f32 = exact fp32 MFMA like the reference (it keeps RAFT fp32 under --fp16, "
-                         "inference_propainter.py:311); f16 = fp16 storage + MFMA with fp32 accumulate")
+    ap.add_argument("--raft-dtype", default="f16", choices=["f32", "f16"],
+                    help="RAFT engine dtype: f16 (default) = fp16 activations/weights on MFMA with fp32 accumulation, fp32 "
+                         "correlation volume, coordinates and flow (SURVEY.md section 7; measured EPE vs the fp32 reference "
+                         "in tests/test_modules_gpu.py); f32 = exact fp32 MFMA like the reference, which keeps RAFT fp32 "
+                         "under --fp16 (inference_propainter.py:311)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the instrumented (per-kernel HIP events) step")
-    ap.add_argument("--cpu-sample-frames", type=int, default=6)
+    ap.add_argument("--cpu-sample-frames", type=int, default=4)
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -196,11 +217,14 @@ def main():
         if name.startswith("conv_gemm") or name == "sparse_window_attention":
             peak = PEAK_TFLOPS["f32" if name.endswith("f32") else "f16"]
             roof = {"kernel": name, "bound": "mfma", "achieved": v["tflops"], "peak": peak, "unit": "TFLOP/s",
-                    "frac": v["tflops"] / peak, "traffic": None, "launches": v["launches"], "avg_launch_us": v["avg_us"],
+                    "frac": v["tflops"] / peak, "traffic": pmc_traffic(name), "launches": v["launches"], "avg_launch_us": v["avg_us"],
+                    "algorithmic_flop_per_launch": v["flops"] / max(1, v["launches"]),
+                    "algorithmic_bytes_per_launch": v["bytes"] / max(1, v["launches"]),
                     "share_of_kernel_time": v["ms"] / sum(x["ms"] for x in kernels.values())}
         else:
             roof = {"kernel": name, "bound": "hbm", "achieved": v["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": v["gbs"] / PEAK_HBM_GBS, "traffic": None, "launches": v["launches"], "avg_launch_us": v["avg_us"],
+                    "frac": v["gbs"] / PEAK_HBM_GBS, "traffic": pmc_traffic(name), "launches": v["launches"], "avg_launch_us": v["avg_us"],
+                    "algorithmic_bytes_per_launch": v["bytes"] / max(1, v["launches"]),
                     "share_of_kernel_time": v["ms"] / sum(x["ms"] for x in kernels.values())}
         stages["instrumented_step_wall_ms"] = prof_wall * 1e3
 

@@ -90,10 +90,24 @@ __global__ __launch_bounds__(256) void attn_ref_kernel(const AttnParams p) {
 }
 
 constexpr int KT = 64;          // keys per tile
-constexpr int KS_LD = HD + 8;   // K tile row stride (elements)
-constexpr int VT_LD = KT + 8;   // V^T tile row stride (elements)
+constexpr int KS_LD = HD + 8;   // K tile row stride (elements): 272 B rows, conflict-free ds_read_b128 / ds_write_b128
+constexpr int VT_LD = KT + 4;   // V^T tile row stride (elements): 34 dwords -> see the bank notes below
 
-__global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnParams p) {
+// Flash-style MFMA kernel.  256 threads = 4 waves; every wave owns QT tiles of 16 queries (QT = 2 -> 128 queries per
+// block for masked windows, whose long key lists dominate the work; QT = 1 -> 64 >= 45 queries for the per-frame
+// self attention of unmasked windows).  The masked / unmasked decision is a device flag, so BOTH instantiations are
+// launched over all windows and each block exits at once if the window is of the other kind (no host sync).
+//
+// Per 64-key tile: K rows are staged row-major; V is staged TRANSPOSED (the PV MFMA wants 8 keys per lane for one
+// channel).  The transposing scalar writes were 16-way bank conflicted with a natural [channel][key] image, so the
+// channel rows are permuted, row(d) = (d % 8) * 16 + d / 8, with a 34-dword row stride: the 16 channel-chunk lanes of a
+// write instruction now hit 16 different banks (2-way at worst from the 2-byte key pairs) and the ds_read_b64
+// fragment reads stay conflict-free (bank = 34*i + 2*g mod 64 is injective over the 32-lane group).  A side effect of
+// the permutation: accumulator row i of tile dt is channel i*8 + dt, so every lane ends with 8 consecutive channels
+// per query -> 16-byte output stores.  Global loads of tile k+1 are issued before the MFMAs of tile k (register
+// prefetch), hiding the gather latency behind the matrix work.
+template <int QT, bool MASKED>
+__global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnParams p) {
   typedef _Float16 T;
   __shared__ __attribute__((aligned(16))) T Ks[KT * KS_LD];
   __shared__ __attribute__((aligned(16))) T Vt[HD * VT_LD];
@@ -102,8 +116,11 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnParams p) {
   const int w = (blockIdx.x / p.heads) % p.nW;
   const int b = blockIdx.x / (p.heads * p.nW);
   const bool masked = p.wmask[b * p.nW + w] > 0.f;
+  if (masked != MASKED) return;                                // the other instantiation owns this window
+  constexpr int QB = 64 * QT;                                  // queries per block
   const int nq_total = p.T * p.wsz;
-  if (masked && (int)blockIdx.y * 64 >= nq_total) return;     // masked windows need ceil(T*45/64) tiles only
+  if (MASKED && (int)blockIdx.y * QB >= nq_total) return;      // masked windows need ceil(T*45/QB) blocks only
+  if (!MASKED && (int)blockIdx.y >= p.T) return;
   const int ngrid = p.wsz + p.n_rolled;
   for (int i = threadIdx.x; i < ngrid; i += 256) idx_lds[i] = i < p.wsz ? p.own[w * p.wsz + i] : p.rolled[w * p.n_rolled + i - p.wsz];
   __syncthreads();
@@ -115,107 +132,136 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnParams p) {
   const T* pkg = reinterpret_cast<const T*>(p.pk);
   const T* pvg = reinterpret_cast<const T*>(p.pv);
 
-  // ---- this lane's query (column lane&15 of the wave's 16-query tile)
-  const int ql = wave * 16 + (lane & 15);
-  int fq, tok;
-  bool qvalid;
-  if (masked) {
-    const int qi = blockIdx.y * 64 + ql;
-    qvalid = qi < nq_total;
-    fq = qvalid ? qi / p.wsz : 0;
-    tok = qvalid ? qi % p.wsz : 0;
-  } else {
-    qvalid = ql < p.wsz;
-    fq = blockIdx.y;
-    tok = qvalid ? ql : 0;
-  }
-  const long long qoff = ((long long)b * p.T + fq) * p.Hp * p.Wp + idx_lds[tok];
-  f16x8 qf[4];
-  {
-    const T* qp = qg + qoff * p.qkv_cs + head * HD + (lane >> 4) * 8;
+  // ---- this lane's queries (column lane&15 of each of the wave's QT 16-query tiles), held as MFMA B fragments
+  long long qoff[QT];
+  bool qvalid[QT];
+  f16x8 qf[QT][4];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const int ql = (wave * QT + qt) * 16 + (lane & 15);
+    int fq, tok;
+    if (MASKED) {
+      const int qi = blockIdx.y * QB + ql;
+      qvalid[qt] = qi < nq_total;
+      fq = qvalid[qt] ? qi / p.wsz : 0;
+      tok = qvalid[qt] ? qi % p.wsz : 0;
+    } else {
+      qvalid[qt] = ql < p.wsz;
+      fq = blockIdx.y;
+      tok = qvalid[qt] ? ql : 0;
+    }
+    qoff[qt] = ((long long)b * p.T + fq) * p.Hp * p.Wp + idx_lds[tok];
+    const T* qp = qg + qoff[qt] * p.qkv_cs + head * HD + (lane >> 4) * 8;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      if (qvalid) qf[s] = *reinterpret_cast<const f16x8*>(qp + s * 32);
-      else qf[s] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (qvalid[qt]) qf[qt][s] = *reinterpret_cast<const f16x8*>(qp + s * 32);
+      else qf[qt][s] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
     }
   }
-  const int kpf = masked ? ngrid + p.P : p.wsz;
-  const int nkeys = masked ? p.n_tind * kpf : p.wsz;
+  const int kpf = MASKED ? ngrid + p.P : p.wsz;
+  const int nkeys = MASKED ? p.n_tind * kpf : p.wsz;
   const float scale = rsqrtf((float)HD);
-
-  f32x4 oacc[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) oacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m_run = -1e30f, l_run = 0.f;
-
   const int frame_blk = blockIdx.y;   // key frame of an unmasked window's block
-  for (int k0 = 0; k0 < nkeys; k0 += KT) {
-    // ---- stage K (row-major) and V (transposed) tiles: 64 keys x 16 chunks of 8 channels.
-    // 16 consecutive lanes read one 256-byte key row (coalesced); zero-fill past the key list.
+
+  f32x4 oacc[QT][8];
+  float m_run[QT], l_run[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    m_run[qt] = -1e30f;
+    l_run[qt] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) oacc[qt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  // ---- tile staging: 64 keys x 16 chunks of 8 channels; 16 consecutive lanes read one 256-byte key row
+  // (coalesced); rows past the key list are zero.
+  u32x4 kr[4], vr[4];
+  auto load_tile = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int c = tid + 256 * i;
       const int key = c >> 4, dch = c & 15;
       const int kk = k0 + key;
-      u32x4 kr = u32x4{0, 0, 0, 0}, vr = u32x4{0, 0, 0, 0};
+      kr[i] = u32x4{0, 0, 0, 0};
+      vr[i] = u32x4{0, 0, 0, 0};
       if (kk < nkeys) {
-        const int f = masked ? p.tind[kk / kpf] : frame_blk;
-        const int r = kk % kpf;
-        kr = *reinterpret_cast<const u32x4*>(key_row<T>(p, kg, pkg, b, f, r, idx_lds, head) + dch * 8);
-        vr = *reinterpret_cast<const u32x4*>(key_row<T>(p, vg, pvg, b, f, r, idx_lds, head) + dch * 8);
+        const int fi = MASKED ? kk / kpf : 0;
+        const int f = MASKED ? p.tind[fi] : frame_blk;
+        const int r = MASKED ? kk - fi * kpf : kk;
+        kr[i] = *reinterpret_cast<const u32x4*>(key_row<T>(p, kg, pkg, b, f, r, idx_lds, head) + dch * 8);
+        vr[i] = *reinterpret_cast<const u32x4*>(key_row<T>(p, vg, pvg, b, f, r, idx_lds, head) + dch * 8);
       }
-      *reinterpret_cast<u32x4*>(&Ks[key * KS_LD + dch * 8]) = kr;
-      const T* ve = reinterpret_cast<const T*>(&vr);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) Vt[(dch * 8 + j) * VT_LD + key] = ve[j];
     }
-    __syncthreads();
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 256 * i;
+      const int key = c >> 4, dch = c & 15;
+      *reinterpret_cast<u32x4*>(&Ks[key * KS_LD + dch * 8]) = kr[i];
+      const T* ve = reinterpret_cast<const T*>(&vr[i]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) Vt[(j * 16 + dch) * VT_LD + key] = ve[j];      // channel dch*8 + j -> row j*16 + dch
+    }
+  };
 
-    // ---- S^T tiles: sacc[kt][r] = score(key = k0 + kt*16 + (lane>>4)*4 + r, query = lane&15)
-    f32x4 sacc[4];
+  load_tile(0);
+  for (int k0 = 0; k0 < nkeys; k0 += KT) {
+    store_tile();
+    __syncthreads();
+    if (k0 + KT < nkeys) load_tile(k0 + KT);          // in flight during the MFMAs below
+
+    // ---- S^T tiles: sacc[qt][kt][r] = score(key = k0 + kt*16 + (lane>>4)*4 + r, query = lane&15 of tile qt)
+    f32x4 sacc[QT][4];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
-      sacc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) sacc[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
       const T* kp = &Ks[(kt * 16 + (lane & 15)) * KS_LD + (lane >> 4) * 8];
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const f16x8 kf = *reinterpret_cast<const f16x8*>(kp + s * 32);
-        sacc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[s], sacc[kt], 0, 0, 0);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) sacc[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qt][s], sacc[qt][kt], 0, 0, 0);
       }
     }
-    // ---- online softmax for this lane's query
-    float tmax = -1e30f;
+    // ---- online softmax per query tile
+    f16x8 pf[QT][2];
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
+    for (int qt = 0; qt < QT; ++qt) {
+      float tmax = -1e30f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int kk = k0 + kt * 16 + (lane >> 4) * 4 + r;
-        const float s = kk < nkeys ? sacc[kt][r] * scale : -1e30f;
-        sacc[kt][r] = s;
-        tmax = fmaxf(tmax, s);
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kk = k0 + kt * 16 + (lane >> 4) * 4 + r;
+          const float sv = kk < nkeys ? sacc[qt][kt][r] * scale : -1e30f;
+          sacc[qt][kt][r] = sv;
+          tmax = fmaxf(tmax, sv);
+        }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+      const float m_new = fmaxf(m_run[qt], tmax);
+      const float alpha = __expf(m_run[qt] - m_new);
+      m_run[qt] = m_new;
+      float psum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = __expf(sacc[qt][kt][r] - m_new);
+          psum += e;
+          pf[qt][kt >> 1][(kt & 1) * 4 + r] = (_Float16)e;
+        }
+      l_run[qt] = l_run[qt] * alpha + psum;     // per-lane partial; the 4 lane groups are summed at the end
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) oacc[qt][dt][r] *= alpha;
       }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-    const float m_new = fmaxf(m_run, tmax);
-    const float alpha = __expf(m_run - m_new);
-    m_run = m_new;
-    float psum = 0.f;
-    f16x8 pf[2];
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float e = __expf(sacc[kt][r] - m_new);
-        psum += e;
-        pf[kt >> 1][(kt & 1) * 4 + r] = (_Float16)e;
-      }
-    l_run = l_run * alpha + psum;     // per-lane partial; the 4 lane groups are summed at the end
-#pragma unroll
-    for (int dt = 0; dt < 8; ++dt) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) oacc[dt][r] *= alpha;
     }
-    // ---- O^T += V^T P^T : k-slot (lane>>4)*8 + i of step j <-> key 32j + (i>>2)*16 + (lane>>4)*4 + (i&3)
+    // ---- O^T += V^T P^T : k-slot (lane>>4)*8 + i of step j <-> key 32j + (i>>2)*16 + (lane>>4)*4 + (i&3);
+    // accumulator row i of tile dt is channel i*8 + dt (row permutation of the V^T image)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -224,21 +270,28 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnParams p) {
         const f16x4 lo = *reinterpret_cast<const f16x4*>(vp);
         const f16x4 hi = *reinterpret_cast<const f16x4*>(vp + 16);
         const f16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[j], oacc[dt], 0, 0, 0);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) oacc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qt][j], oacc[qt][dt], 0, 0, 0);
       }
     }
     __syncthreads();
   }
-  l_run += __shfl_xor(l_run, 16);
-  l_run += __shfl_xor(l_run, 32);
-  if (qvalid) {
-    const float inv = 1.f / l_run;
-    T* op = reinterpret_cast<T*>(p.out) + qoff * p.C + head * HD + (lane >> 4) * 4;
 #pragma unroll
-    for (int dt = 0; dt < 8; ++dt) {
-      const f16x4 o = {(_Float16)(oacc[dt][0] * inv), (_Float16)(oacc[dt][1] * inv), (_Float16)(oacc[dt][2] * inv),
-                       (_Float16)(oacc[dt][3] * inv)};
-      *reinterpret_cast<f16x4*>(op + dt * 16) = o;
+  for (int qt = 0; qt < QT; ++qt) {
+    float l = l_run[qt];
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    if (qvalid[qt]) {
+      const float inv = 1.f / l;
+      // lane holds rows i = (lane>>4)*4 + r of every tile dt -> channels i*8 + dt: 8 consecutive channels per r
+      T* op = reinterpret_cast<T*>(p.out) + qoff[qt] * p.C + head * HD + (lane >> 4) * 32;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        f16x8 o;
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) o[dt] = (_Float16)(oacc[qt][dt][r] * inv);
+        *reinterpret_cast<f16x8*>(op + r * 8) = o;
+      }
     }
   }
 }
@@ -342,7 +395,11 @@ extern "C" int pp_sparse_window_attention(const pp_attn_args_t* a, void* stream)
   hipStream_t st = (hipStream_t)stream;
   const unsigned gx = (unsigned)(p.B * p.nW * p.heads);
   if (a->dtype == PP_F16 && a->impl != 1) {
-    hipLaunchKernelGGL(attn_mfma_kernel, dim3(gx, (unsigned)p.T), dim3(256), 0, st, p);
+    // masked windows: 128-query blocks over the window's T*45 queries; unmasked: one 64-query block per frame.  Both
+    // grids cover every window; blocks of the wrong kind return immediately (device-side flag, no host sync).
+    const unsigned gy_m = (unsigned)((p.T * p.wsz + 127) / 128);
+    hipLaunchKernelGGL((attn_mfma_kernel<2, true>), dim3(gx, gy_m), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((attn_mfma_kernel<1, false>), dim3(gx, (unsigned)p.T), dim3(256), 0, st, p);
   } else {
     const unsigned gy = (unsigned)((p.T * p.wsz + 3) / 4);
     if (a->dtype == PP_F16) hipLaunchKernelGGL((attn_ref_kernel<_Float16>), dim3(gx, gy), dim3(256), 0, st, p);
