@@ -220,7 +220,10 @@ int pp_layernorm(const void* in, const float* gamma, const float* beta, void* ou
 int pp_depthwise_pool(const void* in, const float* weight, const float* bias, void* out, int N, int H, int W, int C,
                       int k, int dtype, void* stream);
 
-/* InstanceNorm2d (no affine, eps) over NHWC [N,H,W,C] + optional ReLU; stats fp32 workspace [N*C*2]. */
+/* InstanceNorm2d (no affine, eps; RAFT/extractor.py:126-133 fnet norm layers) over NHWC [N,H,W,C] + optional ReLU.
+ * Deterministic two-stage reduction (no atomics).  stats_ws: caller-owned fp32 workspace of
+ * pp_instance_norm_workspace_floats(N,H,W,C) elements, 16-byte aligned.  C % 8 == 0, C <= 256. */
+int64_t pp_instance_norm_workspace_floats(int N, int H, int W, int C);
 int pp_instance_norm(const void* in, void* out, float* stats_ws, int N, int H, int W, int C, float eps, int relu,
                      int dtype, void* stream);
 

@@ -99,28 +99,64 @@ __global__ void depthwise_pool_kernel(const T* __restrict__ in, const float* __r
   }
 }
 
-// InstanceNorm statistics: grid (channel-block of 64, slice, n): each thread accumulates one channel over a
-// slice of the pixels; partial sums are combined with atomics into ws[n][c][2] (sum, sumsq in fp32).
+// InstanceNorm statistics, deterministic (no atomics: the flows feed discontinuous 'nearest' warps, so run-to-run
+// bit differences are not acceptable).  Stage 1: grid (slice, n); a block streams its slice of pixels with 16-byte
+// channel vectors (C/8 lanes per pixel, 256/(C/8) pixels per pass), reduces the per-thread partials through LDS in a
+// fixed order and writes part[n][slice][c] = (sum, sumsq).  Stage 2: one thread per (n, c) adds the slices in order
+// and writes ws[n][c] = (mean, rstd).
 template <typename T>
-__global__ void inorm_stats_kernel(const T* __restrict__ in, float* __restrict__ ws, int HW, int C, int slices) {
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int sub = threadIdx.x >> 6;                    // 4 pixel phases per block
-  const int n = blockIdx.z;
-  if (c >= C) return;
+__global__ __launch_bounds__(256) void inorm_stats_kernel(const T* __restrict__ in, float* __restrict__ part, int HW, int C,
+                                                          int slices) {
+  __shared__ float red[256][17];
+  const int lpp = C / 8;                               // lanes per pixel
+  const int ppp = 256 / lpp;                           // pixels per pass
+  const int tid = threadIdx.x;
+  const int n = blockIdx.y, sl = blockIdx.x;
   const int per = (HW + slices - 1) / slices;
-  const int p0 = blockIdx.y * per, p1 = min(HW, p0 + per);
-  float s = 0.f, q = 0.f;
-  for (int p = p0 + sub; p < p1; p += 4) {
-    const float v = to_f32(in[((long long)n * HW + p) * C + c]);
-    s += v; q += v * v;
+  const int p0 = sl * per, p1 = min(HW, p0 + per);
+  float s[8], q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+  const int cc = tid % lpp, pl = tid / lpp;
+  if (pl < ppp) {
+    for (int p = p0 + pl; p < p1; p += ppp) {
+      float v[8];
+      load8<T>(in + ((long long)n * HW + p) * C + cc * 8, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s[j] += v[j]; q[j] += v[j] * v[j]; }
+    }
   }
-  atomicAdd(&ws[((long long)n * C + c) * 2], s);
-  atomicAdd(&ws[((long long)n * C + c) * 2 + 1], q);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { red[tid][j] = s[j]; red[tid][8 + j] = q[j]; }
+  __syncthreads();
+  if (tid < C) {
+    const int c8 = tid / 8, j = tid % 8;
+    float ts = 0.f, tq = 0.f;
+    for (int r = 0; r < ppp; ++r) { ts += red[r * lpp + c8][j]; tq += red[r * lpp + c8][8 + j]; }
+    float* o = part + (((long long)n * slices + sl) * C + tid) * 2;
+    o[0] = ts; o[1] = tq;
+  }
+}
+
+__global__ void inorm_finalize_kernel(const float* __restrict__ part, float* __restrict__ ws, int N, int C, int slices, int HW,
+                                      float eps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * C) return;
+  const int n = i / C, c = i % C;
+  float s = 0.f, q = 0.f;
+  for (int sl = 0; sl < slices; ++sl) {
+    const float* o = part + (((long long)n * slices + sl) * C + c) * 2;
+    s += o[0]; q += o[1];
+  }
+  const float mean = s / (float)HW;
+  const float var = fmaxf(q / (float)HW - mean * mean, 0.f);
+  ws[(long long)i * 2] = mean;
+  ws[(long long)i * 2 + 1] = rsqrtf(var + eps);
 }
 
 template <typename T>
 __global__ void inorm_apply_kernel(const T* __restrict__ in, const float* __restrict__ ws, T* __restrict__ out, long long N,
-                                   int HW, int C, float eps, int relu) {
+                                   int HW, int C, int relu) {
   const long long total = N * HW * (C / 8);
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int cc = (int)(i % (C / 8));
@@ -128,13 +164,13 @@ __global__ void inorm_apply_kernel(const T* __restrict__ in, const float* __rest
     const long long n = pix / HW;
     float v[8];
     load8<T>(in + pix * C + cc * 8, v);
+    const float4* st = reinterpret_cast<const float4*>(ws + (n * C + cc * 8) * 2);   // (mean, rstd) x 8, 16-byte aligned
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float s = ws[(n * C + cc * 8 + j) * 2], q = ws[(n * C + cc * 8 + j) * 2 + 1];
-      const float mean = s / (float)HW;
-      const float var = fmaxf(q / (float)HW - mean * mean, 0.f);
-      float r = (v[j] - mean) * rsqrtf(var + eps);
-      v[j] = relu ? fmaxf(r, 0.f) : r;
+    for (int j = 0; j < 4; ++j) {
+      const float4 m = st[j];
+      const float r0 = (v[2 * j] - m.x) * m.y, r1 = (v[2 * j + 1] - m.z) * m.w;
+      v[2 * j] = relu ? fmaxf(r0, 0.f) : r0;
+      v[2 * j + 1] = relu ? fmaxf(r1, 0.f) : r1;
     }
     store8<T>(out + pix * C + cc * 8, v);
   }
@@ -286,20 +322,32 @@ extern "C" int pp_depthwise_pool(const void* in, const float* weight, const floa
   return launch_status("pp_depthwise_pool");
 }
 
+static int inorm_slices(int HW) {
+  int slices = HW / 2048; if (slices < 1) slices = 1; if (slices > 256) slices = 256;
+  return slices;
+}
+
+extern "C" int64_t pp_instance_norm_workspace_floats(int N, int H, int W, int C) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return PP_ERR_ARG;
+  return (int64_t)N * C * 2 * (1 + inorm_slices(H * W));
+}
+
 extern "C" int pp_instance_norm(const void* in, void* out, float* stats_ws, int N, int H, int W, int C, float eps, int relu,
                                 int dtype, void* stream) {
-  PP_REQUIRE(in && out && stats_ws && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, PP_ERR_ARG, "pp_instance_norm: bad arguments");
+  PP_REQUIRE(in && out && stats_ws && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && C <= 256, PP_ERR_ARG,
+             "pp_instance_norm: bad arguments (C=%d must be a multiple of 8, <= 256)", C);
   PP_REQUIRE(dtype == PP_F32 || dtype == PP_F16, PP_ERR_DTYPE, "pp_instance_norm: dtype %d", dtype);
+  PP_REQUIRE((uintptr_t)stats_ws % 16 == 0, PP_ERR_ALIGN, "pp_instance_norm: workspace must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(stats_ws, 0, sizeof(float) * 2 * (size_t)N * C, st);
-  if (e != hipSuccess) { set_error("pp_instance_norm: memset: %s", hipGetErrorString(e)); return (int)e; }
   const int HW = H * W;
-  int slices = HW / 512; if (slices < 1) slices = 1; if (slices > 128) slices = 128;
-  dim3 sg((C + 63) / 64, slices, N);
+  const int slices = inorm_slices(HW);
+  float* part = stats_ws + (size_t)N * C * 2;           // [N][slices][C][2] after the final (mean, rstd) table
   PP_DISPATCH_T(dtype,
-                hipLaunchKernelGGL((inorm_stats_kernel<T>), sg, dim3(256), 0, st, (const T*)in, stats_ws, HW, C, slices);
+                hipLaunchKernelGGL((inorm_stats_kernel<T>), dim3(slices, N), dim3(256), 0, st, (const T*)in, part, HW, C, slices);
+                hipLaunchKernelGGL(inorm_finalize_kernel, dim3((N * C + 255) / 256), dim3(256), 0, st, (const float*)part, stats_ws,
+                                   N, C, slices, HW, eps);
                 hipLaunchKernelGGL((inorm_apply_kernel<T>), dim3(grid_for((long long)N * HW * (C / 8))), dim3(256), 0, st,
-                                   (const T*)in, stats_ws, (T*)out, (long long)N, HW, C, eps, relu);)
+                                   (const T*)in, (const float*)stats_ws, (T*)out, (long long)N, HW, C, relu);)
   return launch_status("pp_instance_norm");
 }
 

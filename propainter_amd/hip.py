@@ -374,7 +374,9 @@ def depthwise_pool(x, weight, bias, k=4):
 def instance_norm(x, relu=False, eps=1e-5, out=None):
     N, H, W, Cc = x.shape
     out = torch.empty_like(x) if out is None else out
-    ws = torch.empty((N * Cc * 2,), dtype=torch.float32, device=x.device)
+    L = lib()
+    L.pp_instance_norm_workspace_floats.restype = C.c_int64
+    ws = torch.empty((int(L.pp_instance_norm_workspace_floats(N, H, W, Cc)),), dtype=torch.float32, device=x.device)
     assert x.is_contiguous()
     timed("instance_norm", 0, _nbytes(x) * 2 + _nbytes(out), lambda: _check(lib().pp_instance_norm(_p(x), _p(out), _p(ws), _i(N), _i(H), _i(W), _i(Cc), C.c_float(eps),
                                   _i(1 if relu else 0), _i(dtype_code(x.dtype)), _stream()),

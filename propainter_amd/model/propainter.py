@@ -161,12 +161,16 @@ class _GenEngine:
             outs = torch.empty((t, h, w, c), dtype=dt, device=dev)
             if t > 1:
                 # aux[i-1] = [flow_prop(2) | valid(1) | mask_cur(2) | 0 0 0] for step i; all fb checks in one launch
-                sel_f = torch.tensor([fidx[i] for i in range(1, t)], device=dev)
-                sel_m = torch.tensor([order[i] for i in range(1, t)], device=dev)
+                # (step i >= 1 uses flow fidx[i] and the mask of frame order[i]: a reversed / shifted slice -- no index
+                # tensors, so the whole window is capturable in a hipGraph)
+                if name == "backward_1":
+                    fp_sel, fc_sel, m_sel = f_prop[:t - 1].flip(0), f_chk[:t - 1].flip(0), mask2[:t - 1].flip(0)
+                else:
+                    fp_sel, fc_sel, m_sel = f_prop[:t - 1], f_chk[:t - 1], mask2[1:]
                 aux = torch.zeros((t - 1, h, w, 8), dtype=dt, device=dev)
-                aux[..., :2] = f_prop[sel_f]
-                aux[..., 3:5] = mask2[sel_m]
-                chk = f_chk[sel_f].contiguous()
+                aux[..., :2] = fp_sel
+                aux[..., 3:5] = m_sel
+                chk = fc_sel.contiguous()
                 hip.fb_check(aux, chk, out=aux, out_choff=2)
             prop = None
             for i, idx in enumerate(order):

@@ -136,3 +136,24 @@ def test_end_to_end_clip_vs_golden(models):
     outside = g["masks_u8"][..., None] == 0
     assert np.array_equal(comp[np.broadcast_to(outside, comp.shape)], g["frames_u8"][np.broadcast_to(outside, comp.shape)])
     assert psnr > 40.0, f"end-to-end PSNR vs reference {psnr:.2f} dB"
+
+
+@pytest.mark.parametrize("fp16", [False, True], ids=["f32", "f16"])
+def test_clip_graph_replay_is_bit_identical_to_eager(models, fp16):
+    """pipeline.ClipGraph (one hipGraph of the whole pass) replays the very kernels of run_clip in the same order:
+    the composited frames must be bit-identical, also after the static input buffers are refilled with another clip."""
+    from propainter_amd.pipeline import ClipGraph, InferenceConfig, run_clip
+    from propainter_amd.synthetic import synthetic_clip
+    g = load_golden("e2e_128x192.npz")
+    dev = torch.device("cuda")
+    cfg = InferenceConfig(raft_iter=int(g["raft_iter"]), subvideo_length=int(g["subvideo_length"]),
+                          neighbor_length=int(g["neighbor_length"]), ref_stride=int(g["ref_stride"]), fp16=fp16)
+    L, H, W = g["frames_u8"].shape[:3]
+    cg = ClipGraph(models, L, H, W, cfg, dev)
+    for clip in (g["frames_u8"], synthetic_clip(L, H, W, seed=77)):
+        eager = run_clip(models, clip, g["masks_u8"], g["masks_u8"], cfg, dev).clone()
+        again = run_clip(models, clip, g["masks_u8"], g["masks_u8"], cfg, dev)
+        assert torch.equal(again, eager), "the eager pass itself is not run-to-run deterministic"
+        out = cg(clip, g["masks_u8"], g["masks_u8"])
+        torch.cuda.synchronize()
+        assert torch.equal(out, eager), f"graph replay differs from eager in {(out != eager).float().mean().item():.3e} of bytes"

@@ -1,8 +1,12 @@
 #!/bin/bash
-# First-measurement script: bench at 240p and 720p, per-kernel HIP-event breakdown; leaves JSON under gpurun_out/.
+# Bench only: 720p headline with per-step / per-stage timing.  Usage: gpu_bench.sh [bench args]
 mkdir -p gpurun_out
-python -c "import torch;print(torch.__version__, torch.cuda.get_device_name(0))" > gpurun_out/env.txt 2>&1
-timeout 600 python bench.py --height 240 --width 432 --steps 2 --warmup 1 > gpurun_out/bench_240.json 2> gpurun_out/bench_240.err
-echo "240p exit $?"; tail -c 3000 gpurun_out/bench_240.json; tail -5 gpurun_out/bench_240.err
-timeout 900 python bench.py --steps 1 --warmup 1 --no-cpu-baseline "$@" > gpurun_out/bench_720.json 2> gpurun_out/bench_720.err
-echo "720p exit $?"; tail -c 4000 gpurun_out/bench_720.json; tail -5 gpurun_out/bench_720.err
+timeout 900 python bench.py "$@" > gpurun_out/bench_720.json 2> gpurun_out/bench_720.err
+echo "720p exit $?"; python - <<'PY'
+import json
+d=json.load(open('gpurun_out/bench_720.json'))
+print({k:d.get(k) for k in ('value','ms_per_step','step_ms','host_submit_ms','roofline','stages_ms','cpu_baseline')})
+for k,v in sorted((d.get('kernels') or {}).items(), key=lambda kv:-kv[1]['ms']):
+    print(f"{k:26s} n={v['launches']:6d} ms={v['ms']:9.2f} avg_us={v['avg_us']:8.1f} TF={v['tflops']:8.1f} GB/s={v['gbs']:8.1f}")
+PY
+tail -3 gpurun_out/bench_720.err
