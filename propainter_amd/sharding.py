@@ -1,0 +1,389 @@
+"""Sub-video sharding of one long clip across the GPUs of a node.
+
+The reference processes long clips as overlapping sub-videos whose boundaries are fixed by ``--subvideo_length``
+from frame 0 (inference_propainter.py:341-404) and as sliding generator windows (:410-452).  Those chunk boundaries
+are part of the result, so the shard boundaries coincide with them: rank r owns the frames
+``[r*B, (r+1)*B)`` with ``B = subvideo_length * ceil(n_subvideos / world)`` and executes exactly the chunks / windows
+of the global schedule that start inside its range.  What a chunk needs from outside the owner's range (the +-5 flow
+halo of flow completion, the +-10 frame halo of image propagation, neighbour / reference frames of the generator
+windows, the blend contributions of windows straddling a boundary) is exchanged point-to-point with the owning rank --
+``torch.distributed`` send/recv (RCCL over xGMI on the GPU box, gloo in the CPU tests); there is no all-reduce /
+all-gather on the data path.  The composited frames are bit-identical to the single-GPU pass.
+
+``sharded_clip_steps`` is written as a *generator* that yields ``Exchange`` requests: ``run_clip_sharded`` drives it
+with real point-to-point transfers (one process per GPU), ``run_logical_shards`` drives N logical ranks in one
+process by handing the tensors over directly (single-GPU validation of the sharding logic against the unsharded pass).
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from .pipeline import (InferenceConfig, _dev_index, compute_flows, subvideo_chunks, window_schedule)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# plan
+# ----------------------------------------------------------------------------------------------------------------
+@dataclass
+class ShardPlan:
+    """Frame ownership and per-stage needs of every rank (pure host arithmetic; identical on all ranks)."""
+    L: int
+    cfg: InferenceConfig
+    world: int
+    block: int = 0
+    own: list = field(default_factory=list)            # [(lo, hi)] frames per rank (may be empty: lo == hi)
+
+    def __post_init__(self):
+        S = self.cfg.subvideo_length
+        if self.world > 1:
+            if S > 100:
+                raise ValueError("sharded inference needs subvideo_length <= 100 (image propagation uses min(100, S) chunks, "
+                                 "inference_propainter.py:372)")
+            if self.L - 1 <= S:
+                raise ValueError(f"a {self.L}-frame clip is a single sub-video at subvideo_length={S}: nothing to shard "
+                                 "(use one GPU per clip instead)")
+        nsub = -(-self.L // S)
+        self.block = S * (-(-nsub // self.world))
+        self.own = [(min(self.L, r * self.block), min(self.L, (r + 1) * self.block)) for r in range(self.world)]
+        self.fl = self.L - 1
+        ns = self.cfg.neighbor_length // 2
+        self.windows = []                                # (f, neighbor_ids, ref_ids) of the global schedule
+        sched = window_schedule(self.L, self.cfg.neighbor_length, self.cfg.ref_stride, S)
+        for f, (nb, ref) in zip(range(0, self.L, ns), sched):
+            self.windows.append((f, nb, ref))
+
+    def owner(self, frame):
+        return min(self.world - 1, frame // self.block)
+
+    # ---- index ranges (half-open, clipped); an empty range is (0, 0)
+    def flows_own(self, r):
+        lo, hi = self.own[r]
+        return (lo, min(hi, self.fl)) if lo < min(hi, self.fl) else (0, 0)
+
+    def fc_chunks(self, r):
+        """flow-completion chunks (s, e, pad_s, pad_e) owned by rank r (flow index space, pad 5; :341-364)."""
+        return [c for c in subvideo_chunks(self.fl, self.cfg.subvideo_length, 5) if self.owner(c[0] + c[2]) == r]
+
+    def ip_chunks(self, r):
+        """image-propagation chunks owned by rank r (frame index space, pad 10; :373-398)."""
+        sv = min(100, self.cfg.subvideo_length)
+        return [c for c in subvideo_chunks(self.L, sv, 10) if self.owner(c[0] + c[2]) == r]
+
+    def rank_windows(self, r):
+        return [w for w in self.windows if self.owner(w[0]) == r]
+
+    @staticmethod
+    def _env(ranges):
+        ranges = [x for x in ranges if x[1] > x[0]]
+        return (min(a for a, _ in ranges), max(b for _, b in ranges)) if ranges else (0, 0)
+
+    def need_gt_flows(self, r):
+        return self._env([(s, e) for s, e, _, _ in self.fc_chunks(r)])
+
+    def need_pred_flows(self, r):
+        rs = [(s, e - 1) for s, e, _, _ in self.ip_chunks(r)]
+        rs += [(nb[0], nb[-1]) for _, nb, _ in self.rank_windows(r)]
+        return self._env(rs)
+
+    def need_updated(self, r):
+        return self._env([(min(nb + ref), max(nb + ref) + 1) for _, nb, ref in self.rank_windows(r)])
+
+    def need_raw(self, r):
+        """frames / masks every rank reads from the (host-resident) input: envelope of all of its stage inputs."""
+        lo, hi = self.own[r]
+        if hi <= lo:
+            return (0, 0)
+        rs = [(lo, min(self.L, hi + 1))]                                                   # RAFT: own pairs + 1 frame
+        rs += [(s, e + 1) for s, e, _, _ in self.fc_chunks(r)]                             # flow masks of the FC chunks
+        rs += [(s, e) for s, e, _, _ in self.ip_chunks(r)]
+        rs.append(self.need_updated(r))
+        return self._env(rs)
+
+    def blend_routes(self):
+        """{(src, dst): [(frame, f)]}: composites a rank's windows produce for frames another rank owns, in the
+        order both sides enumerate them (windows by f, frames ascending)."""
+        routes = {}
+        for f, nb, _ in self.windows:
+            src = self.owner(f)
+            for idx in nb:
+                dst = self.owner(idx)
+                if dst != src:
+                    routes.setdefault((src, dst), []).append((idx, f))
+        return routes
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# exchange plumbing
+# ----------------------------------------------------------------------------------------------------------------
+@dataclass
+class Exchange:
+    """One point-to-point exchange step: ``send[q]`` goes to rank q; ``recv[q] = (shape, dtype)`` arrives from rank q.
+    The driver answers with {q: tensor}."""
+    send: dict
+    recv: dict
+    tag: str = ""
+
+
+class Span:
+    """A tensor whose dimension `dim` covers the global index range [g0, g0 + size)."""
+
+    def __init__(self, t, g0, dim=1):
+        self.t, self.g0, self.dim = t, g0, dim
+
+    def sl(self, a, b):
+        return self.t.narrow(self.dim, a - self.g0, b - a)
+
+    def take(self, ids, device):
+        return self.t.index_select(self.dim, _dev_index([i - self.g0 for i in ids], device))
+
+
+def _isect(a, b):
+    lo, hi = max(a[0], b[0]), min(a[1], b[1])
+    return (lo, hi) if hi > lo else None
+
+
+def _halo(x, own, needs, rank, dim, tag):
+    """Sub-generator: `x` covers own[rank] along `dim`; returns a Span covering needs[rank].  Every rank sends the part
+    of its own range that another rank needs and receives the parts of its need that others own."""
+    world = len(own)
+    send, recv = {}, {}
+    for q in range(world):
+        if q == rank:
+            continue
+        s = _isect(own[rank], needs[q])
+        if s is not None:
+            send[q] = x.narrow(dim, s[0] - own[rank][0], s[1] - s[0]).contiguous()
+        r = _isect(own[q], needs[rank])
+        if r is not None:
+            shape = list(x.shape)
+            shape[dim] = r[1] - r[0]
+            recv[q] = (tuple(shape), x.dtype)
+    got = yield Exchange(send, recv, tag)
+    need = needs[rank]
+    if need[1] <= need[0]:
+        return Span(x.narrow(dim, 0, 0), 0, dim)
+    pieces = []
+    for q in range(world):
+        r = _isect(own[q], need)
+        if r is None:
+            continue
+        pieces.append(x.narrow(dim, r[0] - own[rank][0], r[1] - r[0]) if q == rank else got[q])
+    return Span(pieces[0] if len(pieces) == 1 else torch.cat(pieces, dim), need[0], dim)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# the sharded pass
+# ----------------------------------------------------------------------------------------------------------------
+@torch.no_grad()
+def sharded_clip_steps(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg: InferenceConfig, device, rank, world):
+    """Generator: rank `rank`'s part of the pass over one clip.  Inputs are the WHOLE clip (uint8 frames [L,H,W,3],
+    masks [L,H,W] {0,255}; numpy or tensors, normally host-resident -- every rank reads its slice, no exchange of raw
+    input).  Yields ``Exchange`` requests; returns ``(lo, comp_u8[hi-lo,H,W,3])``, the rank's composited frames."""
+    fix_raft, fix_flow_complete, model = models
+    L = len(frames_u8)
+    plan = ShardPlan(L, cfg, world)
+    lo, hi = plan.own[rank]
+    active = hi > lo
+    ranks = range(world)
+    to_t = lambda a: a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))
+    H, W = frames_u8.shape[1], frames_u8.shape[2]
+    dt_stage = torch.float16 if cfg.fp16 else torch.float32
+
+    # ---- raw inputs of this rank (global range [r0, r1))
+    r0, r1 = plan.need_raw(rank)
+    fr_u8 = to_t(frames_u8[r0:r1]).to(device)
+    frames = Span(fr_u8.permute(0, 3, 1, 2).float().div(255)[None] * 2 - 1, r0)             # [1,n,3,H,W] in [-1,1]
+    flow_masks = Span(to_t(flow_masks_u8[r0:r1]).to(device).float().div(255)[None, :, None], r0)
+    masks_dilated = Span(to_t(masks_dilated_u8[r0:r1]).to(device).float().div(255)[None, :, None], r0)
+
+    # ---- stage A: RAFT on the own pairs (needs frame `hi` of the right neighbour: raw input)
+    fo = [plan.flows_own(q) for q in ranks]
+    if fo[rank][1] > fo[rank][0]:
+        ff, fb = compute_flows(fix_raft, frames.sl(fo[rank][0], fo[rank][1] + 1), cfg.raft_iter)
+        gt = torch.stack([ff, fb], 0)                                                        # [2,1,n,2,H,W]
+    else:
+        gt = torch.zeros((2, 1, 0, 2, H, W), dtype=torch.float32, device=device)
+    if cfg.fp16:                                                                             # (:333-337)
+        frames.t, flow_masks.t, masks_dilated.t = frames.t.half(), flow_masks.t.half(), masks_dilated.t.half()
+        gt = gt.half()
+    gt = yield from _halo(gt, fo, [plan.need_gt_flows(q) for q in ranks], rank, 2, "gt_flows")
+
+    # ---- stage B: flow completion on the own chunks (+-5 flow halo)
+    pf, pb = [], []
+    for s, e, ps, pe in plan.fc_chunks(rank):
+        sub = (gt.sl(s, e)[0], gt.sl(s, e)[1])
+        fm = flow_masks.sl(s, e + 1)
+        pred, _ = fix_flow_complete.forward_bidirect_flow(sub, fm)
+        pred = fix_flow_complete.combine_flow(sub, pred, fm)
+        pf.append(pred[0][:, ps:e - s - pe])
+        pb.append(pred[1][:, ps:e - s - pe])
+    if pf:
+        pred_own = torch.stack([torch.cat(pf, 1), torch.cat(pb, 1)], 0)
+    else:
+        pred_own = torch.zeros((2, 1, 0, 2, H, W), dtype=dt_stage, device=device)
+    pred = yield from _halo(pred_own, fo, [plan.need_pred_flows(q) for q in ranks], rank, 2, "pred_flows")
+
+    # ---- stage C: image propagation on the own chunks (+-10 frame halo of completed flows; frames/masks are raw)
+    uf, um = [], []
+    for s, e, ps, pe in plan.ip_chunks(rank):
+        fr, md = frames.sl(s, e), masks_dilated.sl(s, e)
+        sub_flows = (pred.sl(s, e - 1)[0], pred.sl(s, e - 1)[1])
+        prop, upd_m = model.img_propagation(fr * (1 - md), sub_flows, md, 'nearest')
+        upd_f = fr * (1 - md) + prop * md
+        uf.append(upd_f[:, ps:e - s - pe])
+        um.append(upd_m[:, ps:e - s - pe])
+    if uf:
+        upd_own = torch.cat([torch.cat(uf, 1), torch.cat(um, 1)], 2)                         # [1,n,4,H,W]: frame | mask
+    else:
+        upd_own = torch.zeros((1, 0, 4, H, W), dtype=dt_stage, device=device)
+    upd = yield from _halo(upd_own, plan.own, [plan.need_updated(q) for q in ranks], rank, 1, "updated_frames")
+
+    # ---- stage D: the own generator windows; composites of frames owned elsewhere go to their owner afterwards
+    routes = plan.blend_routes()
+    foreign_f = {}                                                   # own frame -> window ids f of foreign contributions
+    for (src, dst), items in routes.items():
+        if dst == rank:
+            for idx, f in items:
+                foreign_f.setdefault(idx, []).append(f)
+    comp = torch.zeros((max(0, hi - lo), H, W, 3), dtype=torch.uint8, device=device)
+    done = [False] * max(0, hi - lo)
+    deferred = {}                                                    # own frame with foreign contributions -> [(f, cur)]
+    outbox = {}                                                      # dst rank -> [cur] in route order
+    enc_all, enc_pos = None, {}
+    my_windows = plan.rank_windows(rank)
+    if my_windows and hasattr(model, "encode_frames"):
+        # encoder features once per frame this rank's windows actually touch (own frames + the strided references)
+        used = sorted({i for _, nb, ref in my_windows for i in nb + ref})
+        enc_pos = {g: k for k, g in enumerate(used)}
+        uu = upd.take(used, device)
+        enc_all = model.encode_frames(uu[:, :, :3].contiguous(), masks_dilated.take(used, device), uu[:, :, 3:4].contiguous())
+
+    def blend(idx, cur):
+        k = idx - lo
+        if done[k]:
+            cur = (comp[k].float() * 0.5 + cur.float() * 0.5).to(torch.uint8)
+        comp[k] = cur
+        done[k] = True
+
+    for f, nb, ref in my_windows:
+        ids = nb + ref
+        u = upd.take(ids, device)
+        kw = {} if enc_all is None else {"enc_feat": enc_all.index_select(0, _dev_index([enc_pos[i] for i in ids], device))}
+        fl = pred.sl(nb[0], nb[-1])
+        out = model(u[:, :, :3].contiguous(), (fl[0], fl[1]), masks_dilated.take(ids, device), u[:, :, 3:4].contiguous(),
+                    len(nb), **kw)
+        img = (((out[0].float() + 1) / 2).permute(0, 2, 3, 1) * 255).to(torch.uint8)          # (:435-442)
+        for i, idx in enumerate(nb):
+            m = masks_dilated.sl(idx, idx + 1)[0, 0].permute(1, 2, 0).to(torch.uint8)
+            ori = fr_u8[idx - r0]
+            cur = img[i] * m + ori * (1 - m)
+            dst = plan.owner(idx)
+            if dst != rank:
+                outbox.setdefault(dst, []).append(cur)
+            elif idx in foreign_f:
+                deferred.setdefault(idx, []).append((f, cur))
+            else:
+                blend(idx, cur)
+    send = {q: torch.stack(v, 0) for q, v in outbox.items()}
+    recv = {src: ((len(items), H, W, 3), torch.uint8) for (src, dst), items in routes.items() if dst == rank}
+    got = yield Exchange(send, recv, "blend")
+    for (src, dst), items in routes.items():
+        if dst == rank:
+            for k, (idx, f) in enumerate(items):
+                deferred.setdefault(idx, []).append((f, got[src][k]))
+    for idx in sorted(deferred):                                     # ordered 0.5/0.5 blend: increasing window position f
+        for f, cur in sorted(deferred[idx], key=lambda fc: fc[0]):
+            blend(idx, cur)
+    return lo, comp
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# drivers
+# ----------------------------------------------------------------------------------------------------------------
+def _dist_exchange(ex, device, group=None):
+    """Answers one Exchange with torch.distributed point-to-point ops (RCCL send/recv between the two GPUs' xGMI link;
+    gloo stages through host memory)."""
+    import torch.distributed as dist
+    via_host = dist.get_backend(group) == "gloo"
+    bufs, ops, keep = {}, [], []
+    for q, (shape, dtype) in sorted(ex.recv.items()):
+        bufs[q] = torch.empty(shape, dtype=dtype, device="cpu" if via_host else device)
+        ops.append(dist.P2POp(dist.irecv, bufs[q], q, group))
+    for q, t in sorted(ex.send.items()):
+        t = t.cpu() if via_host else t.contiguous()
+        keep.append(t)
+        ops.append(dist.P2POp(dist.isend, t, q, group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return {q: b.to(device) for q, b in bufs.items()}
+
+
+def run_clip_sharded(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg, device, group=None):
+    """One process per GPU: this rank's part of the clip.  Returns (lo, comp_u8) -- frames [lo, lo+len) of the result."""
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    gen = sharded_clip_steps(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg, device, rank, world)
+    try:
+        ex = next(gen)
+        while True:
+            ex = gen.send(_dist_exchange(ex, device, group))
+    except StopIteration as stop:
+        return stop.value
+
+
+def gather_frames(lo, comp, total, dst=0, group=None):
+    """Collects the ranks' composited frames on rank `dst` (uint8 [total,H,W,3] there, None elsewhere)."""
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    meta = [None] * world
+    dist.all_gather_object(meta, (lo, comp.shape[0]), group=group)
+    via_host = dist.get_backend(group) == "gloo"
+    if rank != dst:
+        if comp.shape[0]:
+            dist.send(comp.cpu() if via_host else comp.contiguous(), dst, group=group)
+        return None
+    out = torch.empty((total,) + tuple(comp.shape[1:]), dtype=comp.dtype, device=comp.device)
+    for q, (qlo, n) in enumerate(meta):
+        if n == 0:
+            continue
+        if q == rank:
+            out[qlo:qlo + n] = comp
+        else:
+            buf = torch.empty((n,) + tuple(comp.shape[1:]), dtype=comp.dtype, device="cpu" if via_host else comp.device)
+            dist.recv(buf, q, group=group)
+            out[qlo:qlo + n] = buf.to(comp.device)
+    return out
+
+
+def run_logical_shards(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg, device, world):
+    """Runs `world` logical ranks in ONE process (e.g. on one GPU), handing exchanged tensors over directly.  Used to
+    validate the sharded pass against ``run_clip`` where only one device is available.  Returns uint8 [L,H,W,3]."""
+    gens = [sharded_clip_steps(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg, device, r, world) for r in range(world)]
+    reqs, results = [None] * world, [None] * world
+    for r, g in enumerate(gens):
+        reqs[r] = next(g)
+    while any(r is not None for r in reqs):
+        nxt = [None] * world
+        for r, g in enumerate(gens):
+            if reqs[r] is None:
+                continue
+            got = {}
+            for q, (shape, dtype) in reqs[r].recv.items():
+                t = reqs[q].send[r]
+                assert tuple(t.shape) == tuple(shape) and t.dtype == dtype, (reqs[r].tag, r, q, t.shape, shape)
+                got[q] = t
+            try:
+                nxt[r] = g.send(got)
+            except StopIteration as stop:
+                results[r] = stop.value
+        # every rank must be at the same exchange (SPMD)
+        tags = {x.tag for x in nxt if x is not None}
+        assert len(tags) <= 1, tags
+        reqs = nxt
+    L = len(frames_u8)
+    out = torch.zeros((L,) + tuple(results[0][1].shape[1:]), dtype=torch.uint8, device=device)
+    for lo, comp in results:
+        out[lo:lo + comp.shape[0]] = comp
+    return out

@@ -157,3 +157,23 @@ def test_clip_graph_replay_is_bit_identical_to_eager(models, fp16):
         out = cg(clip, g["masks_u8"], g["masks_u8"])
         torch.cuda.synchronize()
         assert torch.equal(out, eager), f"graph replay differs from eager in {(out != eager).float().mean().item():.3e} of bytes"
+
+
+@pytest.mark.parametrize("fp16", [False, True], ids=["f32", "f16"])
+def test_logical_shards_on_one_gpu_match_the_unsharded_pass(models, fp16):
+    """Sub-video sharding with the REAL engines: 3 logical ranks on one GPU (exchanges handed over in-process, the
+    same generator the RCCL driver runs) must reproduce run_clip bit for bit -- every kernel is batch-invariant."""
+    from propainter_amd.pipeline import InferenceConfig, run_clip
+    from propainter_amd.sharding import run_logical_shards
+    from propainter_amd.synthetic import synthetic_clip, synthetic_mask
+    import scipy.ndimage
+    L, H, W = 26, 128, 192
+    clip = synthetic_clip(L, H, W, seed=9)
+    m = scipy.ndimage.binary_dilation(synthetic_mask(H, W), iterations=4).astype(np.uint8) * 255
+    masks = np.repeat(m[None], L, 0)
+    dev = torch.device("cuda")
+    cfg = InferenceConfig(raft_iter=3, subvideo_length=10, neighbor_length=4, ref_stride=3, fp16=fp16)
+    ref = run_clip(models, clip, masks, masks, cfg, dev)
+    out = run_logical_shards(models, clip, masks, masks, cfg, dev, 3)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref), f"sharded pass differs in {(out != ref).float().mean().item():.3e} of bytes"

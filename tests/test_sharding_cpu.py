@@ -1,0 +1,170 @@
+"""Sub-video sharding (propainter_amd/sharding.py) on the CPU: the shard plan, the exchange protocol and the ordered
+blend are validated with cheap stand-in models whose temporal footprint mimics the real ones (pairwise flow, whole-chunk
+recurrences, windows that read every neighbour / reference frame), so any difference in chunking, halo contents or
+blend order changes the bytes.  The sharded result must be bit-identical to ``run_clip``.  The N > 1 path runs over
+``gloo`` with world_size 2 (one process per rank, as on the GPU box over RCCL)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from propainter_amd.pipeline import InferenceConfig, run_clip
+from propainter_amd.sharding import ShardPlan, gather_frames, run_clip_sharded, run_logical_shards
+from propainter_amd.synthetic import synthetic_clip
+
+
+class FakeRaft:
+    batch_invariant = True
+
+    def __call__(self, frames, iters=20):
+        a, b = frames[:, :-1], frames[:, 1:]
+        d = (b - a).mean(2, keepdim=True)
+        ff = torch.cat([d * 3 + 0.1 * a[:, :, :1], -d * 2 + 0.05 * b[:, :, 1:2]], 2)
+        fb = torch.cat([-d * 3 + 0.1 * b[:, :, :1], d * 2 - 0.05 * a[:, :, 2:3]], 2)
+        return ff * iters / 20.0, fb * iters / 20.0
+
+
+class FakeFC:
+    """Completed flow = value depending on the WHOLE chunk through a forward and a backward recurrence."""
+
+    def forward_bidirect_flow(self, flows_bi, masks):
+        out = []
+        for k, fl in enumerate(flows_bi):
+            m = masks[:, :-1] if k == 0 else masks[:, 1:]
+            x = fl * (1 - m)
+            acc_f, acc_b = torch.zeros_like(x), torch.zeros_like(x)
+            run = torch.zeros_like(x[:, 0])
+            for t in range(x.shape[1]):
+                run = 0.7 * run + x[:, t]
+                acc_f[:, t] = run
+            run = torch.zeros_like(x[:, 0])
+            for t in range(x.shape[1] - 1, -1, -1):
+                run = 0.6 * run + x[:, t]
+                acc_b[:, t] = run
+            out.append(0.5 * acc_f + 0.25 * acc_b)
+        return out, [None, None]
+
+    def combine_flow(self, flows_bi, pred_bi, masks):
+        mf, mb = masks[:, :-1], masks[:, 1:]
+        return pred_bi[0] * mf + flows_bi[0] * (1 - mf), pred_bi[1] * mb + flows_bi[1] * (1 - mb)
+
+
+class FakeGenerator:
+    def img_propagation(self, masked_frames, flows, masks, interpolation='nearest'):
+        x, m = masked_frames.clone(), masks.clone()
+        t = x.shape[1]
+        for i in range(t - 2, -1, -1):                       # backward pass, then forward pass on its outputs
+            w = torch.sigmoid(flows[0][:, i, :1])
+            x[:, i] = x[:, i] * (1 - m[:, i]) + m[:, i] * (w * x[:, i + 1] + (1 - w) * x[:, i])
+            m[:, i] = m[:, i] * m[:, i + 1]
+        for i in range(1, t):
+            w = torch.sigmoid(flows[1][:, i - 1, 1:2])
+            x[:, i] = x[:, i] * (1 - m[:, i]) + m[:, i] * (w * x[:, i - 1] + (1 - w) * x[:, i])
+            m[:, i] = m[:, i] * m[:, i - 1]
+        return x, m
+
+    def __call__(self, frames, flows, masks_in, masks_updated, l_t, interpolation='bilinear', t_dilation=2):
+        ctx = (frames * (1 - 0.5 * masks_updated)).mean(1, keepdim=True)           # every neighbour + reference frame
+        fl = flows[0].abs().mean((1, 2), keepdim=True) - flows[1].abs().mean((1, 2), keepdim=True)
+        pos = torch.linspace(-0.3, 0.3, frames.shape[1]).view(1, -1, 1, 1, 1)
+        out = torch.tanh(0.6 * frames + 0.4 * ctx + 0.05 * fl + pos * masks_in)
+        return out[:, :l_t]
+
+
+def _inputs(L, H=24, W=32, seed=5):
+    clip = synthetic_clip(L, H, W, seed=seed)
+    m = np.zeros((L, H, W), dtype=np.uint8)
+    m[:, H // 3: 2 * H // 3, W // 4: 3 * W // 4] = 255
+    return clip, m
+
+
+MODELS = (FakeRaft(), FakeFC(), FakeGenerator())
+CASES = [
+    # L, subvideo, neighbor_length, ref_stride, world
+    (50, 20, 10, 10, 2),
+    (50, 20, 10, 10, 3),
+    (47, 10, 6, 4, 4),
+    (33, 16, 10, 5, 2),
+    (64, 20, 10, 10, 8),      # more ranks than sub-videos per block: some ranks own one sub-video, the last ones none
+]
+
+
+@pytest.mark.parametrize("L,S,nl,rs,world", CASES)
+def test_logical_shards_are_bit_identical_to_the_unsharded_pass(L, S, nl, rs, world):
+    clip, m = _inputs(L)
+    dev = torch.device("cpu")
+    for fp16 in (False,):
+        cfg = InferenceConfig(raft_iter=20, subvideo_length=S, neighbor_length=nl, ref_stride=rs, fp16=fp16)
+        ref = run_clip(MODELS, clip, m, m, cfg, dev)
+        out = run_logical_shards(MODELS, clip, m, m, cfg, dev, world)
+        assert out.dtype == torch.uint8 and out.shape == ref.shape
+        assert torch.equal(out, ref), f"{(out != ref).float().mean().item():.3e} of bytes differ"
+
+
+def test_single_rank_shard_equals_run_clip_without_chunking():
+    clip, m = _inputs(18)
+    cfg = InferenceConfig(raft_iter=20, subvideo_length=80, neighbor_length=10, ref_stride=10)
+    dev = torch.device("cpu")
+    assert torch.equal(run_logical_shards(MODELS, clip, m, m, cfg, dev, 1), run_clip(MODELS, clip, m, m, cfg, dev))
+
+
+def test_shard_plan_properties():
+    cfg = InferenceConfig(subvideo_length=80, neighbor_length=10, ref_stride=10)
+    plan = ShardPlan(320, cfg, 4)                            # BASELINE config 4: 320 frames on 4 GPUs
+    assert plan.own == [(0, 80), (80, 160), (160, 240), (240, 320)]
+    for r in range(4):
+        lo, hi = plan.own[r]
+        assert all(lo <= f < hi for f, _, _ in plan.rank_windows(r))
+        glo, ghi = plan.need_gt_flows(r)
+        assert glo == max(0, lo - 5) and ghi == min(319, hi + 5)
+        ulo, uhi = plan.need_updated(r)
+        assert ulo >= max(0, lo - 45) and uhi <= min(320, hi + 45)
+    routes = plan.blend_routes()
+    assert set(routes) == {(0, 1), (1, 0), (1, 2), (2, 1), (2, 3), (3, 2)}
+    assert routes[(1, 0)] == [(75 + i, 80) for i in range(5)] and routes[(0, 1)] == [(80, 75)]
+    plan8 = ShardPlan(160, InferenceConfig(subvideo_length=20), 8)                 # BASELINE config 5
+    assert plan8.own[0] == (0, 20) and plan8.own[7] == (140, 160)
+    with pytest.raises(ValueError):
+        ShardPlan(80, cfg, 2)                                # one sub-video: nothing to shard
+    with pytest.raises(ValueError):
+        ShardPlan(400, InferenceConfig(subvideo_length=120), 2)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, L, S, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        clip, m = _inputs(L)
+        cfg = InferenceConfig(raft_iter=20, subvideo_length=S, neighbor_length=10, ref_stride=10)
+        lo, comp = run_clip_sharded(MODELS, clip, m, m, cfg, torch.device("cpu"))
+        full = gather_frames(lo, comp, L, dst=0)
+        if rank == 0:
+            ref = run_clip(MODELS, clip, m, m, cfg, torch.device("cpu"))
+            q.put((bool(torch.equal(full, ref)), int(lo), int(comp.shape[0])))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_over_gloo_match_the_unsharded_pass():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 50, 20, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok, lo, n = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok and lo == 0 and n == 40          # 3 sub-videos of 20 on 2 ranks: blocks of 40 frames

@@ -20,6 +20,8 @@ from propainter_amd.conv import ConvLayer  # noqa: E402
 
 SHAPES = [
     # name, N, H, W, cin list, cout, k, stride, pad, groups
+    ("big_gru_zr_1x5_n36", 36, 90, 160, [128, 256], 256, (1, 5), 1, (0, 2), 1),
+    ("big_gru_q_5x1_n36", 36, 90, 160, [128, 256], 128, (5, 1), 1, (2, 0), 1),
     ("raft_gru_zr_1x5", 8, 90, 160, [128, 256], 256, (1, 5), 1, (0, 2), 1),
     ("raft_gru_q_5x1", 8, 90, 160, [128, 256], 128, (5, 1), 1, (2, 0), 1),
     ("raft_convc1_1x1", 8, 90, 160, [324], 256, (1, 1), 1, 0, 1),
