@@ -1,0 +1,139 @@
+#!/usr/bin/env python
+"""ProPainter inference on MI355X -- drop-in for the reference's ``inference_propainter.py`` command line
+(flag names, defaults and the ``results/<video_name>/`` layout follow inference_propainter.py:181-217,233,453-472).
+
+    python inference_propainter.py -i inputs/object_removal/bmx-trees -m inputs/object_removal/bmx-trees_mask --fp16
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 inference_propainter.py -i long_clip ...
+
+The device path (RAFT, flow completion, image propagation, sliding-window generator, uint8 composite) runs on the
+HIP engine (libpropainter_hip.so); with several processes (one per GPU) a long clip is sharded by sub-video
+(propainter_amd/sharding.py).  Extra flags that the reference does not have: ``--weights_dir``, ``--seeded_weights``
+(no checkpoints ship with either repository), ``--raft_fp32``.
+"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    p.add_argument('-i', '--video', type=str, default='inputs/object_removal/bmx-trees', help='Path of the input video or image folder.')
+    p.add_argument('-m', '--mask', type=str, default='inputs/object_removal/bmx-trees_mask', help='Path of the mask(s) or mask folder.')
+    p.add_argument('-o', '--output', type=str, default='results', help='Output folder. Default: results')
+    p.add_argument("--resize_ratio", type=float, default=1.0, help='Resize scale for processing video.')
+    p.add_argument('--height', type=int, default=-1, help='Height of the processing video.')
+    p.add_argument('--width', type=int, default=-1, help='Width of the processing video.')
+    p.add_argument('--mask_dilation', type=int, default=4, help='Mask dilation for video and flow masking.')
+    p.add_argument("--ref_stride", type=int, default=10, help='Stride of global reference frames.')
+    p.add_argument("--neighbor_length", type=int, default=10, help='Length of local neighboring frames.')
+    p.add_argument("--subvideo_length", type=int, default=80, help='Length of sub-video for long video inference.')
+    p.add_argument("--raft_iter", type=int, default=20, help='Iterations for RAFT inference.')
+    p.add_argument('--mode', default='video_inpainting', choices=['video_inpainting', 'video_outpainting'],
+                   help="Modes: video_inpainting / video_outpainting")
+    p.add_argument('--scale_h', type=float, default=1.0, help='Outpainting scale of height for video_outpainting mode.')
+    p.add_argument('--scale_w', type=float, default=1.2, help='Outpainting scale of width for video_outpainting mode.')
+    p.add_argument('--save_fps', type=int, default=24, help='Frame per second. Default: 24')
+    p.add_argument('--save_frames', action='store_true', help='Save output frames. Default: False')
+    p.add_argument('--fp16', action='store_true', help='Use fp16 (half precision) during inference. Default: fp32 (single precision).')
+    # ---- not in the reference
+    p.add_argument('--weights_dir', type=str, default='weights', help='Folder holding raft-things.pth, recurrent_flow_completion.pth, ProPainter.pth.')
+    p.add_argument('--seeded_weights', action='store_true', help='Run with the deterministic seeded weights (no checkpoints available offline).')
+    p.add_argument('--raft_fp32', action='store_true', help='Keep the RAFT convolutions in fp32 like the reference (default with --fp16: fp16 MFMA, fp32 accumulate).')
+    return p
+
+
+def load_models(args, device):
+    import torch
+    from propainter_amd.model.modules.flow_comp_raft import RAFT_bi
+    from propainter_amd.model.propainter import InpaintGenerator
+    from propainter_amd.model.recurrent_flow_completion import RecurrentFlowCompleteNet
+    raft_dt = torch.float16 if (args.fp16 and not args.raft_fp32) else None
+    if args.seeded_weights:
+        from propainter_amd.synthetic import seeded_models
+        return seeded_models(device, raft_dtype=raft_dt)
+    paths = {n: os.path.join(args.weights_dir, n) for n in ('raft-things.pth', 'recurrent_flow_completion.pth', 'ProPainter.pth')}
+    missing = [p for p in paths.values() if not os.path.exists(p)]
+    if missing:
+        raise SystemExit(f"missing checkpoints {missing}: place the released .pth files in {args.weights_dir}/ "
+                         "(the reference downloads them from its GitHub release) or pass --seeded_weights")
+    fix_raft = RAFT_bi(paths['raft-things.pth'], device, compute_dtype=raft_dt)
+    fix_flow_complete = RecurrentFlowCompleteNet(paths['recurrent_flow_completion.pth'])
+    for p in fix_flow_complete.parameters():
+        p.requires_grad = False
+    fix_flow_complete.to(device).eval()
+    model = InpaintGenerator(model_path=paths['ProPainter.pth']).to(device).eval()
+    if args.fp16:                                            # (:333-337)
+        fix_flow_complete, model = fix_flow_complete.half(), model.half()
+    return fix_raft, fix_flow_complete, model
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    import numpy as np
+    import torch
+    from propainter_amd import hip, video_io
+    from propainter_amd.pipeline import InferenceConfig, run_clip
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("inference_propainter.py runs on the HIP engine only: no GPU visible (the CPU path is the oracle, "
+                         "oracle/propainter_oracle.py, and is test infrastructure)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    hip.lib()
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    frames, fps, size, video_name = video_io.read_frames(args.video)
+    if args.width != -1 and args.height != -1:
+        size = (args.width, args.height)
+    if args.resize_ratio != 1.0:
+        size = (int(args.resize_ratio * size[0]), int(args.resize_ratio * size[1]))
+    frames, size, out_size = video_io.resize_frames(frames, size)
+    fps = args.save_fps if fps is None else fps
+    save_root = os.path.join(args.output, video_name)
+    if args.mode == 'video_inpainting':
+        flow_masks, masks_dilated = video_io.read_masks(args.mask, len(frames), size, flow_mask_dilates=args.mask_dilation,
+                                                        mask_dilates=args.mask_dilation)
+    else:
+        frames, flow_masks, masks_dilated, size = video_io.extrapolation(frames, (args.scale_h, args.scale_w))
+    frames_u8 = np.stack([np.asarray(f, dtype=np.uint8) for f in frames])
+    flow_masks = np.stack(flow_masks)
+    masks_dilated = np.stack(masks_dilated)
+    L = len(frames_u8)
+
+    models = load_models(args, device)
+    cfg = InferenceConfig(raft_iter=args.raft_iter, subvideo_length=args.subvideo_length, neighbor_length=args.neighbor_length,
+                          ref_stride=args.ref_stride, fp16=bool(args.fp16))
+    if rank == 0:
+        print(f'\nProcessing: {video_name} [{L} frames]...')
+    t0 = time.perf_counter()
+    if world > 1:
+        from propainter_amd.sharding import gather_frames, run_clip_sharded
+        lo, part = run_clip_sharded(models, frames_u8, flow_masks, masks_dilated, cfg, device)
+        comp = gather_frames(lo, part, L, dst=0)
+    else:
+        comp = run_clip(models, frames_u8, flow_masks, masks_dilated, cfg, device)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        comp = comp.cpu().numpy()
+        print(f'{L} frames in {dt:.2f} s ({L / dt:.2f} frames/s on {world} GPU(s))')
+        video_io.save_results(save_root, list(comp), video_io.masked_preview(frames_u8, masks_dilated), out_size, fps,
+                              args.save_frames)
+        print(f'\nAll results are saved in {save_root}')
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,140 @@
+"""Host-side pre/post-processing of the CLI (what inference_propainter.py:34-156,219-264,453-472 of the reference does
+around the device path): frame / mask reading, resize to multiples of 8, mask dilation, outpainting canvases, result
+writing.  PIL + numpy + scipy only -- cv2, imageio and torchvision.io are optional and probed at run time."""
+import os
+
+import numpy as np
+import scipy.ndimage
+from PIL import Image
+
+VIDEO_EXT = ('mp4', 'mov', 'avi', 'MP4', 'MOV', 'AVI')
+IMAGE_EXT = ('jpg', 'jpeg', 'png', 'JPG', 'JPEG', 'PNG')
+
+
+def resize_frames(frames, size=None):
+    """frames: list of PIL images; size (w, h) or None.  Processing size = size rounded down to multiples of 8
+    (inference_propainter.py:37-48).  Returns (frames, process_size, out_size)."""
+    out_size = tuple(size) if size is not None else frames[0].size
+    process_size = (out_size[0] - out_size[0] % 8, out_size[1] - out_size[1] % 8)
+    if size is not None or out_size != process_size:
+        frames = [f.resize(process_size) for f in frames]
+    return frames, process_size, out_size
+
+
+def read_frames(path):
+    """Image folder or video file -> (list of RGB PIL images, fps or None, (w, h), name) (:52-71)."""
+    if path.endswith(VIDEO_EXT):
+        name = os.path.basename(path)[:-4]
+        try:
+            import imageio.v2 as imageio
+            rd = imageio.get_reader(path)
+            fps = rd.get_meta_data().get('fps')
+            frames = [Image.fromarray(np.asarray(f)[..., :3]) for f in rd]
+        except ImportError:
+            try:
+                import torchvision
+                v, _, info = torchvision.io.read_video(filename=path, pts_unit='sec')
+                frames, fps = [Image.fromarray(f) for f in v.numpy()], info['video_fps']
+            except ImportError as e:
+                raise RuntimeError("reading video files needs imageio(+ffmpeg) or torchvision.io; neither is installed -- "
+                                   "pass a folder of frames instead") from e
+    else:
+        name = os.path.basename(os.path.normpath(path))
+        files = sorted(f for f in os.listdir(path) if f.endswith(IMAGE_EXT))
+        frames = [Image.open(os.path.join(path, f)).convert('RGB') for f in files]
+        fps = None
+    if not frames:
+        raise RuntimeError(f"no frames found in {path}")
+    return frames, fps, frames[0].size, name
+
+
+def read_masks(path, length, size, flow_mask_dilates=8, mask_dilates=5):
+    """Single mask image or folder of per-frame masks -> (flow_masks, masks_dilated): lists of uint8 {0,255} arrays
+    [h,w] (:81-115: nearest resize, grey conversion, scipy binary dilation, or the 0.1 threshold when dilation is 0)."""
+    if path.endswith(IMAGE_EXT):
+        imgs = [Image.open(path)]
+    else:
+        imgs = [Image.open(os.path.join(path, f)) for f in sorted(os.listdir(path)) if f.endswith(IMAGE_EXT)]
+
+    def dil(a, it):
+        if it > 0:
+            return scipy.ndimage.binary_dilation(a, iterations=it).astype(np.uint8) * 255
+        return (a > 0.1).astype(np.uint8) * 255          # binary_mask(th=0.1) on a uint8 image == non-zero
+
+    flow_masks, masks_dilated = [], []
+    for im in imgs:
+        if size is not None:
+            im = im.resize(size, Image.NEAREST)
+        a = np.array(im.convert('L'))
+        flow_masks.append(dil(a, flow_mask_dilates))
+        masks_dilated.append(dil(a, mask_dilates))
+    if len(imgs) == 1:
+        flow_masks, masks_dilated = flow_masks * length, masks_dilated * length
+    if len(flow_masks) < length:
+        raise RuntimeError(f"{len(flow_masks)} masks for {length} frames")
+    return flow_masks[:length], masks_dilated[:length]
+
+
+def extrapolation(frames, scale):
+    """Outpainting canvas (:118-156): frames centred in a (scale_h, scale_w) larger field of view (multiples of 8);
+    flow mask keeps a 4-px rim of known pixels out when the border is wider than 10 px."""
+    n = len(frames)
+    w, h = frames[0].size
+    H = int(scale[0] * h); W = int(scale[1] * w)
+    H -= H % 8; W -= W % 8
+    y0, x0 = int((H - h) / 2), int((W - w) / 2)
+    out = []
+    for f in frames:
+        c = np.zeros((H, W, 3), dtype=np.uint8)
+        c[y0:y0 + h, x0:x0 + w] = np.asarray(f)
+        out.append(Image.fromarray(c))
+    dh, dw = (4 if y0 > 10 else 0), (4 if x0 > 10 else 0)
+    fm = np.ones((H, W), dtype=np.uint8)
+    fm[y0 + dh:y0 + h - dh, x0 + dw:x0 + w - dw] = 0
+    md = np.ones((H, W), dtype=np.uint8)
+    md[y0:y0 + h, x0:x0 + w] = 0
+    return out, [fm * 255] * n, [md * 255] * n, (W, H)
+
+
+def masked_preview(frames_u8, masks_dilated, alpha=0.6):
+    """Green overlay of the masked region (:247-258)."""
+    out = []
+    for f, m in zip(frames_u8, masks_dilated):
+        mk = (m[..., None] / 255.0)
+        green = np.zeros_like(f, dtype=np.float64); green[..., 1] = 255
+        fuse = (1 - alpha) * f + alpha * green
+        out.append((mk * fuse + (1 - mk) * f).astype(np.uint8))
+    return out
+
+
+def _resize_u8(a, size, resample):
+    return np.asarray(Image.fromarray(a).resize(size, resample)) if (a.shape[1], a.shape[0]) != tuple(size) else a
+
+
+def save_results(save_root, comp_frames, masked_frames, out_size, fps, save_frames):
+    """results/<name>/{masked_in.mp4, inpaint_out.mp4, frames/%04d.png} (:453-472).  Without imageio/ffmpeg the videos
+    cannot be encoded: the frames are written as PNG folders instead (and the caller is told)."""
+    os.makedirs(save_root, exist_ok=True)
+    wrote = []
+    if save_frames:
+        d = os.path.join(save_root, 'frames')
+        os.makedirs(d, exist_ok=True)
+        for i, f in enumerate(comp_frames):
+            Image.fromarray(_resize_u8(f, out_size, Image.BICUBIC)).save(os.path.join(d, f"{i:04d}.png"))
+        wrote.append(d)
+    masked = [_resize_u8(f, out_size, Image.BILINEAR) for f in masked_frames]
+    comp = [_resize_u8(f, out_size, Image.BILINEAR) for f in comp_frames]
+    try:
+        import imageio.v2 as imageio
+        imageio.mimwrite(os.path.join(save_root, 'masked_in.mp4'), masked, fps=fps, quality=7)
+        imageio.mimwrite(os.path.join(save_root, 'inpaint_out.mp4'), comp, fps=fps, quality=7)
+        wrote += [os.path.join(save_root, 'masked_in.mp4'), os.path.join(save_root, 'inpaint_out.mp4')]
+    except Exception as e:   # no imageio / no ffmpeg in this image
+        for name, seq in (('masked_in', masked), ('inpaint_out', comp)):
+            d = os.path.join(save_root, name)
+            os.makedirs(d, exist_ok=True)
+            for i, f in enumerate(seq):
+                Image.fromarray(f).save(os.path.join(d, f"{i:04d}.png"))
+            wrote.append(d)
+        print(f"[propainter_amd] mp4 encoding unavailable ({type(e).__name__}); wrote PNG folders instead")
+    return wrote

@@ -1,0 +1,83 @@
+"""CLI drop-in surface (inference_propainter.py at the repo root) and its host-side I/O (propainter_amd/video_io.py)."""
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+from PIL import Image
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import inference_propainter as cli  # noqa: E402
+from propainter_amd import video_io  # noqa: E402
+
+# flag -> default of the reference CLI (inference_propainter.py:181-217)
+REFERENCE_FLAGS = {
+    "video": 'inputs/object_removal/bmx-trees', "mask": 'inputs/object_removal/bmx-trees_mask', "output": 'results',
+    "resize_ratio": 1.0, "height": -1, "width": -1, "mask_dilation": 4, "ref_stride": 10, "neighbor_length": 10,
+    "subvideo_length": 80, "raft_iter": 20, "mode": 'video_inpainting', "scale_h": 1.0, "scale_w": 1.2, "save_fps": 24,
+    "save_frames": False, "fp16": False,
+}
+
+
+def test_cli_flags_and_defaults_match_the_reference():
+    args = cli.build_parser().parse_args([])
+    for k, v in REFERENCE_FLAGS.items():
+        assert getattr(args, k) == v, k
+    a = cli.build_parser().parse_args(["-i", "x", "-m", "y.png", "-o", "z", "--fp16", "--save_frames", "--mode", "video_outpainting"])
+    assert (a.video, a.mask, a.output, a.fp16, a.save_frames, a.mode) == ("x", "y.png", "z", True, True, "video_outpainting")
+    ref_cli = "/root/reference/inference_propainter.py"
+    if os.path.exists(ref_cli):                      # authoring container only: every reference flag exists here
+        flags = set(re.findall(r"'--([a-z_0-9]+)'|\"--([a-z_0-9]+)\"", open(ref_cli).read()))
+        for f in {a or b for a, b in flags}:
+            assert hasattr(args, f), f
+
+
+def test_resize_to_multiples_of_eight():
+    frames = [Image.fromarray(np.zeros((243, 437, 3), dtype=np.uint8))] * 2
+    out, proc, out_size = video_io.resize_frames(frames, None)
+    assert proc == (432, 240) and out_size == (437, 243) and out[0].size == (432, 240)
+    out, proc, out_size = video_io.resize_frames(frames, (1280, 720))
+    assert proc == (1280, 720) and out_size == (1280, 720) and out[0].size == (1280, 720)
+
+
+def test_read_masks_dilation_and_broadcast(tmp_path):
+    import scipy.ndimage
+    m = np.zeros((40, 64), dtype=np.uint8)
+    m[10:20, 30:40] = 255
+    p = tmp_path / "mask.png"
+    Image.fromarray(m).save(p)
+    fm, md = video_io.read_masks(str(p), 5, (64, 40), flow_mask_dilates=4, mask_dilates=4)
+    assert len(fm) == 5 and len(md) == 5 and fm[0].dtype == np.uint8
+    want = scipy.ndimage.binary_dilation(m, iterations=4).astype(np.uint8) * 255
+    assert np.array_equal(fm[0], want) and np.array_equal(md[3], want) and set(np.unique(want)) == {0, 255}
+    fm0, _ = video_io.read_masks(str(p), 2, (64, 40), flow_mask_dilates=0, mask_dilates=0)
+    assert np.array_equal(fm0[0], m)
+    d = tmp_path / "masks"
+    d.mkdir()
+    for i in range(3):
+        mi = np.zeros((40, 64), dtype=np.uint8); mi[5 + i:9 + i, 5:9] = 255
+        Image.fromarray(mi).save(d / f"{i:05d}.png")
+    fm, md = video_io.read_masks(str(d), 3, (64, 40), 4, 4)
+    assert len(fm) == 3 and not np.array_equal(fm[0], fm[2])
+    with pytest.raises(RuntimeError):
+        video_io.read_masks(str(d), 4, (64, 40), 4, 4)
+
+
+def test_outpainting_canvas():
+    frames = [Image.fromarray(np.full((240, 432, 3), 200, dtype=np.uint8))] * 2
+    out, fm, md, size = video_io.extrapolation(frames, (1.0, 1.2))
+    assert size == (512, 240) and out[0].size == (512, 240)            # int(1.2*432)=518 -> 512
+    x0 = (512 - 432) // 2
+    assert md[0][:, :x0].min() == 255 and md[0][:, x0:x0 + 432].max() == 0
+    assert fm[0][:, x0 + 3].min() == 255 and fm[0][:, x0 + 4].max() == 0      # 4-px rim of known pixels is distrusted
+    assert np.asarray(out[0])[0, 0].max() == 0 and np.asarray(out[0])[0, x0].min() == 200
+
+
+def test_save_results_layout(tmp_path):
+    comp = [np.full((16, 24, 3), i, dtype=np.uint8) for i in range(3)]
+    wrote = video_io.save_results(str(tmp_path / "clip"), comp, comp, (24, 16), 24, True)
+    assert os.path.exists(tmp_path / "clip" / "frames" / "0002.png")
+    assert any("inpaint_out" in w for w in wrote) and any("masked_in" in w for w in wrote)

@@ -4,6 +4,7 @@ REAL reference (tests/golden/*.npz) and against the CPU oracle on fresh seeded i
 Tolerances (stated per north_star): fp32 engine 1e-3 of the output range; fp16 engine (fp16 storage + MFMA, fp32
 accumulate) 3e-2 of the range for the feed-forward stages; RAFT in fp16 is judged by end-point error in pixels."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -177,3 +178,27 @@ def test_logical_shards_on_one_gpu_match_the_unsharded_pass(models, fp16):
     out = run_logical_shards(models, clip, masks, masks, cfg, dev, 3)
     torch.cuda.synchronize()
     assert torch.equal(out, ref), f"sharded pass differs in {(out != ref).float().mean().item():.3e} of bytes"
+
+
+def test_cli_end_to_end_on_a_frame_folder(tmp_path):
+    """inference_propainter.py (repo root) on a folder of PNG frames + a single mask image, seeded weights."""
+    import inference_propainter as cli
+    from PIL import Image
+    from propainter_amd.synthetic import synthetic_clip, synthetic_mask
+    L, H, W = 6, 128, 192
+    d = tmp_path / "clip"
+    d.mkdir()
+    clip = synthetic_clip(L, H, W, seed=4)
+    for i, f in enumerate(clip):
+        Image.fromarray(f).save(d / f"{i:05d}.png")
+    Image.fromarray(synthetic_mask(H, W)).save(tmp_path / "mask.png")
+    cli.main(["-i", str(d), "-m", str(tmp_path / "mask.png"), "-o", str(tmp_path / "results"), "--seeded_weights", "--fp16",
+              "--save_frames", "--raft_iter", "3", "--neighbor_length", "4", "--ref_stride", "3"])
+    out = sorted(os.listdir(tmp_path / "results" / "clip" / "frames"))
+    assert out == [f"{i:04d}.png" for i in range(L)]
+    f0 = np.asarray(Image.open(tmp_path / "results" / "clip" / "frames" / "0000.png"))
+    assert f0.shape == (H, W, 3)
+    outside = synthetic_mask(H, W) == 0
+    import scipy.ndimage
+    outside = ~scipy.ndimage.binary_dilation(~outside, iterations=4)
+    assert np.array_equal(f0[outside], clip[0][outside])          # known pixels pass through untouched
