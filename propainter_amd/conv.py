@@ -32,26 +32,43 @@ def fold_batchnorm(weight, bias, bn_weight, bn_bias, mean, var, eps=1e-5):
     return w.float(), b.float()
 
 
-def pack_weight(weight, src_channels, groups=1, k_multiple=64):
+def pack_weight(weight, src_channels, groups=1, ktable=None):
     """weight [Cout, Cin_g, kh, kw] (any float dtype, CPU or GPU) -> (packed fp32 [groups, cout_pad, K], K, cout_g).
-    K order = (ky, kx, source, channel) with every source padded to a multiple of 8 channels."""
-    w = weight.detach().float()
+
+    The K order is whatever ``ktable`` (int32 [kchunks(+1), 4] from pp_conv_build_ktable: {dy, dx, src | grp<<8 | tap<<16,
+    choff} per 8-channel chunk, src 255 = zero chunk) says -- the table is the single source of truth shared with the
+    kernels; the tap id indexes the kernel window in row-major (ky, kx) order.  Every source is padded to a multiple of
+    8 channels (zero weights)."""
+    w = weight.detach().float().cpu()
     cout, cin_g, kh, kw = w.shape
     assert sum(src_channels) == cin_g, (src_channels, cin_g)
-    parts, off = [], 0
+    parts, off, bases, base = [], 0, [], 0
     for c in src_channels:
         part = w[:, off:off + c]
         if pad8(c) != c:
             part = torch.cat([part, part.new_zeros(cout, pad8(c) - c, kh, kw)], 1)
         parts.append(part)
+        bases.append(base)
+        base += pad8(c)
         off += c
-    w = torch.cat(parts, 1).permute(0, 2, 3, 1).reshape(cout, -1)        # [Cout, kh*kw*Cpad]
-    k_real = w.shape[1]
-    K = (k_real + k_multiple - 1) // k_multiple * k_multiple
+    ctot = base
+    wt = torch.cat(parts, 1).permute(0, 2, 3, 1).reshape(cout, kh * kw * ctot)          # [Cout, tap, Cpad_total]
+    if ktable is None:
+        ktable = hip.build_ktable([(ky, kx) for ky in range(kh) for kx in range(kw)], [pad8(c) for c in src_channels])
+    kt = np.asarray(ktable)
+    if kt.shape[0] % 8 == 1:
+        kt = kt[:-1]                                                                     # drop the zero-page row
+    K = kt.shape[0] * 8
+    code = kt[:, 2].astype(np.int64)
+    src, tap, choff = code & 0xff, (code >> 16) & 0xff, kt[:, 3].astype(np.int64)
+    live = src != 255
+    col0 = np.where(live, tap * ctot + np.asarray(bases + [0] * 256, dtype=np.int64)[np.minimum(src, len(bases))] + choff, 0)
+    cols = torch.from_numpy((col0[:, None] + np.arange(8)[None, :]).reshape(-1))
+    wk = wt[:, cols] * torch.from_numpy(np.repeat(live, 8)).float()[None, :]              # [Cout, K]
     cout_g = cout // groups
     cout_pad = (cout_g + 15) // 16 * 16
-    packed = w.new_zeros(groups, cout_pad, K)
-    packed[:, :cout_g, :k_real] = w.view(groups, cout_g, k_real)
+    packed = wk.new_zeros(groups, cout_pad, K)
+    packed[:, :cout_g] = wk.view(groups, cout_g, K)
     return packed, K, cout_g
 
 
@@ -70,15 +87,15 @@ class ConvLayer:
         self.src_cpad = [pad8(c) for c in self.src_channels]
         self.pad_mode = 1 if pad_mode == "replicate" else 0
         self.dtype = dtype
-        packed, K, cout_g = pack_weight(weight, self.src_channels, groups)
+        if taps is None:
+            taps = [(ky * self.dilation[0], kx * self.dilation[1]) for ky in range(kh) for kx in range(kw)]
+        kt = hip.build_ktable(taps, self.src_cpad, dcn_groups)
+        packed, K, cout_g = pack_weight(weight, self.src_channels, groups, ktable=kt)   # K order = the table's order
         self.cout_g, self.cout = cout_g, cout
         self.cout_pad = packed.shape[1]
         self.K = K
         self.weight = packed.to(device=device, dtype=dtype).contiguous()
         self.bias = None if bias is None else bias.detach().float().to(device).contiguous()
-        if taps is None:
-            taps = [(ky * self.dilation[0], kx * self.dilation[1]) for ky in range(kh) for kx in range(kw)]
-        kt = hip.build_ktable(taps, self.src_cpad, dcn_groups)
         assert (kt.shape[0] - 1) * 8 == K, (kt.shape, K)     # + the trailing zero-page entry
         self.kchunks = kt.shape[0] - 1
         self.ktable = torch.from_numpy(kt).to(device)

@@ -341,15 +341,35 @@ extern "C" int pp_conv_build_ktable(int ntaps, const int32_t* dy, const int32_t*
   if (out == nullptr) return padded;
   PP_REQUIRE(out_capacity >= padded + 1, PP_ERR_WORKSPACE, "pp_conv_build_ktable: need %d entries, got %d", padded + 1, out_capacity);
   int k = 0;
-  for (int t = 0; t < ntaps; ++t) {
-    int cglobal = 0;
+  if (dcn_groups) {
+    // deformable sampling: tap-major (every chunk carries its own offset group / tap id)
+    for (int t = 0; t < ntaps; ++t) {
+      int cglobal = 0;
+      for (int s = 0; s < nsrc; ++s)
+        for (int c = 0; c < src_channels[s]; c += 8, cglobal += 8, ++k) {
+          int grp = cglobal / (ctotal / dcn_groups);
+          out[4 * k + 0] = dy[t];
+          out[4 * k + 1] = dx[t];
+          out[4 * k + 2] = s | (grp << 8) | (t << 16);
+          out[4 * k + 3] = c;
+        }
+    }
+  } else {
+    // channel-block-major: (source, 64-channel block, tap, 8-channel chunk).  All taps of one 128-byte channel block
+    // are consecutive K steps, so the pixels a tile re-reads for its neighbouring taps are still in the XCD's L2
+    // (the live set per K step is tiles x 128 px x 128 B ~ 1 MB per XCD); with the tap-major order every tap pass
+    // streamed the full pixel (all sources, all channels) of the tile's halo through L2 (> 4 MB per XCD at the RAFT /
+    // generator sizes), and the gather ran at Infinity-Fabric instead of L2 speed.
     for (int s = 0; s < nsrc; ++s)
-      for (int c = 0; c < src_channels[s]; c += 8, cglobal += 8, ++k) {
-        int grp = dcn_groups ? cglobal / (ctotal / dcn_groups) : 0;
-        out[4 * k + 0] = dy[t];
-        out[4 * k + 1] = dx[t];
-        out[4 * k + 2] = s | (grp << 8) | (t << 16);
-        out[4 * k + 3] = c;
+      for (int cb = 0; cb < src_channels[s]; cb += 64) {
+        const int ce = cb + 64 < src_channels[s] ? cb + 64 : src_channels[s];
+        for (int t = 0; t < ntaps; ++t)
+          for (int c = cb; c < ce; c += 8, ++k) {
+            out[4 * k + 0] = dy[t];
+            out[4 * k + 1] = dx[t];
+            out[4 * k + 2] = s | (t << 16);
+            out[4 * k + 3] = c;
+          }
       }
   }
   for (; k < padded; ++k) { out[4 * k] = 0; out[4 * k + 1] = 0; out[4 * k + 2] = 255; out[4 * k + 3] = 0; }

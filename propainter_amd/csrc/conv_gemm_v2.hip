@@ -44,7 +44,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int S, bool UNI>
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int S, bool UNI, int SCHED = 0>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_v2_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the body uses device-only types (__amdgpu_buffer_rsrc_t): the host pass only needs the stub
   typedef _Float16 T;
@@ -292,29 +292,84 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_v2_kernel(co
     else if (S >= 5 && ahead == 3) wait_vmcnt<(S >= 5 ? 3 : 0) * G>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();                     // stage `buf` complete for all waves; stage `nbuf` (read at step ks-1) is free
-    if (more) {
-      if constexpr (UNI) {
-        entry_ready(e1);
-        issue_uni(ks + S - 1, nbuf, e1);
-      } else {
-        entries_ready(E);
-        issue(ks + S - 1, nbuf, E);
-      }
-    }
     const char* sb = lds + buf * STAGE;
+    if constexpr (SCHED == 2) {                     // [diagnostic] DMA + barriers only
+      if (more) {
+        if constexpr (UNI) { entry_ready(e1); issue_uni(ks + S - 1, nbuf, e1); }
+        else { entries_ready(E); issue(ks + S - 1, nbuf, E); }
+      }
+    } else if constexpr (SCHED == 3) {              // [diagnostic] LDS reads + MFMA only (stale tiles)
+      if (more) { if constexpr (UNI) entry_ready(e1); else entries_ready(E); }
 #pragma unroll
-    for (int kk = 0; kk < BK / 32; ++kk) {
-      const int so = ((kk * 4 + (lane >> 4)) ^ fswz) * 16;
-      f16x8 af[TM], bf[TN];
+      for (int kk = 0; kk < BK / 32; ++kk) {
+        const int so = ((kk * 4 + (lane >> 4)) ^ fswz) * 16;
+        f16x8 af[TM], bf[TN];
 #pragma unroll
-      for (int t = 0; t < TM; ++t) af[t] = *reinterpret_cast<const f16x8*>(sb + a_off + t * 16 * ROWB + so);
+        for (int t = 0; t < TM; ++t) af[t] = *reinterpret_cast<const f16x8*>(sb + a_off + t * 16 * ROWB + so);
 #pragma unroll
-      for (int t = 0; t < TN; ++t) bf[t] = *reinterpret_cast<const f16x8*>(sb + b_off + t * 16 * ROWB + so);
+        for (int t = 0; t < TN; ++t) bf[t] = *reinterpret_cast<const f16x8*>(sb + b_off + t * 16 * ROWB + so);
 #pragma unroll
-      for (int a = 0; a < TN; ++a)
+        for (int a = 0; a < TN; ++a)
 #pragma unroll
-        for (int b = 0; b < TM; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[a], af[b], acc[a][b], 0, 0, 0);
+          for (int b = 0; b < TM; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[a], af[b], acc[a][b], 0, 0, 0);
+      }
+    } else if constexpr (SCHED == 0) {
+      if (more) {
+        if constexpr (UNI) {
+          entry_ready(e1);
+          issue_uni(ks + S - 1, nbuf, e1);
+        } else {
+          entries_ready(E);
+          issue(ks + S - 1, nbuf, E);
+        }
+      }
+#pragma unroll
+      for (int kk = 0; kk < BK / 32; ++kk) {
+        const int so = ((kk * 4 + (lane >> 4)) ^ fswz) * 16;
+        f16x8 af[TM], bf[TN];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) af[t] = *reinterpret_cast<const f16x8*>(sb + a_off + t * 16 * ROWB + so);
+#pragma unroll
+        for (int t = 0; t < TN; ++t) bf[t] = *reinterpret_cast<const f16x8*>(sb + b_off + t * 16 * ROWB + so);
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+          for (int b = 0; b < TM; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[a], af[b], acc[a][b], 0, 0, 0);
+      }
+    } else {
+      // SCHED 1: every fragment of the K step is requested from LDS first (one exposed LDS latency per step instead of
+      // one per 4-MFMA group), the next stage's DMA is issued while those reads are in flight, then the MFMAs run
+      // back to back.  sched_barrier fences keep hipcc from sinking the reads back next to their uses.
+      constexpr int KK = BK / 32;
+      f16x8 af[KK][TM], bf[KK][TN];
+      if (more) {                                      // the table entry (SMEM, requested before the barrier) must be
+        if constexpr (UNI) entry_ready(e1);            // retired BEFORE the LDS reads are queued: lgkmcnt counts both
+        else entries_ready(E);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        const int so = ((kk * 4 + (lane >> 4)) ^ fswz) * 16;
+#pragma unroll
+        for (int t = 0; t < TM; ++t) af[kk][t] = *reinterpret_cast<const f16x8*>(sb + a_off + t * 16 * ROWB + so);
+#pragma unroll
+        for (int t = 0; t < TN; ++t) bf[kk][t] = *reinterpret_cast<const f16x8*>(sb + b_off + t * 16 * ROWB + so);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) {
+        if constexpr (UNI) issue_uni(ks + S - 1, nbuf, e1);
+        else issue(ks + S - 1, nbuf, E);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+          for (int b = 0; b < TM; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[kk][a], af[kk][b], acc[a][b], 0, 0, 0);
     }
     buf = buf + 1 == S ? 0 : buf + 1;
     nbuf = nbuf + 1 == S ? 0 : nbuf + 1;
@@ -394,7 +449,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_v2_kernel(co
 #endif
 }
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int S>
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int S, int SCHED = 0>
 static int launch_v2(ConvParams p, bool uni, hipStream_t stream) {
   p.tiles_m = (int)((p.M + BM - 1) / BM);
   p.tiles_n = (p.cout_g + BN - 1) / BN;
@@ -402,9 +457,9 @@ static int launch_v2(ConvParams p, bool uni, hipStream_t stream) {
   const dim3 grid((unsigned)nblk), block(64 * WAVES_M * WAVES_N);
   // the uniform-step fast path needs uniform steps at this BK (flag bit = chunks per step) -- see conv_v2_dispatch
   if (uni && (p.ktable_uniform & (BK / 8)))
-    hipLaunchKernelGGL((conv_gemm_v2_kernel<BM, BN, BK, WAVES_M, WAVES_N, S, true>), grid, block, 0, stream, p);
+    hipLaunchKernelGGL((conv_gemm_v2_kernel<BM, BN, BK, WAVES_M, WAVES_N, S, true, SCHED>), grid, block, 0, stream, p);
   else
-    hipLaunchKernelGGL((conv_gemm_v2_kernel<BM, BN, BK, WAVES_M, WAVES_N, S, false>), grid, block, 0, stream, p);
+    hipLaunchKernelGGL((conv_gemm_v2_kernel<BM, BN, BK, WAVES_M, WAVES_N, S, false, SCHED>), grid, block, 0, stream, p);
   return launch_status("pp_conv2d(v2)");
 }
 
@@ -443,6 +498,21 @@ int conv_v2_dispatch(const ConvParams& p, int cfg, hipStream_t stream) {
     case 40: return launch_v2<256, 16, 32, 4, 1, 4>(p, uni, stream);    // wave tile 64x16
     case 41: return launch_v2<256, 16, 32, 4, 1, 3>(p, uni, stream);
     case 42: return launch_v2<256, 16, 32, 4, 1, 2>(p, uni, stream);
+    // SCHED 1 variants (all fragment reads of a K step up front)
+    case 50: return launch_v2<128, 128, 64, 2, 2, 2, 1>(p, uni, stream);
+    case 51: return launch_v2<256, 128, 64, 4, 2, 3, 1>(p, uni, stream);
+    case 52: return launch_v2<128, 128, 32, 2, 2, 4, 1>(p, uni, stream);
+    case 53: return launch_v2<128, 128, 32, 2, 2, 3, 1>(p, uni, stream);
+    case 54: return launch_v2<256, 128, 32, 4, 2, 4, 1>(p, uni, stream);
+    case 60: return launch_v2<128, 128, 64, 2, 2, 2, 2>(p, uni, stream);   // diagnostics (wrong results by design)
+    case 61: return launch_v2<128, 128, 64, 2, 2, 2, 3>(p, uni, stream);
+    case 64: return launch_v2<128, 128, 32, 2, 2, 4, 2>(p, uni, stream);
+    case 65: return launch_v2<128, 128, 64, 2, 2, 3, 2>(p, uni, stream);
+    case 66: return launch_v2<256, 128, 32, 4, 2, 4, 2>(p, uni, stream);
+    case 67: return launch_v2<128, 128, 32, 2, 2, 3, 2>(p, uni, stream);
+    case 68: return launch_v2<128, 128, 32, 2, 2, 4, 3>(p, uni, stream);
+    case 62: return launch_v2<256, 128, 64, 4, 2, 3, 2>(p, uni, stream);
+    case 63: return launch_v2<256, 128, 64, 4, 2, 3, 3>(p, uni, stream);
     default: return -1000;
   }
 }
