@@ -107,11 +107,14 @@ typedef struct {
   int32_t dcn_cstride;
   int32_t dcn_mask_off;          /* channel index of the first modulation mask (288)           */
   int32_t impl;                  /* 0 = auto; 1 = force the register-staged kernel; 2 = LDS-DMA kernel without the
-                                    uniform-step fast path; >= 10 = a specific LDS-DMA tile configuration (+100: no
-                                    fast path) (fp16 only; tile sweeps, see csrc/conv_gemm_v2.hip)                */
+                                    uniform-step fast path; 10..69 = a specific LDS-DMA tile configuration (+100: no
+                                    fast path); 70..72 = force the halo-tile kernel (fp16 only; tile sweeps, see
+                                    csrc/conv_gemm_v2.hip, csrc/conv_gemm_v3.hip)                                  */
   int32_t ktable_uniform;        /* bit mask describing `ktable`: 4 / 8 set when every aligned run of 4 / 8 chunks is one
                                     (tap, source) with consecutive channel offsets (true when every source has a
                                     multiple of 32 / 64 channels); 0 = unknown (always correct)                   */
+  int32_t tap_h, tap_w;          /* > 0: the table describes a dense, dilation-1 tap_h x tap_w window in row-major tap order
+                                    (enables the halo-tile kernel for stride-1 "same" convolutions); 0 = unknown    */
 } pp_conv_args_t;
 
 /* Host helper: fill `out` (kchunks_padded x 4 int32) for `ntaps` taps (dy[i], dx[i] are input

@@ -87,6 +87,8 @@ class ConvLayer:
         self.src_cpad = [pad8(c) for c in self.src_channels]
         self.pad_mode = 1 if pad_mode == "replicate" else 0
         self.dtype = dtype
+        # dense dilation-1 window in row-major order: the halo-tile kernel may serve it (pp_conv_args_t.tap_h / tap_w)
+        self.tap_hw = (kh, kw) if (taps is None and self.dilation == (1, 1) and dcn_groups == 0) else (0, 0)
         if taps is None:
             taps = [(ky * self.dilation[0], kx * self.dilation[1]) for ky in range(kh) for kx in range(kw)]
         kt = hip.build_ktable(taps, self.src_cpad, dcn_groups)
@@ -152,6 +154,7 @@ class ConvLayer:
             a.dcn_offmask, a.dcn_cstride, a.dcn_mask_off = dcn_offmask.data_ptr(), dcn_offmask.shape[-1], 288
         a.impl = self.impl
         a.ktable_uniform = self.ktable_uniform
+        a.tap_h, a.tap_w = self.tap_hw
         self._keep = (srcs, out, residual, dcn_offmask)
         hip.conv2d_raw(a, cin_read=sum(self.src_cpad) * self.groups)
         return out

@@ -1,0 +1,162 @@
+// Lean shared epilogue of the LDS-DMA convolution kernels (conv_gemm_v2.hip / conv_gemm_v3.hip).
+//
+// Measured with in-kernel cycle stamps (tools/bench_conv.py impl 75): the first epilogue (fp32 staging tile, then
+// bias / activation / residual per element inside the store loop, every uniform option re-tested per element) cost
+// 12-13 k cycles per 64x64 wave tile -- instruction-bound, as much as 8 K-steps of MFMA work.  Here:
+//   phase 1 (registers): bias + scale + activation on the accumulators, with the uniform options hoisted into ONE switch;
+//   staging: fp16 pairs straight into LDS when the output is fp16 and there is no residual (half the LDS traffic),
+//            otherwise fp32 (the residual is added in fp32 before the single final rounding, as before);
+//   phase 2: one ds_read_b128 (+ residual add) + one 16-byte global store per 8 couts, nothing else.
+// Every lane handles 64 outputs either way; the minimum is ~6 VALU per output.
+#pragma once
+#include "conv_params.h"
+
+namespace pp {
+
+// RowMap: prow (0..WM-1, pixel row of the wave tile) -> flat output pixel index, or -1 when the row is outside the image.
+template <int WM, int WN, typename RowMap>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[WN / 16][WM / 16], char* wave_lds, int lane,
+                                              int co_wave /* first cout of the wave tile within the group */, int g,
+                                              char* outp, const RowMap rowmap) {
+  constexpr int TM = WM / 16, TN = WN / 16;
+  typedef _Float16 T;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const bool has_res = p.residual != nullptr;
+  const bool stage16 = p.out_f16 && !has_res;
+  // ---- phase 1: bias, scale, activation in registers (each lane: 4 consecutive couts of 16 pixel rows per tile)
+  {
+    const float scale = p.out_scale;
+    const int act = p.act;
+    const float slope = act == PP_ACT_NONE ? 1.f : (act == PP_ACT_LRELU ? p.act_param : 0.f);
+#pragma unroll
+    for (int a = 0; a < TN; ++a) {
+      f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+      const int c0 = co_wave + a * 16 + l4 * 4;
+      if (p.bias != nullptr) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b4[r] = c0 + r < p.cout_g ? p.bias[g * p.cout_g + c0 + r] : 0.f;
+      }
+      if (act < PP_ACT_SIGMOID) {
+#pragma unroll
+        for (int b = 0; b < TM; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = (acc[a][b][r] + b4[r]) * scale;
+            acc[a][b][r] = v > 0.f ? v : v * slope;
+          }
+      } else if (act == PP_ACT_SIGMOID) {             // 1 / (1 + e^-v): v_exp + v_rcp (1 ulp; the result is rounded to fp16)
+#pragma unroll
+        for (int b = 0; b < TM; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            acc[a][b][r] = __builtin_amdgcn_rcpf(1.f + __expf(-(acc[a][b][r] + b4[r]) * scale));
+      } else if (act == PP_ACT_TANH) {                // 1 - 2 / (e^2v + 1); saturates correctly at +-inf
+#pragma unroll
+        for (int b = 0; b < TM; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            acc[a][b][r] = 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * (acc[a][b][r] + b4[r]) * scale) + 1.f);
+      } else {
+#pragma unroll
+        for (int b = 0; b < TM; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[a][b][r] = apply_act_special((acc[a][b][r] + b4[r]) * scale, act);
+      }
+    }
+  }
+  constexpr int LPR = WN / 8;                       // lanes per pixel row (8 couts each)
+  constexpr int RPP = 64 / LPR;                     // pixel rows per pass
+  const int cl = (lane % LPR) * 8;
+  const int co = co_wave + cl;
+  const int nval = min(8, p.cout_g - co);
+  const int out_cbase = p.out_choff + g * p.out_cgroup;
+  if (stage16) {
+    // ---- fp16 staging: row stride WN*2 + 16 bytes
+    constexpr int LD = WN * 2 + 16;
+#pragma unroll
+    for (int b = 0; b < TM; ++b)
+#pragma unroll
+      for (int a = 0; a < TN; ++a) {
+        f16x4 h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = (_Float16)acc[a][b][r];
+        *reinterpret_cast<f16x4*>(wave_lds + (b * 16 + l15) * LD + (a * 16 + l4 * 4) * 2) = h;
+      }
+    const bool vec_ok = ((p.out_cstride | out_cbase) & 7) == 0;
+    _Float16* ob = reinterpret_cast<_Float16*>(outp) + out_cbase + co;
+#pragma unroll 4
+    for (int pass = 0; pass < WM / RPP; ++pass) {
+      const int prow = pass * RPP + lane / LPR;
+      const long long m = rowmap(prow);
+      if (m < 0 || nval <= 0) continue;
+      const u32x4 raw = *reinterpret_cast<const u32x4*>(wave_lds + prow * LD + cl * 2);
+      _Float16* op = ob + m * p.out_cstride;
+      if (nval == 8 && vec_ok) *reinterpret_cast<u32x4*>(op) = raw;
+      else {
+        const _Float16* h = reinterpret_cast<const _Float16*>(&raw);
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+          if (r < nval) op[r] = h[r];
+      }
+    }
+    return;
+  }
+  // ---- fp32 staging (residual and / or fp32 output): row stride WN + 4 floats
+  constexpr int LDF = WN + 4;
+  float* et = reinterpret_cast<float*>(wave_lds);
+#pragma unroll
+  for (int b = 0; b < TM; ++b)
+#pragma unroll
+    for (int a = 0; a < TN; ++a) *reinterpret_cast<f32x4*>(et + (b * 16 + l15) * LDF + a * 16 + l4 * 4) = acc[a][b];
+  const int res_cbase = p.res_choff + g * p.out_cgroup;
+  const bool res_vec_ok = ((p.res_cstride | res_cbase) & 7) == 0;
+  const bool relu2 = p.act2 == PP_ACT_RELU;
+#pragma unroll 2
+  for (int pass = 0; pass < WM / RPP; ++pass) {
+    const int prow = pass * RPP + lane / LPR;
+    const long long m = rowmap(prow);
+    if (m < 0 || nval <= 0) continue;
+    float v[8];
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(et + prow * LDF + cl);
+    const f32x4 hi = *reinterpret_cast<const f32x4*>(et + prow * LDF + cl + 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { v[r] = lo[r]; v[4 + r] = hi[r]; }
+    if (has_res) {
+      const T* rp = reinterpret_cast<const T*>(p.residual) + m * p.res_cstride + res_cbase + co;
+      if (nval == 8 && res_vec_ok) {
+        float rv[8];
+        load8<T>(rp, rv);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += rv[r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+          if (r < nval) v[r] += to_f32(rp[r]);
+      }
+      if (relu2) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
+    }
+    const long long oidx = m * p.out_cstride + out_cbase + co;
+    if (p.out_f16) {
+      _Float16* op = reinterpret_cast<_Float16*>(outp) + oidx;
+      if (nval == 8 && ((p.out_cstride | out_cbase) & 7) == 0) store8<_Float16>(op, v);
+      else {
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+          if (r < nval) op[r] = (_Float16)v[r];
+      }
+    } else {
+      float* op = reinterpret_cast<float*>(outp) + oidx;
+      if (nval == 8 && ((p.out_cstride | out_cbase) & 3) == 0) store8<float>(op, v);
+      else {
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+          if (r < nval) op[r] = v[r];
+      }
+    }
+  }
+}
+
+}  // namespace pp

@@ -1,0 +1,298 @@
+// fp16 implicit-GEMM convolution, third generation: HALO TILES.  Same GEMM view, K-chunk table and packed weights as
+// conv_gemm_v2.hip (channel-block-major K order), for the stride-1 "same" convolutions with a small rectangular tap
+// window (3x3, 1x5, 5x1) whose sources are multiples of 64 channels -- the RAFT update block, the propagation / offset
+// convolutions, the decoders: most of the path's FLOPs.
+//
+// Why: measured on MI355X (profiles/r1_conv_dma_vs_mfma.txt) the v2 kernel is bound by its L2->LDS gather, not by MFMA:
+// with the MFMAs removed a GRU convolution still takes 78 % of its time, with the gather removed it runs at
+// 1.2-1.3 PFLOP/s.  v2 re-fetches every pixel once per tap (9x for 3x3).  Here a block owns a 2-D tile of TH x TW
+// output pixels and, per 64-channel block, DMA-loads the (TH+KH-1) x (TW+KW-1) input patch ONCE (zero padding = the
+// buffer range check); all KH*KW taps then read their A fragments from that patch at a row offset dy*PW + dx.  The
+// activation traffic into LDS drops by 6.4x (3x3) / 4x (1x5, 5x1); only the weight tiles (L1/L2-resident, 16 KiB per K
+// step) still stream every step.
+//
+//   LDS: 2 patch buffers [PROWS][64 ch] (double buffered across channel blocks; the next block's patch arrives in
+//        pieces, one LDS-DMA instruction per wave per tap step) + 2 weight stages [BN][64] + epilogue tile (aliased).
+//   Swizzle: 16-byte slot ^ ((row >> 1) & 7) on both the DMA source chunk and the fragment read, keyed by the PATCH row,
+//        so any 16 consecutive patch rows (one MFMA fragment: 16 pixels of a tile row) are conflict-free.
+//   4 waves (2 x 2), wave tile 64 px x BN/2 couts, v_mfma_f32_16x16x32_f16, fp32 accumulate.  Epilogue as in v2.
+#include "conv_epilogue.h"
+
+namespace pp {
+
+typedef __attribute__((address_space(3))) void* lptr3_t;
+
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef int i32x4s __attribute__((ext_vector_type(4)));
+// (free functions with by-value arguments, not capturing lambdas: a by-reference closure of buffer resources ends up in
+// scratch memory, and scratch loads share vmcnt with the LDS-DMA stream)
+static __device__ __forceinline__ void v3_fetch_entry(const int4* ptr, i32x4s& e) {   // scalar load; complete after v3_entry_ready
+  asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(e) : "s"(ptr));
+}
+static __device__ __forceinline__ void v3_entry_ready(i32x4s& e) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(e)::"memory"); }
+static __device__ __forceinline__ void v3_dma16(__amdgpu_buffer_rsrc_t r, char* dst, int voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lptr3_t)dst, 16, voff, soff, 0, 0);
+}
+#endif
+
+// PROF: diagnostic build that accumulates s_memtime deltas per phase into pp_debug_conv_prof() (see tools/bench_conv.py)
+__device__ unsigned long long g_v3_prof[12];
+
+template <int TH, int TW, int KH, int KW, int BN, bool PROF = false, int STAGGER = 0>
+__global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef _Float16 T;
+  constexpr int NW = 4, WAVES_N = 2;
+  constexpr int BM = TH * TW;
+  constexpr int WM = BM / 2, WN = BN / WAVES_N;
+  constexpr int TM = WM / 16, TN = WN / 16;
+  constexpr int PH = TH + KH - 1, PW = TW + KW - 1, P = PH * PW;
+  constexpr int NTAPS = KH * KW;
+  constexpr int PIECES = (P + 8 * NW - 1) / (8 * NW) * NW;     // LDS-DMA instructions per patch (8 rows each)
+  constexpr int PPW = PIECES / NW;                              // ... per wave
+  constexpr int PATCH_BYTES = PIECES * 1024;
+  constexpr int BSTAGE = BN * 128;
+  constexpr int B_PER_WAVE = BN / 8 / NW;
+  constexpr int PIPE_BYTES = 2 * PATCH_BYTES + 2 * BSTAGE;
+  constexpr int EPI_LD = WN + 4;
+  constexpr int EPI_BYTES = NW * WM * EPI_LD * 4;
+  constexpr int LDS_BYTES = PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES;
+  static_assert(BM == 128 && (TW == 16 || TW == 8) && PPW <= NTAPS && BN % 32 == 0 && LDS_BYTES <= 80 * 1024, "tile");
+
+  __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
+  unsigned long long pf_start = 0;
+  if constexpr (PROF) pf_start = __builtin_readcyclecounter();
+  char* const patch0 = lds;
+  char* const bst0 = lds + 2 * PATCH_BYTES;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // ---- XCD-aware block order (as v2): each XCD gets a contiguous run of tiles, couts fastest
+  int bid = blockIdx.x;
+  {
+    const int nblk = gridDim.x;
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, loc = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int tn = bid % p.tiles_n;
+  int tile = bid / p.tiles_n;
+  const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
+  const int txi = tile % tiles_x; tile /= tiles_x;
+  const int tyi = tile % tiles_y;
+  const int n = tile / tiles_y;
+  const int ty0 = tyi * TH, tx0 = txi * TW;
+  const int n0 = tn * BN;
+
+  // ---- DMA roles.  Patch piece q = j*NW + wave covers patch rows q*8 .. q*8+7; lane -> (row q*8 + lane/8, slot lane%8).
+  // (q*8 + rin) >> 1 & 7 == (4*q + (rin >> 1)) & 7 and q has the parity of `wave` (NW is even): one logical chunk per lane.
+  const int rin = lane >> 3, slot = lane & 7;
+  const int lc = slot ^ ((4 * (wave & 1) + (rin >> 1)) & 7);
+  int ppix[PPW];                                          // global pixel index of the lane's patch row, -1 = zero fill
+#pragma unroll
+  for (int j = 0; j < PPW; ++j) {
+    const int r = (j * NW + wave) * 8 + rin;
+    const int py = r / PW, px = r - py * PW;
+    const int iy = ty0 - p.ph + py, ix = tx0 - p.pw + px;
+    const bool ok = (r < P) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+    ppix[j] = ok ? (n * p.H + iy) * p.W + ix : -1;
+  }
+  int wvoff[B_PER_WAVE];
+#pragma unroll
+  for (int j = 0; j < B_PER_WAVE; ++j) {
+    int row = n0 + (j * NW + wave) * 8 + rin;
+    if (row >= p.cout_pad) row = p.cout_pad - 1;          // clamped rows feed accumulators that are never stored
+    wvoff[j] = row * p.kchunks * 16 + lc * 16;
+  }
+  const int nrec = p.N * p.H * p.W;
+  // (individual scalars, not arrays: a dynamically indexed private array would live in scratch, and scratch loads share
+  // vmcnt with the LDS-DMA stream)
+  const int rb0 = p.src[0].cstride * 2, rb1 = p.src[1].cstride * 2, rb2 = p.src[2].cstride * 2, rb3 = p.src[3].cstride * 2;
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.src[0].ptr + p.src[0].choff * 2), 0, nrec * rb0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.src[1].ptr + p.src[1].choff * 2), 0, nrec * rb1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.src[2].ptr + p.src[2].choff * 2), 0, nrec * rb2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.src[3].ptr + p.src[3].choff * 2), 0, nrec * rb3, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.weight), 0, p.cout_pad * p.kchunks * 16, 0x00020000);
+
+#define V3_ISSUE_PIECE(j, pbuf, e)                                                                              \
+  do {                                                                                                          \
+    const int s_ = (e)[2] & 0xff;                                                                               \
+    const __amdgpu_buffer_rsrc_t r_ = s_ == 1 ? rs1 : s_ == 2 ? rs2 : s_ == 3 ? rs3 : rs0;                      \
+    const int rowbytes_ = s_ == 1 ? rb1 : s_ == 2 ? rb2 : s_ == 3 ? rb3 : rb0;                                  \
+    const int voff_ = ppix[j] >= 0 ? ppix[j] * rowbytes_ + (e)[3] * 2 + lc * 16 : (int)0x80000000;              \
+    v3_dma16(r_, patch0 + (pbuf) * PATCH_BYTES + ((j) * NW + wave) * 1024, voff_, 0);                           \
+  } while (0)
+#define V3_ISSUE_B(ks_, par_)                                                                                   \
+  do {                                                                                                          \
+    _Pragma("unroll") for (int j_ = 0; j_ < B_PER_WAVE; ++j_)                                                   \
+      v3_dma16(rw, bst0 + (par_) * BSTAGE + (j_ * NW + wave) * 1024, wvoff[j_], (ks_) * 128);                   \
+  } while (0)
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment geometry: A row of fragment t = patch row pp0[t] + tap shift; B row = wn*WN + t*16 + (lane & 15)
+  const int l15 = lane & 15, l4 = lane >> 4;
+  int pp0[TM];
+#pragma unroll
+  for (int t = 0; t < TM; ++t) {
+    const int m = wm * WM + t * 16 + l15;
+    pp0[t] = (m / TW) * PW + (m % TW);
+  }
+  const int b_off = (wn * WN + l15) * 128;
+  const int bswz = (l15 >> 1) & 7;
+
+  const int nblocks = p.kchunks / (8 * NTAPS);
+  const int nk = nblocks * NTAPS;
+  if constexpr (STAGGER == 1) {
+    // De-phase the resident blocks.  All blocks of a launch start together and take the same time, so without this all
+    // ~512 resident tiles reach their epilogue at once: a 16 MB store burst at HBM write speed with nothing to overlap,
+    // once per round.  The first generation of blocks sleeps 0..7/8 of a tile time (phase = bits 3..5 of the block id, so
+    // every XCD gets every phase); later blocks are dispatched as slots free up and inherit the spread.
+    if (blockIdx.x < 512u && gridDim.x >= 1536u) {
+      const int phase = (blockIdx.x >> 3) & 7;
+      const int iters = (phase * nk * 1700 / 8) >> 12;          // ~4096 cycles per iteration (64 x s_sleep 64 cycles)
+      for (int i = 0; i < iters; ++i) __builtin_amdgcn_s_sleep(64);
+    }
+  }
+  unsigned long long pf_wait = 0, pf_vm = 0, pf_issue = 0, pf_comp = 0, pf_t0 = 0, pf_a = 0, pf_b = 0, pf_c = 0;
+  if constexpr (PROF) pf_t0 = __builtin_readcyclecounter();
+  // ---- prologue: patch of block 0 (all pieces) + weights of step 0
+  {
+    i32x4s e;
+    v3_fetch_entry(p.ktable, e);
+    v3_entry_ready(e);
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) V3_ISSUE_PIECE(j, 0, e);
+    V3_ISSUE_B(0, 0);
+  }
+  int ks = 0, par = 0;
+  for (int blk = 0; blk < nblocks; ++blk) {
+    const bool have_next = blk + 1 < nblocks;
+    i32x4s en;
+    if (have_next) v3_fetch_entry(p.ktable + (blk + 1) * (NTAPS * 8), en);
+    const char* pcur = patch0 + (blk & 1) * PATCH_BYTES;
+    const int pnext = (blk + 1) & 1;
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t) {
+      if constexpr (PROF) pf_a = __builtin_readcyclecounter();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if constexpr (PROF) { pf_b = __builtin_readcyclecounter(); pf_vm += pf_b - pf_a; }
+      __builtin_amdgcn_s_barrier();          // weights of step ks (and, at t == 0, the whole patch of this block) are in LDS
+      if constexpr (PROF) { pf_c = __builtin_readcyclecounter(); pf_wait += pf_c - pf_b; }
+      if (t == 0 && have_next) v3_entry_ready(en);
+      if (ks + 1 < nk) V3_ISSUE_B(ks + 1, par ^ 1);
+      if (t < PPW && have_next) V3_ISSUE_PIECE(t, pnext, en);
+      if constexpr (PROF) { pf_a = __builtin_readcyclecounter(); pf_issue += pf_a - pf_c; }
+      const int sh = (t / KW) * PW + (t % KW);          // compile-time after unrolling
+      const char* sb = bst0 + par * BSTAGE;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        f16x8 af[TM], bf[TN];
+#pragma unroll
+        for (int f = 0; f < TM; ++f) {
+          const int row = pp0[f] + sh;
+          af[f] = *reinterpret_cast<const f16x8*>(pcur + row * 128 + (((kk * 4 + l4) ^ ((row >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int f = 0; f < TN; ++f)
+          bf[f] = *reinterpret_cast<const f16x8*>(sb + b_off + f * 16 * 128 + (((kk * 4 + l4) ^ bswz) << 4));
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+          for (int b = 0; b < TM; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[a], af[b], acc[a][b], 0, 0, 0);
+      }
+      if constexpr (PROF) { asm volatile("s_nop 0" ::: "memory"); pf_comp += __builtin_readcyclecounter() - pf_a; }
+      ++ks;
+      par ^= 1;
+    }
+  }
+  if constexpr (PROF) pf_b = __builtin_readcyclecounter();
+  __syncthreads();                                    // LDS becomes the epilogue tile
+  unsigned long long pf_e1 = 0, pf_e2 = 0;
+  if constexpr (PROF) pf_e1 = __builtin_readcyclecounter();
+
+  // ---- epilogue (conv_epilogue.h): wave-private staging tile at lds + wave * (EPI_BYTES / NW)
+  if constexpr (PROF) pf_e2 = pf_e1;
+  struct RowMap {
+    int wm_base, ty0, tx0, H, W; long long nbase;
+    __device__ __forceinline__ long long operator()(int prow) const {
+      const int mt = wm_base + prow;
+      const int iy = ty0 + mt / TW, ix = tx0 + mt % TW;
+      return (iy < H && ix < W) ? (nbase + iy) * W + ix : -1ll;
+    }
+  };
+  const RowMap rowmap{wm * WM, ty0, tx0, p.H, p.W, (long long)n * p.H};
+  conv_epilogue<WM, WN>(p, acc, lds + wave * (EPI_BYTES / NW), lane, n0 + wn * WN, 0, p.out, rowmap);
+  if constexpr (PROF) {
+    const unsigned long long te = __builtin_readcyclecounter();
+    if (lane == 0 && (blockIdx.x & 63) == 5) {        // a 1/64 sample of the blocks: the atomics must not perturb the run
+      atomicAdd(&g_v3_prof[0], pf_vm); atomicAdd(&g_v3_prof[1], pf_wait); atomicAdd(&g_v3_prof[2], pf_issue);
+      atomicAdd(&g_v3_prof[3], pf_comp); atomicAdd(&g_v3_prof[4], pf_b - pf_t0); atomicAdd(&g_v3_prof[5], te - pf_b);
+      atomicAdd(&g_v3_prof[8], pf_e1 - pf_b); atomicAdd(&g_v3_prof[9], pf_e2 - pf_e1); atomicAdd(&g_v3_prof[10], te - pf_e2);
+      atomicAdd(&g_v3_prof[11], pf_t0 - pf_start);
+      atomicAdd(&g_v3_prof[6], 1ull); atomicAdd(&g_v3_prof[7], (unsigned long long)nk);
+    }
+  }
+#undef V3_ISSUE_PIECE
+#undef V3_ISSUE_B
+#endif
+}
+
+template <int TH, int TW, int KH, int KW, int BN, bool PROF = false, int STAGGER = 0>
+static int launch_v3(ConvParams p, hipStream_t stream) {
+  p.tiles_n = (p.cout_g + BN - 1) / BN;
+  const long long tiles = (long long)p.N * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
+  const long long nblk = tiles * p.tiles_n;
+  if (nblk >= (1ll << 31)) return -1000;
+  hipLaunchKernelGGL((conv_halo_kernel<TH, TW, KH, KW, BN, PROF, STAGGER>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
+  return launch_status("pp_conv2d(v3)");
+}
+
+// Returns -1000 when the shape is outside the halo-tile family (caller falls back to v2).
+// cfg: 0 = auto, 70 = force (BN by cout), 71 = BN 128, 72 = BN 64.
+int conv_v3_dispatch(const ConvParams& p, int cfg, hipStream_t stream) {
+  const int kh = p.tap_h, kw = p.tap_w;
+  if (kh <= 0 || kw <= 0) return -1000;
+  if (p.groups != 1 || p.sh != 1 || p.sw != 1 || p.pad_mode != 0 || p.OH != p.H || p.OW != p.W) return -1000;
+  if (p.ph != (kh - 1) / 2 || p.pw != (kw - 1) / 2 || !(p.ktable_uniform & 8)) return -1000;
+  if (p.kchunks % (8 * kh * kw) != 0 || p.src_gstride != 0 || p.out_gstride != 0) return -1000;
+  if ((long long)p.cout_pad * p.kchunks * 16 >= (1ll << 31)) return -1000;
+  for (int i = 0; i < p.nsrc; ++i)
+    if ((long long)p.N * p.H * p.W * p.src[i].cstride * 2 >= (1ll << 31)) return -1000;
+  if (cfg == 0 && (p.cout_g < 48 || p.H < 8 || p.W < 8)) return -1000;      // tiny couts / maps: v2's narrow tiles do better
+  const bool n64 = cfg == 72 || (cfg != 71 && p.cout_g <= 64);
+  if (cfg == 76 || cfg == 77) {   // staggered start (76) / + phase timing (77)
+    if (kh == 3 && kw == 3) return cfg == 76 ? launch_v3<8, 16, 3, 3, 128, false, 1>(p, stream) : launch_v3<8, 16, 3, 3, 128, true, 2>(p, stream);
+    if (kh == 1 && kw == 5) return cfg == 76 ? launch_v3<8, 16, 1, 5, 128, false, 1>(p, stream) : launch_v3<8, 16, 1, 5, 128, true, 2>(p, stream);
+    if (kh == 5 && kw == 1) return cfg == 76 ? launch_v3<16, 8, 5, 1, 128, false, 1>(p, stream) : launch_v3<16, 8, 5, 1, 128, true, 2>(p, stream);
+    return -1000;
+  }
+  if (cfg == 75) {   // diagnostic: phase timing (BN 128)
+    if (kh == 3 && kw == 3) return launch_v3<8, 16, 3, 3, 128, true>(p, stream);
+    if (kh == 1 && kw == 5) return launch_v3<8, 16, 1, 5, 128, true>(p, stream);
+    if (kh == 5 && kw == 1) return launch_v3<16, 8, 5, 1, 128, true>(p, stream);
+    return -1000;
+  }
+  if (kh == 3 && kw == 3) return n64 ? launch_v3<8, 16, 3, 3, 64>(p, stream) : launch_v3<8, 16, 3, 3, 128>(p, stream);
+  if (kh == 1 && kw == 5) return n64 ? launch_v3<8, 16, 1, 5, 64>(p, stream) : launch_v3<8, 16, 1, 5, 128>(p, stream);
+  if (kh == 5 && kw == 1) return n64 ? launch_v3<16, 8, 5, 1, 64>(p, stream) : launch_v3<16, 8, 5, 1, 128>(p, stream);
+  return -1000;
+}
+
+}  // namespace pp
+
+// [diagnostic, not part of the public header] reads and clears the phase counters of the PROF build:
+// out[0..7] = {vmcnt wait, barrier wait, DMA issue, compute, main loop total, epilogue, waves, K steps} (cycles summed over waves)
+extern "C" int pp_debug_conv_prof(unsigned long long* out) {
+  unsigned long long zero[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(pp::g_v3_prof), sizeof(zero));
+  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(pp::g_v3_prof), zero, sizeof(zero));
+  return (int)e;
+}

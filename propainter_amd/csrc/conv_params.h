@@ -30,9 +30,12 @@ struct ConvParams {
   long long M;
   int tiles_m, tiles_n, groups;   // v2 only: 1-D grid decomposition
   int ktable_uniform;             // v2 only: bit 4 / bit 8 set when every 4- / 8-chunk K step is one (tap, source) run
+  int tap_h, tap_w;               // v3 only: rectangular dilation-1 tap window (0 = unknown)
 };
 
 // conv_gemm_v2.hip; returns -1000 when the shape is outside that family (caller falls back to conv_gemm.hip)
 int conv_v2_dispatch(const ConvParams& p, int cfg, hipStream_t stream);
+// conv_gemm_v3.hip (halo tiles); returns -1000 when the shape is outside that family (caller falls back to v2)
+int conv_v3_dispatch(const ConvParams& p, int cfg, hipStream_t stream);
 
 }  // namespace pp

@@ -34,6 +34,7 @@ class ConvArgs(C.Structure):
         ("out", C.c_void_p), ("out_cstride", C.c_int32), ("out_choff", C.c_int32), ("out_cgroup", C.c_int32),
         ("src_gstride", C.c_int64), ("out_gstride", C.c_int64), ("dcn_offmask", C.c_void_p),
         ("dcn_cstride", C.c_int32), ("dcn_mask_off", C.c_int32), ("impl", C.c_int32), ("ktable_uniform", C.c_int32),
+        ("tap_h", C.c_int32), ("tap_w", C.c_int32),
     ]
 
 

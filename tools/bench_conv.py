@@ -123,6 +123,14 @@ def main():
             else:
                 d = (out.float() - ref).abs().max().item()
             print(f"{name:24s} {impl:4d} {ms:9.3f} {flops / ms / 1e9:9.1f} {d:16.3e}", flush=True)
+            if impl in (75, 77):      # phase counters of the PROF build (cycles per wave)
+                import ctypes
+                buf = (ctypes.c_uint64 * 12)()
+                hip.lib().pp_debug_conv_prof(buf)
+                w = max(1, buf[6])
+                print("    per wave: vmcnt-wait %.0f  barrier-wait %.0f  dma-issue %.0f  compute %.0f  | loop %.0f  epilogue %.0f  (K steps %.0f, waves %d)"
+                      % (buf[0] / w, buf[1] / w, buf[2] / w, buf[3] / w, buf[4] / w, buf[5] / w, buf[7] / w, w))
+                print("    epilogue: sync %.0f  acc->lds %.0f  bias/act/store %.0f | setup before loop %.0f" % (buf[8] / w, buf[9] / w, buf[10] / w, buf[11] / w))
 
 
 if __name__ == "__main__":
