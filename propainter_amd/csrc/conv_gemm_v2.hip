@@ -24,7 +24,7 @@
 //     BK=64:  slot = chunk ^ ((row >> 1) & 7)          BK=32:  slot = chunk ^ G[(row >> 2) & 3], G = {0,3,2,1}
 // Zero padding / K padding: out-of-image taps and padding chunks fetch from the all-zero int4 that
 // pp_conv_build_ktable appends after the last table entry (ktable[kchunks]).
-#include "conv_params.h"
+#include "conv_epilogue.h"
 
 namespace pp {
 
@@ -376,76 +376,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_v2_kernel(co
   }
   __syncthreads();                                    // every wave is done with the stages: LDS becomes the epilogue tile
 
-  // ---- epilogue.  Phase 1: accumulators -> this wave's fp32 tile [WM pixels][WN couts] in LDS.
-  float* et = reinterpret_cast<float*>(lds) + wave * (WM * EPI_LD);
-#pragma unroll
-  for (int b = 0; b < TM; ++b)
-#pragma unroll
-    for (int a = 0; a < TN; ++a)
-      *reinterpret_cast<f32x4*>(et + (b * 16 + (lane & 15)) * EPI_LD + a * 16 + (lane >> 4) * 4) = acc[a][b];
-  // (wave-private tile: no block barrier needed, the LDS queue is in order within a wave)
-  // Phase 2: each lane owns 8 consecutive couts of one pixel: bias, activation, residual, 16/32-byte stores.
-  constexpr int LPR = WN / 8 > 0 ? WN / 8 : 1;        // lanes per pixel row
-  constexpr int RPP = 64 / LPR;                       // pixel rows per pass
-  const int out_cbase = p.out_choff + g * p.out_cgroup;
-  const int res_cbase = p.res_choff + g * p.out_cgroup;
-  char* outp = p.out + (long long)g * p.out_gstride * (p.out_f16 ? 2 : 4);
-  const int cl = (lane % LPR) * 8;                    // cout offset inside the wave tile
-  const int co = n0 + wn * WN + cl;                   // first of this lane's 8 couts (within the group)
-  const bool vec_ok = ((p.out_cstride | out_cbase) & 7) == 0;
-  const bool res_vec_ok = ((p.res_cstride | res_cbase) & 7) == 0;
-  float bs[8];
-#pragma unroll
-  for (int r = 0; r < 8; ++r) bs[r] = (p.bias != nullptr && co + r < p.cout_g) ? p.bias[g * p.cout_g + co + r] : 0.f;
-  const int nval = min(8, p.cout_g - co);             // valid couts of this lane (<= 0: nothing to store)
-#pragma unroll 2
-  for (int pass = 0; pass < WM / RPP; ++pass) {
-    const int prow = pass * RPP + lane / LPR;
-    const long long m = m0 + wm * WM + prow;
-    if (m >= p.M || nval <= 0 || (WN < 8 * LPR && cl >= WN)) continue;
-    float v[8];
-    const f32x4 lo = *reinterpret_cast<const f32x4*>(et + prow * EPI_LD + cl);
-    const f32x4 hi = *reinterpret_cast<const f32x4*>(et + prow * EPI_LD + cl + 4);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { v[r] = lo[r]; v[4 + r] = hi[r]; }
-#pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] = apply_act((v[r] + bs[r]) * p.out_scale, p.act, p.act_param);
-    if (p.residual != nullptr) {
-      const T* rp = reinterpret_cast<const T*>(p.residual) + m * p.res_cstride + res_cbase + co;
-      if (nval == 8 && res_vec_ok) {
-        float rv[8];
-        load8<T>(rp, rv);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] += rv[r];
-      } else {
-#pragma unroll
-        for (int r = 0; r < 8; ++r)
-          if (r < nval) v[r] += to_f32(rp[r]);
-      }
+  // ---- epilogue (conv_epilogue.h): wave-private staging tile; 8 consecutive couts (16 B fp16 / 32 B fp32) per lane
+  struct RowMap {
+    long long m_base, M;
+    __device__ __forceinline__ long long operator()(int prow) const {
+      const long long m = m_base + prow;
+      return m < M ? m : -1ll;
     }
-    if (p.act2 == PP_ACT_RELU) {
-#pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
-    }
-    const long long oidx = m * p.out_cstride + out_cbase + co;
-    if (p.out_f16) {
-      _Float16* op = reinterpret_cast<_Float16*>(outp) + oidx;
-      if (nval == 8 && vec_ok) store8<_Float16>(op, v);
-      else {
-#pragma unroll
-        for (int r = 0; r < 8; ++r)
-          if (r < nval) op[r] = (_Float16)v[r];
-      }
-    } else {
-      float* op = reinterpret_cast<float*>(outp) + oidx;
-      if (nval == 8 && ((p.out_cstride | out_cbase) & 3) == 0) store8<float>(op, v);
-      else {
-#pragma unroll
-        for (int r = 0; r < 8; ++r)
-          if (r < nval) op[r] = v[r];
-      }
-    }
-  }
+  };
+  const RowMap rowmap{m0 + wm * WM, p.M};
+  if constexpr (WN >= 16 && WN % 8 == 0)
+    conv_epilogue<WM, WN>(p, acc, lds + wave * (WM * EPI_LD * 4), lane, n0 + wn * WN, g,
+                          p.out + (long long)g * p.out_gstride * (p.out_f16 ? 2 : 4), rowmap);
 #endif
 }
 
