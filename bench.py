@@ -70,6 +70,7 @@ def parse():
     ap.add_argument("--eager", action="store_true",
                     help="issue every launch from Python each step instead of replaying the captured hipGraph of the pass "
                          "(pipeline.ClipGraph); the kernels and their order are identical, only the submission differs")
+    ap.add_argument("--detail", action="store_true", help="split the per-kernel table by convolution layer shape (diagnostic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the instrumented (per-kernel HIP events) step")
     ap.add_argument("--cpu-sample-frames", type=int, default=4)
@@ -234,7 +235,7 @@ def main():
             e = torch.cuda.Event(enable_timing=True)
             e.record()
             marks.append((name, e, time.perf_counter()))
-        with hip.KernelProfiler() as kp:
+        with hip.KernelProfiler(detail=args.detail) as kp:
             t1 = time.perf_counter()
             step(hook)
             torch.cuda.synchronize()

@@ -198,7 +198,11 @@ typedef struct {
   const int32_t* tind;         /* device [n_tind] key frame indices                                */
   const float* wmask;          /* device [B, nW]; > 0 => masked window                             */
   void* out;                   /* [B,T,Hp,Wp,C] (cstride = C), every position written               */
-  int32_t impl;                /* 0 = auto (MFMA for fp16), 1 = force the scalar reference kernel   */
+  int32_t impl;                /* 0 = auto (MFMA for fp16), 1 = force the scalar reference kernel, 6 = grid-mapped MFMA
+                                  launch even when `work` is given                                    */
+  int32_t work_ints;           /* capacity of `work` in int32 elements (>= 1 + B*nW)                */
+  void* work;                  /* optional device scratch: compacted list of masked windows for the persistent,
+                                  load-balanced launch of the masked-window kernel; NULL = grid-mapped launch */
 } pp_attn_args_t;
 
 int pp_sparse_window_attention(const pp_attn_args_t* args, void* stream);

@@ -28,6 +28,7 @@ struct AttnParams {
   const int* own; const int* rolled; const int* tind;
   const float* wmask;
   char* out;
+  const int* work;     // [1 + B*nW]: count of masked windows, then their flat (b*nW + w) ids (attn_compact_kernel)
 };
 
 constexpr int HD = 128;  // head dim
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256) void attn_ref_kernel(const AttnParams p) {
 
 constexpr int KT = 64;          // keys per tile
 constexpr int KS_LD = HD + 8;   // K tile row stride (elements): 272 B rows, conflict-free ds_read_b128 / ds_write_b128
-constexpr int VT_LD = KT + 4;   // V^T tile row stride (elements): 34 dwords -> see the bank notes below
+constexpr int VT_LD = KT + 8;   // V^T tile row stride (elements): 144-byte rows keep the 16-byte fragment reads aligned
 
 // Flash-style MFMA kernel.  256 threads = 4 waves; every wave owns QT tiles of 16 queries (QT = 2 -> 128 queries per
 // block for masked windows, whose long key lists dominate the work; QT = 1 -> 64 >= 45 queries for the per-frame
@@ -106,23 +107,21 @@ constexpr int VT_LD = KT + 4;   // V^T tile row stride (elements): 34 dwords -> 
 // the permutation: accumulator row i of tile dt is channel i*8 + dt, so every lane ends with 8 consecutive channels
 // per query -> 16-byte output stores.  Global loads of tile k+1 are issued before the MFMAs of tile k (register
 // prefetch), hiding the gather latency behind the matrix work.
-template <int QT, bool MASKED>
-__global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnParams p) {
+__device__ unsigned long long g_attn_prof[8];
+
+template <int QT, bool MASKED, bool PROF>
+__device__ __forceinline__ void attn_block(const AttnParams& p, const int b, const int w, const int head, const int yb,
+                                           _Float16* Ks, _Float16* Vt, int* idx_lds, int* tind_lds) {
   typedef _Float16 T;
-  __shared__ __attribute__((aligned(16))) T Ks[KT * KS_LD];
-  __shared__ __attribute__((aligned(16))) T Vt[HD * VT_LD];
-  __shared__ int idx_lds[256];
-  const int head = blockIdx.x % p.heads;
-  const int w = (blockIdx.x / p.heads) % p.nW;
-  const int b = blockIdx.x / (p.heads * p.nW);
-  const bool masked = p.wmask[b * p.nW + w] > 0.f;
-  if (masked != MASKED) return;                                // the other instantiation owns this window
   constexpr int QB = 64 * QT;                                  // queries per block
   const int nq_total = p.T * p.wsz;
-  if (MASKED && (int)blockIdx.y * QB >= nq_total) return;      // masked windows need ceil(T*45/QB) blocks only
-  if (!MASKED && (int)blockIdx.y >= p.T) return;
+  if (MASKED && yb * QB >= nq_total) return;                   // masked windows need ceil(T*45/QB) blocks only
+  if (!MASKED && yb >= p.T) return;
   const int ngrid = p.wsz + p.n_rolled;
   for (int i = threadIdx.x; i < ngrid; i += 256) idx_lds[i] = i < p.wsz ? p.own[w * p.wsz + i] : p.rolled[w * p.n_rolled + i - p.wsz];
+  // key frames in LDS: a global tind[] read inside the tile loop put a dependent load (and, vmcnt being in-order, a
+  // drain of the whole K/V prefetch) in front of every gather -- 6.5 k of the 10.7 k cycles per tile (tools/bench_attn.py)
+  if (MASKED && threadIdx.x < p.n_tind) tind_lds[threadIdx.x] = p.tind[threadIdx.x];
   __syncthreads();
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -141,13 +140,13 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnParams p) {
     const int ql = (wave * QT + qt) * 16 + (lane & 15);
     int fq, tok;
     if (MASKED) {
-      const int qi = blockIdx.y * QB + ql;
+      const int qi = yb * QB + ql;
       qvalid[qt] = qi < nq_total;
       fq = qvalid[qt] ? qi / p.wsz : 0;
       tok = qvalid[qt] ? qi % p.wsz : 0;
     } else {
       qvalid[qt] = ql < p.wsz;
-      fq = blockIdx.y;
+      fq = yb;
       tok = qvalid[qt] ? ql : 0;
     }
     qoff[qt] = ((long long)b * p.T + fq) * p.Hp * p.Wp + idx_lds[tok];
@@ -158,10 +157,11 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnParams p) {
       else qf[qt][s] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
     }
   }
-  const int kpf = MASKED ? ngrid + p.P : p.wsz;
-  const int nkeys = MASKED ? p.n_tind * kpf : p.wsz;
-  const float scale = rsqrtf((float)HD);
-  const int frame_blk = blockIdx.y;   // key frame of an unmasked window's block
+  const int kpf = MASKED ? ngrid + p.P : p.wsz;                // keys per key frame
+  const int tpf = (kpf + KT - 1) / KT;                         // 64-key tiles per frame (the last one is partial: masked out)
+  const int ntiles = (MASKED ? p.n_tind : 1) * tpf;
+  const float sc2 = rsqrtf((float)HD) * 1.4426950408889634f;   // softmax scale folded with log2(e)
+  const int frame_blk = yb;   // key frame of an unmasked window's block
 
   f32x4 oacc[QT][8];
   float m_run[QT], l_run[QT];
@@ -176,20 +176,27 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnParams p) {
   // ---- tile staging: 64 keys x 16 chunks of 8 channels; 16 consecutive lanes read one 256-byte key row
   // (coalesced); rows past the key list are zero.
   u32x4 kr[4], vr[4];
-  auto load_tile = [&](int k0) {
+  // (strides copied into registers: selecting between p.qkv_cs and p.pkv_cs per lane made hipcc fetch the kernel-argument
+  // field with a *vector* load in front of every gather -- a dependent load + vmcnt(0) drain per K/V row, 5 k cycles a tile)
+  const long long qkv_cs = p.qkv_cs, pkv_cs = p.pkv_cs;
+  const long long frame_tok = (long long)p.Hp * p.Wp, frame_pool = p.P;
+  const int hoff = head * HD;
+  auto load_tile = [&](int fi, int r0) {                       // keys r0 .. r0+63 of key frame #fi (no division, no global index reads)
+    const int f = MASKED ? tind_lds[fi] : frame_blk;
+    const long long bf = (long long)b * p.T + f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int c = tid + 256 * i;
       const int key = c >> 4, dch = c & 15;
-      const int kk = k0 + key;
+      const int r = r0 + key;
       kr[i] = u32x4{0, 0, 0, 0};
       vr[i] = u32x4{0, 0, 0, 0};
-      if (kk < nkeys) {
-        const int fi = MASKED ? kk / kpf : 0;
-        const int f = MASKED ? p.tind[fi] : frame_blk;
-        const int r = MASKED ? kk - fi * kpf : kk;
-        kr[i] = *reinterpret_cast<const u32x4*>(key_row<T>(p, kg, pkg, b, f, r, idx_lds, head) + dch * 8);
-        vr[i] = *reinterpret_cast<const u32x4*>(key_row<T>(p, vg, pvg, b, f, r, idx_lds, head) + dch * 8);
+      if (r < kpf) {
+        const bool grid = r < ngrid;
+        const long long row = grid ? bf * frame_tok + idx_lds[grid ? r : 0] : bf * frame_pool + (r - ngrid);
+        const long long eoff = row * (grid ? qkv_cs : pkv_cs) + hoff + dch * 8;
+        kr[i] = *reinterpret_cast<const u32x4*>((grid ? kg : pkg) + eoff);
+        vr[i] = *reinterpret_cast<const u32x4*>((grid ? vg : pvg) + eoff);
       }
     }
   };
@@ -200,16 +207,28 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnParams p) {
       const int key = c >> 4, dch = c & 15;
       *reinterpret_cast<u32x4*>(&Ks[key * KS_LD + dch * 8]) = kr[i];
       const T* ve = reinterpret_cast<const T*>(&vr[i]);
+      // key column permuted so that the 8 keys one lane feeds to a PV MFMA (32j + g*4 + {0..3} and 32j + 16 + g*4 + {0..3})
+      // are 16 contiguous bytes: slot = 32j + g*8 + hi*4 + i for key = 32j + hi*16 + g*4 + i  -> one ds_read_b128 per fragment
+      const int kslot = (key & 32) | ((key & 12) << 1) | ((key & 16) >> 2) | (key & 3);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) Vt[(j * 16 + dch) * VT_LD + key] = ve[j];      // channel dch*8 + j -> row j*16 + dch
+      for (int j = 0; j < 8; ++j) Vt[(j * 16 + dch) * VT_LD + kslot] = ve[j];    // channel dch*8 + j -> row j*16 + dch
     }
   };
 
-  load_tile(0);
-  for (int k0 = 0; k0 < nkeys; k0 += KT) {
+  unsigned long long pf[6] = {0, 0, 0, 0, 0, 0}, ta = 0, tb = 0;
+  load_tile(0, 0);
+  int fi_n = 0, r0_n = 0;                                       // position of the tile being prefetched
+  for (int ti = 0; ti < ntiles; ++ti) {
+    const int r0 = r0_n;                                        // first key (within its frame) of the tile consumed now
+    r0_n += KT;
+    if (r0_n >= kpf) { r0_n = 0; ++fi_n; }
+    if constexpr (PROF) ta = __builtin_readcyclecounter();
     store_tile();
+    if constexpr (PROF) { tb = __builtin_readcyclecounter(); pf[0] += tb - ta; }
     __syncthreads();
-    if (k0 + KT < nkeys) load_tile(k0 + KT);          // in flight during the MFMAs below
+    if constexpr (PROF) { ta = __builtin_readcyclecounter(); pf[1] += ta - tb; }
+    if (ti + 1 < ntiles) load_tile(fi_n, r0_n);         // in flight during the MFMAs below
+    if constexpr (PROF) { tb = __builtin_readcyclecounter(); pf[2] += tb - ta; }
 
     // ---- S^T tiles: sacc[qt][kt][r] = score(key = k0 + kt*16 + (lane>>4)*4 + r, query = lane&15 of tile qt)
     f32x4 sacc[QT][4];
@@ -225,56 +244,72 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnParams p) {
         for (int qt = 0; qt < QT; ++qt) sacc[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qt][s], sacc[qt][kt], 0, 0, 0);
       }
     }
-    // ---- online softmax per query tile
-    f16x8 pf[QT][2];
+    if constexpr (PROF) { ta = __builtin_readcyclecounter(); pf[3] += ta - tb; }
+    // ---- online softmax per query tile, in the exp2 domain: p = 2^(s*c - m), c = scale*log2(e), m = running max of s*c.
+    // (one fma + one v_exp per score; the key-validity mask only on the partial last tile of a frame; the accumulator
+    // rescale only when some lane's running max actually moved)
+    f16x8 pfr[QT][2];
+    const bool partial = r0 + KT > kpf;                       // wave-uniform
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-      float tmax = -1e30f;
+      if (partial) {
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (r0 + kt * 16 + (lane >> 4) * 4 + r >= kpf) sacc[qt][kt][r] = -1e30f;
+      }
+      float tmax = sacc[qt][0][0];
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int kk = k0 + kt * 16 + (lane >> 4) * 4 + r;
-          const float sv = kk < nkeys ? sacc[qt][kt][r] * scale : -1e30f;
-          sacc[qt][kt][r] = sv;
-          tmax = fmaxf(tmax, sv);
-        }
+        for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, sacc[qt][kt][r]);
       tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
       tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-      const float m_new = fmaxf(m_run[qt], tmax);
-      const float alpha = __expf(m_run[qt] - m_new);
-      m_run[qt] = m_new;
+      const float m_new = fmaxf(m_run[qt], tmax * sc2);
+      const bool moved = m_new > m_run[qt];
       float psum = 0.f;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float e = __expf(sacc[qt][kt][r] - m_new);
+          const float e = __builtin_amdgcn_exp2f(fmaf(sacc[qt][kt][r], sc2, -m_new));
           psum += e;
-          pf[qt][kt >> 1][(kt & 1) * 4 + r] = (_Float16)e;
+          pfr[qt][kt >> 1][(kt & 1) * 4 + r] = (_Float16)e;
         }
-      l_run[qt] = l_run[qt] * alpha + psum;     // per-lane partial; the 4 lane groups are summed at the end
+      if (__builtin_amdgcn_ballot_w64(moved) != 0ull) {       // wave-uniform: rare after the first tiles
+        const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
+        l_run[qt] *= alpha;
 #pragma unroll
-      for (int dt = 0; dt < 8; ++dt) {
+        for (int dt = 0; dt < 8; ++dt) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) oacc[qt][dt][r] *= alpha;
+          for (int r = 0; r < 4; ++r) oacc[qt][dt][r] *= alpha;
+        }
       }
+      m_run[qt] = m_new;
+      l_run[qt] += psum;                        // per-lane partial; the 4 lane groups are summed at the end
     }
+    if constexpr (PROF) { tb = __builtin_readcyclecounter(); pf[4] += tb - ta; }
     // ---- O^T += V^T P^T : k-slot (lane>>4)*8 + i of step j <-> key 32j + (i>>2)*16 + (lane>>4)*4 + (i&3);
     // accumulator row i of tile dt is channel i*8 + dt (row permutation of the V^T image)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
 #pragma unroll
       for (int dt = 0; dt < 8; ++dt) {
-        const T* vp = &Vt[(dt * 16 + (lane & 15)) * VT_LD + 32 * j + (lane >> 4) * 4];
-        const f16x4 lo = *reinterpret_cast<const f16x4*>(vp);
-        const f16x4 hi = *reinterpret_cast<const f16x4*>(vp + 16);
-        const f16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const f16x8 vf = *reinterpret_cast<const f16x8*>(&Vt[(dt * 16 + (lane & 15)) * VT_LD + 32 * j + (lane >> 4) * 8]);
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt) oacc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qt][j], oacc[qt][dt], 0, 0, 0);
+        for (int qt = 0; qt < QT; ++qt) oacc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pfr[qt][j], oacc[qt][dt], 0, 0, 0);
       }
     }
+    if constexpr (PROF) { ta = __builtin_readcyclecounter(); pf[5] += ta - tb; }
     __syncthreads();
+  }
+  if constexpr (PROF) {
+    if (lane == 0 && (blockIdx.x & 15) == 3) {
+      for (int i = 0; i < 6; ++i) atomicAdd(&g_attn_prof[i], pf[i]);
+      atomicAdd(&g_attn_prof[6], 1ull);
+      atomicAdd(&g_attn_prof[7], (unsigned long long)ntiles);
+    }
   }
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
@@ -294,6 +329,59 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnParams p) {
       }
     }
   }
+}
+
+// Grid-mapped launch: blockIdx.x = (b, window, head), blockIdx.y = query block / frame.  The masked / unmasked decision is
+// a device flag, so blocks of the other kind exit at once.
+template <int QT, bool MASKED, bool PROF = false>
+__global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnParams p) {
+  __shared__ __attribute__((aligned(16))) _Float16 Ks[KT * KS_LD];
+  __shared__ __attribute__((aligned(16))) _Float16 Vt[HD * VT_LD];
+  __shared__ int idx_lds[256];
+  __shared__ int tind_lds[64];
+  const int head = blockIdx.x % p.heads;
+  const int w = (blockIdx.x / p.heads) % p.nW;
+  const int b = blockIdx.x / (p.heads * p.nW);
+  const bool masked = p.wmask[b * p.nW + w] > 0.f;
+  if (masked != MASKED) return;                                // the other instantiation owns this window
+  attn_block<QT, MASKED, PROF>(p, b, w, head, (int)blockIdx.y, Ks, Vt, idx_lds, tind_lds);
+}
+
+// Persistent launch for the masked windows (the long key lists: ~all of the attention time).  With the grid-mapped
+// launch the working blocks (25 % of the grid at the benchmark mask) land unevenly on the CUs and the slowest CU runs 3
+// rounds where 2 would do.  Here a compacted list of masked windows (attn_compact_kernel) is walked by 2 blocks per CU with a
+// fixed stride; consecutive items are the query blocks of one (window, head), so they share their K/V rows in L2.
+template <int QT, bool PROF = false>
+__global__ __launch_bounds__(256, 2) void attn_mfma_persistent_kernel(const AttnParams p, const int gy) {
+  __shared__ __attribute__((aligned(16))) _Float16 Ks[KT * KS_LD];
+  __shared__ __attribute__((aligned(16))) _Float16 Vt[HD * VT_LD];
+  __shared__ int idx_lds[256];
+  __shared__ int tind_lds[64];
+  const int total = p.work[0] * p.heads * gy;
+  for (int item = blockIdx.x; item < total; item += gridDim.x) {
+    const int yb = item % gy;
+    const int wh = item / gy;
+    const int head = wh % p.heads;
+    const int bw = p.work[1 + wh / p.heads];
+    attn_block<QT, true, PROF>(p, bw / p.nW, bw % p.nW, head, yb, Ks, Vt, idx_lds, tind_lds);
+    __syncthreads();                                           // the LDS tables are rewritten by the next item
+  }
+}
+
+// work[0] = number of masked windows, work[1..] = their flat ids, ascending (one block; B*nW is a few hundred)
+__global__ void attn_compact_kernel(const float* __restrict__ wmask, int n, int* __restrict__ work) {
+  __shared__ int cnt[256];
+  const int tid = threadIdx.x;
+  const int per = (n + 255) / 256;
+  int c = 0;
+  for (int i = tid * per; i < min(n, (tid + 1) * per); ++i) c += wmask[i] > 0.f;
+  cnt[tid] = c;
+  __syncthreads();
+  int base = 0;
+  for (int i = 0; i < tid; ++i) base += cnt[i];
+  for (int i = tid * per; i < min(n, (tid + 1) * per); ++i)
+    if (wmask[i] > 0.f) work[1 + base++] = i;
+  if (tid == 255) work[0] = base;
 }
 
 // wmask[b, w] = sum_lt max_{window} mask   (one thread per (b, w))
@@ -381,7 +469,7 @@ extern "C" int pp_sparse_window_attention(const pp_attn_args_t* a, void* stream)
   PP_REQUIRE(a->wh * a->ww + a->n_rolled <= 256 && a->wh * a->ww <= 64, PP_ERR_ARG, "pp_sparse_window_attention: window too large");
   PP_REQUIRE(a->q && a->k && a->v && a->own && a->rolled && a->tind && a->wmask && a->out && (a->P == 0 || (a->pk && a->pv)),
              PP_ERR_ARG, "pp_sparse_window_attention: null pointer");
-  PP_REQUIRE(a->n_tind > 0 && a->n_tind <= a->T, PP_ERR_ARG, "pp_sparse_window_attention: n_tind %d", a->n_tind);
+  PP_REQUIRE(a->n_tind > 0 && a->n_tind <= a->T && a->n_tind <= 64, PP_ERR_ARG, "pp_sparse_window_attention: n_tind %d (1..min(T, 64))", a->n_tind);
   const int esz = a->dtype == PP_F16 ? 2 : 4;
   PP_REQUIRE((a->qkv_cstride * esz) % 16 == 0 && (a->pkv_cstride * esz) % 16 == 0 && (uintptr_t)a->q % 16 == 0 &&
                  (uintptr_t)a->k % 16 == 0 && (uintptr_t)a->v % 16 == 0 && (uintptr_t)a->out % 16 == 0,
@@ -391,14 +479,30 @@ extern "C" int pp_sparse_window_attention(const pp_attn_args_t* a, void* stream)
   p.n_rolled = a->n_rolled; p.P = a->P; p.n_tind = a->n_tind; p.nW = (a->Hp / a->wh) * (a->Wp / a->ww);
   p.q = (const char*)a->q; p.k = (const char*)a->k; p.v = (const char*)a->v; p.qkv_cs = a->qkv_cstride;
   p.pk = (const char*)a->pk; p.pv = (const char*)a->pv; p.pkv_cs = a->pkv_cstride;
-  p.own = a->own; p.rolled = a->rolled; p.tind = a->tind; p.wmask = a->wmask; p.out = (char*)a->out;
+  p.own = a->own; p.rolled = a->rolled; p.tind = a->tind; p.wmask = a->wmask; p.out = (char*)a->out; p.work = nullptr;
   hipStream_t st = (hipStream_t)stream;
   const unsigned gx = (unsigned)(p.B * p.nW * p.heads);
   if (a->dtype == PP_F16 && a->impl != 1) {
     // masked windows: 128-query blocks over the window's T*45 queries; unmasked: one 64-query block per frame.  Both
     // grids cover every window; blocks of the wrong kind return immediately (device-side flag, no host sync).
     const unsigned gy_m = (unsigned)((p.T * p.wsz + 127) / 128);
-    hipLaunchKernelGGL((attn_mfma_kernel<2, true>), dim3(gx, gy_m), dim3(256), 0, st, p);
+    if (a->work != nullptr && a->impl != 6) {
+      PP_REQUIRE(a->work_ints >= 1 + p.B * p.nW, PP_ERR_WORKSPACE, "pp_sparse_window_attention: work needs %d ints, got %d", 1 + p.B * p.nW,
+                 a->work_ints);
+      p.work = (const int*)a->work;
+      hipLaunchKernelGGL(attn_compact_kernel, dim3(1), dim3(256), 0, st, p.wmask, p.B * p.nW, (int*)a->work);
+      static int n_cu = 0;
+      if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+      }
+      if (a->impl == 5) hipLaunchKernelGGL((attn_mfma_persistent_kernel<2, true>), dim3(2 * n_cu), dim3(256), 0, st, p, (int)gy_m);
+      else hipLaunchKernelGGL((attn_mfma_persistent_kernel<2>), dim3(2 * n_cu), dim3(256), 0, st, p, (int)gy_m);
+    } else {
+      hipLaunchKernelGGL((attn_mfma_kernel<2, true>), dim3(gx, gy_m), dim3(256), 0, st, p);
+    }
     hipLaunchKernelGGL((attn_mfma_kernel<1, false>), dim3(gx, (unsigned)p.T), dim3(256), 0, st, p);
   } else {
     const unsigned gy = (unsigned)((p.T * p.wsz + 3) / 4);
@@ -406,4 +510,13 @@ extern "C" int pp_sparse_window_attention(const pp_attn_args_t* a, void* stream)
     else hipLaunchKernelGGL((attn_ref_kernel<float>), dim3(gx, gy), dim3(256), 0, st, p);
   }
   return launch_status("pp_sparse_window_attention");
+}
+
+// [diagnostic] phase counters of attn_mfma_kernel<2, true, PROF>: {store_tile, barrier, load issue, S mfma, softmax, PV mfma,
+// waves, tiles} (cycles summed over the sampled waves); read-and-clear.
+extern "C" int pp_debug_attn_prof(unsigned long long* out) {
+  unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(pp::g_attn_prof), sizeof(zero));
+  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(pp::g_attn_prof), zero, sizeof(zero));
+  return (int)e;
 }

@@ -45,7 +45,7 @@ class AttnArgs(C.Structure):
         ("P", C.c_int32), ("n_tind", C.c_int32), ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p),
         ("qkv_cstride", C.c_int32), ("pk", C.c_void_p), ("pv", C.c_void_p), ("pkv_cstride", C.c_int32),
         ("own", C.c_void_p), ("rolled", C.c_void_p), ("tind", C.c_void_p), ("wmask", C.c_void_p),
-        ("out", C.c_void_p), ("impl", C.c_int32),
+        ("out", C.c_void_p), ("impl", C.c_int32), ("work_ints", C.c_int32), ("work", C.c_void_p),
     ]
 
 
@@ -87,8 +87,9 @@ class KernelProfiler:
     pair of HIP events recorded on the stream the kernel is launched on (torch's current stream) and tagged with its
     algorithmic FLOPs / bytes.  ``summary()`` synchronises and aggregates per class."""
 
-    def __init__(self):
+    def __init__(self, detail=False):
         self.records = []          # (name, flops, bytes, ev0, ev1)
+        self.detail = detail       # split the convolution classes by layer shape
 
     def __enter__(self):
         global _profiler
@@ -218,6 +219,8 @@ def conv2d_raw(args: ConvArgs, cin_read=None):
     if args.dcn_offmask:
         nbytes += M * 432 * esz
     name = "conv_gemm_dcn" if args.dcn_offmask else ("conv_gemm_f16" if args.dtype == PP_F16 else "conv_gemm_f32")
+    if _profiler is not None and getattr(_profiler, "detail", False):      # per-layer-shape classes (bench.py --detail)
+        name += f" | taps{args.tap_h}x{args.tap_w} s{args.stride_h} K{K} cout{args.cout_g}x{args.groups} M{M} {args.H}x{args.W}"
     timed(name, flops, nbytes, lambda: _check(lib().pp_conv2d(C.byref(args), _stream()), "pp_conv2d"))
 
 
@@ -320,6 +323,8 @@ def sparse_window_attention(q, k, v, pk, pv, own, rolled, tind, wmask, heads=4, 
     out = torch.empty((B, T, Hp, Wp, C_), dtype=q.dtype, device=q.device)
     a.out = out.data_ptr()
     a.impl = impl
+    work = torch.empty((1 + B * wmask.shape[-1],), dtype=torch.int32, device=q.device)   # compacted masked-window list
+    a.work, a.work_ints = work.data_ptr(), work.numel()
     for t in (q, k, v, own, rolled, tind, wmask):
         if not t.is_cuda:
             raise RuntimeError("sparse_window_attention needs GPU tensors")
