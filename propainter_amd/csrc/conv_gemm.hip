@@ -110,24 +110,28 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
   float a_w[A_ROWS][DEFORM ? 4 : 1];   // deform: corner weights (already times modulation mask)
   Chunk<T> b_reg[B_ROWS];
 
-  auto src_ptr = [&](int s, int& cstride, int& cbase) -> const T* {
-    const ConvSrc& S = p.src[s];   // s is wave-divergent only across the 4 chunks; select chain keeps SGPRs
-    cstride = S.cstride;
-    cbase = S.choff + g * S.cgroup;
-    return reinterpret_cast<const T*>(S.ptr) + (long long)g * p.src_gstride;
-  };
+  // Per-source base / stride / channel base in registers.  (Selecting `p.src[s]` with the per-lane source id made hipcc
+  // fetch the kernel-argument fields with VECTOR loads inside the K loop -- a dependent load and a vmcnt(0) drain in
+  // front of every gather; the same pathology cost the attention kernel 5 k cycles per tile.)
+  const T* sp_[PP_CONV_MAX_SRC];
+  int cs_[PP_CONV_MAX_SRC], cb_[PP_CONV_MAX_SRC];
+#pragma unroll
+  for (int i = 0; i < PP_CONV_MAX_SRC; ++i) {
+    sp_[i] = reinterpret_cast<const T*>(p.src[i].ptr) + (long long)g * p.src_gstride;
+    cs_[i] = p.src[i].cstride;
+    cb_[i] = p.src[i].choff + g * p.src[i].cgroup;
+  }
+  const int imgH = p.H, imgW = p.W, pad_mode = p.pad_mode;
 
   auto issue_loads = [&](int ks) {
     const int4 e = p.ktable[ks * 4 + chunk];
     const int s = e.z & 0xff;
     int cstride = 0, cbase = 0;
     const T* sp = nullptr;
-    if (s != 255) {
-      // explicit select over the (<= 4) sources
-      if (s == 0) sp = src_ptr(0, cstride, cbase);
-      else if (s == 1) sp = src_ptr(1, cstride, cbase);
-      else if (s == 2) sp = src_ptr(2, cstride, cbase);
-      else sp = src_ptr(3, cstride, cbase);
+    if (s != 255) {      // value selects over the (<= 4) sources: v_cndmask, no memory access
+      sp = s == 0 ? sp_[0] : s == 1 ? sp_[1] : s == 2 ? sp_[2] : sp_[3];
+      cstride = s == 0 ? cs_[0] : s == 1 ? cs_[1] : s == 2 ? cs_[2] : cs_[3];
+      cbase = s == 0 ? cb_[0] : s == 1 ? cb_[1] : s == 2 ? cb_[2] : cb_[3];
     }
 #pragma unroll
     for (int i = 0; i < A_ROWS; ++i) {

@@ -42,9 +42,9 @@ template <int TH, int TW, int KH, int KW, int BN, bool PROF = false, int STAGGER
 __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef _Float16 T;
-  constexpr int NW = 4, WAVES_N = 2;
+  constexpr int NW = 4, WAVES_N = BN >= 32 ? 2 : 1, WAVES_M = NW / WAVES_N;   // BN 16 (tiny cout): 4 waves along the pixels
   constexpr int BM = TH * TW;
-  constexpr int WM = BM / 2, WN = BN / WAVES_N;
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 16, TN = WN / 16;
   constexpr int PH = TH + KH - 1, PW = TW + KW - 1, P = PH * PW;
   constexpr int NTAPS = KH * KW;
@@ -52,12 +52,14 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p) {
   constexpr int PPW = PIECES / NW;                              // ... per wave
   constexpr int PATCH_BYTES = PIECES * 1024;
   constexpr int BSTAGE = BN * 128;
-  constexpr int B_PER_WAVE = BN / 8 / NW;
+  constexpr int B_INST = BN / 8;                               // weight-tile DMA instructions per stage (8 rows each)
+  constexpr int B_PER_WAVE = (B_INST + NW - 1) / NW;
+  constexpr bool B_RAGGED = (B_INST % NW) != 0;                 // BN 16: only waves 0..B_INST-1 fetch weights
   constexpr int PIPE_BYTES = 2 * PATCH_BYTES + 2 * BSTAGE;
   constexpr int EPI_LD = WN + 4;
   constexpr int EPI_BYTES = NW * WM * EPI_LD * 4;
   constexpr int LDS_BYTES = PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES;
-  static_assert(BM == 128 && (TW == 16 || TW == 8) && PPW <= NTAPS && BN % 32 == 0 && LDS_BYTES <= 80 * 1024, "tile");
+  static_assert(BM == 128 && (TW == 16 || TW == 8) && PPW <= NTAPS && (BN % 32 == 0 || BN == 16) && LDS_BYTES <= 80 * 1024, "tile");
 
   __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
   unsigned long long pf_start = 0;
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
   // ---- XCD-aware block order (as v2): each XCD gets a contiguous run of tiles, couts fastest
   int bid = blockIdx.x;
@@ -127,7 +129,8 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p) {
 #define V3_ISSUE_B(ks_, par_)                                                                                   \
   do {                                                                                                          \
     _Pragma("unroll") for (int j_ = 0; j_ < B_PER_WAVE; ++j_)                                                   \
-      v3_dma16(rw, bst0 + (par_) * BSTAGE + (j_ * NW + wave) * 1024, wvoff[j_], (ks_) * 128);                   \
+      if (!B_RAGGED || j_ * NW + wave < B_INST)                                                                 \
+        v3_dma16(rw, bst0 + (par_) * BSTAGE + (j_ * NW + wave) * 1024, wvoff[j_], (ks_) * 128);                 \
   } while (0)
 
   f32x4 acc[TN][TM];
@@ -266,8 +269,14 @@ int conv_v3_dispatch(const ConvParams& p, int cfg, hipStream_t stream) {
   if ((long long)p.cout_pad * p.kchunks * 16 >= (1ll << 31)) return -1000;
   for (int i = 0; i < p.nsrc; ++i)
     if ((long long)p.N * p.H * p.W * p.src[i].cstride * 2 >= (1ll << 31)) return -1000;
-  if (cfg == 0 && (p.cout_g < 48 || p.H < 8 || p.W < 8)) return -1000;      // tiny couts / maps: v2's narrow tiles do better
+  if (cfg == 0 && ((p.cout_g > 16 && p.cout_g < 48) || p.H < 8 || p.W < 8)) return -1000;      // 17..47 couts / tiny maps: v2's narrow tiles do better
   const bool n64 = cfg == 72 || (cfg != 71 && p.cout_g <= 64);
+  if (cfg == 73 || (cfg == 0 && p.cout_g <= 16)) {   // tiny cout (flow head, RGB decoder): A-bandwidth bound, halo tiles cut the gather 6x
+    if (kh == 3 && kw == 3) return launch_v3<8, 16, 3, 3, 16>(p, stream);
+    if (kh == 1 && kw == 5) return launch_v3<8, 16, 1, 5, 16>(p, stream);
+    if (kh == 5 && kw == 1) return launch_v3<16, 8, 5, 1, 16>(p, stream);
+    return -1000;
+  }
   if (cfg == 76 || cfg == 77) {   // staggered start (76) / + phase timing (77)
     if (kh == 3 && kw == 3) return cfg == 76 ? launch_v3<8, 16, 3, 3, 128, false, 1>(p, stream) : launch_v3<8, 16, 3, 3, 128, true, 2>(p, stream);
     if (kh == 1 && kw == 5) return cfg == 76 ? launch_v3<8, 16, 1, 5, 128, false, 1>(p, stream) : launch_v3<8, 16, 1, 5, 128, true, 2>(p, stream);
