@@ -78,7 +78,16 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
   const int wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int g = blockIdx.z;
-  const long long m0 = (long long)blockIdx.x * BM;
+  // XCD-aware tile order (as the LDS-DMA kernels): consecutive block ids go round-robin over the 8 XCDs, so give each
+  // XCD a contiguous run of M tiles -- the deformable gather of a tile then finds its neighbourhood in that XCD's L2
+  // (PMC: 1.2 GB of fabric traffic per 79 MB-algorithmic launch without this).
+  int bx = blockIdx.x;
+  if (gridDim.y == 1 && gridDim.z == 1) {
+    const int nblk = gridDim.x;
+    const int q = nblk >> 3, r = nblk & 7, xcd = bx & 7, loc = bx >> 3;
+    bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const long long m0 = (long long)bx * BM;
   const int n0 = blockIdx.y * BN;
 
   // ---- per-thread gather state: A rows (tid>>2) + 64*i, chunk (tid&3) of every 32-wide k step

@@ -220,7 +220,7 @@ class ClipGraph:
         out_u8 = g(frames_u8, flow_masks_u8, masks_dilated_u8)   # uint8 [L,H,W,3] on device (static buffer)
     """
 
-    def __init__(self, models, L, H, W, cfg: InferenceConfig, device, example=None):
+    def __init__(self, models, L, H, W, cfg: InferenceConfig, device, example=None, release_eager_pool=False):
         self.shape = (L, H, W)
         self.frames = torch.zeros((L, H, W, 3), dtype=torch.uint8, device=device)
         self.flow_masks = torch.zeros((L, H, W), dtype=torch.uint8, device=device)
@@ -234,7 +234,8 @@ class ClipGraph:
             run()
         torch.cuda.current_stream(device).wait_stream(side)
         torch.cuda.synchronize(device)
-        torch.cuda.empty_cache()                 # hand the eager pass's cached blocks back before the graph pool grows
+        if release_eager_pool:                   # hand the eager pass's cached blocks back before the graph pool grows
+            torch.cuda.empty_cache()             # (default: keep them -- 288 GB holds both pools and later eager passes stay warm)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = run()

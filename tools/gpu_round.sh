@@ -10,6 +10,7 @@ if [ -z "$SKIP_TESTS" ]; then
   echo "pytest exit $?" >> gpurun_out/pytest_gpu.log
   tail -30 gpurun_out/pytest_gpu.log
 fi
+timeout 300 python __graft_entry__.py --smoke > gpurun_out/smoke.log 2>&1; echo "smoke exit $?"; tail -2 gpurun_out/smoke.log
 timeout 900 python bench.py --steps 2 --warmup 1 $BENCH_ARGS > gpurun_out/bench_720.json 2> gpurun_out/bench_720.err
 echo "720p exit $?"; python - <<'PY'
 import json
@@ -24,10 +25,10 @@ PY
 tail -5 gpurun_out/bench_720.err
 if [ -z "$SKIP_PROF" ]; then
   cd /tmp && export TMPDIR=/tmp
-  CMD="python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile $BENCH_ARGS"
+  CMD="python $R/bench.py --eager --steps 1 --warmup 0 --no-cpu-baseline --no-profile $BENCH_ARGS"
   timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_trace --output-format csv -- $CMD > $R/gpurun_out/prof_trace.log 2>&1
   echo "trace exit $?"
-  CMD1="python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile $BENCH_ARGS"
+  CMD1="python $R/bench.py --eager --steps 1 --warmup 0 --no-cpu-baseline --no-profile $BENCH_ARGS"
   timeout 600 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/pmc_fetch --output-format csv -- $CMD1 > $R/gpurun_out/pmc_fetch.log 2>&1
   echo "pmc fetch exit $?"
   timeout 600 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/pmc_write --output-format csv -- $CMD1 > $R/gpurun_out/pmc_write.log 2>&1

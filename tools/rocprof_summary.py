@@ -18,11 +18,15 @@ import json
 import re
 import sys
 
-FAMILIES = [
+FAMILIES = [   # (substring of the demangled OR mangled kernel name, family)
+    ("conv_halo_kernel", "conv_gemm_f16 (LDS-DMA implicit GEMM)"),
     ("conv_gemm_v2_kernel", "conv_gemm_f16 (LDS-DMA implicit GEMM)"),
     ("conv_gemm_kernel<_Float16", "conv_gemm_f16/dcn (register-staged)"),
+    ("conv_gemm_kernelIDF16_", "conv_gemm_f16/dcn (register-staged)"),
     ("conv_gemm_kernel<float", "conv_gemm_f32"),
-    ("attn_mfma_kernel", "sparse_window_attention"),
+    ("conv_gemm_kernelIf", "conv_gemm_f32"),
+    ("attn_mfma", "sparse_window_attention"),
+    ("attn_compact", "sparse_window_attention"),
     ("attn_ref_kernel", "sparse_window_attention (scalar)"),
     ("fold_tokens_kernel", "fold_tokens"),
     ("corr_lookup", "corr_lookup"),
