@@ -99,6 +99,43 @@ __global__ void depthwise_pool_kernel(const T* __restrict__ in, const float* __r
   }
 }
 
+// Vectorised variant (C % 8 == 0, k*k*C floats of weights fit LDS): one thread per (output pixel, 8 channels), 16-byte
+// input loads, weights staged once per block in LDS as [tap][C] so a thread reads its 8 weights with two ds_read_b128.
+// Same accumulation order (bias, then taps in row-major order) as the scalar kernel: identical results.
+template <typename T>
+__global__ __launch_bounds__(256) void depthwise_pool8_kernel(const T* __restrict__ in, const float* __restrict__ wgt,
+                                                              const float* __restrict__ bias, T* __restrict__ out, int N, int H,
+                                                              int W, int C, int k) {
+  extern __shared__ float wl[];                       // [k*k][C]
+  const int kk = k * k;
+  for (int i = threadIdx.x; i < kk * C; i += blockDim.x) {
+    const int c = i / kk, t = i - c * kk;
+    wl[t * C + c] = wgt[i];
+  }
+  __syncthreads();
+  const int OH = H / k, OW = W / k, c8 = C / 8;
+  const long long total = (long long)N * OH * OW * c8;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % c8);
+    const long long pix = i / c8;
+    const int ox = (int)(pix % OW), oy = (int)((pix / OW) % OH);
+    const long long n = pix / ((long long)OW * OH);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = bias ? bias[cc * 8 + j] : 0.f;
+    for (int ky = 0; ky < k; ++ky)
+      for (int kx = 0; kx < k; ++kx) {
+        float v[8];
+        load8<T>(in + ((n * H + oy * k + ky) * (long long)W + ox * k + kx) * C + cc * 8, v);
+        const float* wp = wl + (ky * k + kx) * C + cc * 8;
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wp), w1 = *reinterpret_cast<const f32x4*>(wp + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[j] += w0[j] * v[j]; acc[4 + j] += w1[j] * v[4 + j]; }
+      }
+    store8<T>(out + pix * C + cc * 8, acc);
+  }
+}
+
 // InstanceNorm statistics, deterministic (no atomics: the flows feed discontinuous 'nearest' warps, so run-to-run
 // bit differences are not acceptable).  Stage 1: grid (slice, n); a block streams its slice of pixels with 16-byte
 // channel vectors (C/8 lanes per pixel, 256/(C/8) pixels per pass), reduces the per-thread partials through LDS in a
@@ -316,6 +353,14 @@ extern "C" int pp_depthwise_pool(const void* in, const float* weight, const floa
                                  int k, int dtype, void* stream) {
   PP_REQUIRE(in && weight && out && N > 0 && H >= k && W >= k && C > 0 && k > 0, PP_ERR_ARG, "pp_depthwise_pool: bad arguments");
   PP_REQUIRE(dtype == PP_F32 || dtype == PP_F16, PP_ERR_DTYPE, "pp_depthwise_pool: dtype %d", dtype);
+  if (C % 8 == 0 && (size_t)k * k * C * sizeof(float) <= 48 * 1024 && (uintptr_t)in % 16 == 0 && (uintptr_t)out % 16 == 0) {
+    int g8 = grid_for((long long)N * (H / k) * (W / k) * (C / 8));
+    if (g8 > 512) g8 = 512;                           // every block stages the weights once: keep the blocks long-lived
+    const size_t shm = (size_t)k * k * C * sizeof(float);
+    PP_DISPATCH_T(dtype, hipLaunchKernelGGL((depthwise_pool8_kernel<T>), dim3(g8), dim3(256), shm, (hipStream_t)stream, (const T*)in,
+                                            weight, bias, (T*)out, N, H, W, C, k);)
+    return launch_status("pp_depthwise_pool");
+  }
   const int g = grid_for((long long)N * (H / k) * (W / k) * C);
   PP_DISPATCH_T(dtype, hipLaunchKernelGGL((depthwise_pool_kernel<T>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const T*)in,
                                           weight, bias, (T*)out, N, H, W, C, k);)

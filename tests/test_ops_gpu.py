@@ -63,6 +63,9 @@ CONV_CASES = [
     dict(name="7x7s3_c40", cin=[40], cout=512, k=(7, 7), stride=3, pad=3, residual=True),
     dict(name="cout48", cin=[64], cout=48, k=(3, 3), stride=2, pad=1),
     dict(name="cout432", cin=[128], cout=432, k=(3, 3), stride=1, pad=1),
+    dict(name="5x1_tanh", cin=[128, 256], cout=128, k=(5, 1), stride=1, pad=(2, 0), act="tanh"),          # halo-tile kernel, 16x8 tiles
+    dict(name="3x3_res_halo", cin=[128], cout=128, k=(3, 3), stride=1, pad=1, act="lrelu", residual=True),   # fp32 staging epilogue
+    dict(name="3x3_cout64_halo", cin=[64, 64], cout=64, k=(3, 3), stride=1, pad=1, act="relu"),
 ]
 
 
@@ -107,6 +110,32 @@ def test_conv2d(dev, case, dt):
     check(case["name"], out[..., :case["cout"]].permute(0, 3, 1, 2), ref, tol(dt))
     if out.shape[-1] > case["cout"]:
         assert (out[..., case["cout"]:] == 0).all(), "channel padding must stay zero"
+
+
+@pytest.mark.parametrize("k,pad", [((3, 3), 1), ((1, 5), (0, 2)), ((5, 1), (2, 0))], ids=["3x3", "1x5", "5x1"])
+def test_conv_kernel_families_are_bit_identical(dev, k, pad):
+    """The register-staged kernel (impl 1), the LDS-DMA kernel (impl 12) and the halo-tile kernel (impl 70) walk K in the
+    same (table-defined) order with the same MFMA, so on an fp16 layer they must agree bit for bit -- on a ragged map
+    (edge tiles partly outside), with two sources, bias, activation and a channel-window output."""
+    from propainter_amd.conv import ConvLayer
+    g = torch.Generator().manual_seed(21)
+    N, H, W = 2, 21, 37
+    cin, cout = [64, 128], 192
+    w = torch.randn(cout, sum(cin), *k, generator=g) / math.sqrt(sum(cin) * k[0] * k[1])
+    b = torch.randn(cout, generator=g) * 0.1
+    layer = ConvLayer(w, b, padding=pad, src_channels=cin, dtype=torch.float16, device=dev)
+    srcs = [nhwc(torch.randn(N, c, H, W, generator=g), torch.float16) for c in cin]
+    outs = {}
+    for impl in (1, 12, 70):
+        layer.impl = impl
+        buf = torch.full((N, H, W, 256), 3.0, dtype=torch.float16, device=dev)
+        layer(srcs, out=buf, out_choff=64, act="lrelu", act_param=0.2)
+        torch.cuda.synchronize()
+        outs[impl] = buf
+        assert (buf[..., :64] == 3).all()
+    assert torch.equal(outs[1], outs[12]) and torch.equal(outs[1], outs[70])
+    ref = F.leaky_relu(F.conv2d(torch.cat([s[..., :c].permute(0, 3, 1, 2).float().cpu() for s, c in zip(srcs, cin)], 1), w, b, 1, pad), 0.2)
+    check("families", outs[70][..., 64:].permute(0, 3, 1, 2), ref, 1e-2)
 
 
 def test_conv2d_output_window_and_large_m(dev):
@@ -278,6 +307,31 @@ def _attention_reference(q, k, v, pk, pv, own, rolled, tind, wmask, heads=4):
                 y = torch.einsum("thqk,tkhc->tqhc", a, vf[b][:, own[w]])
             out[b][:, own[w]] = y
     return out.reshape(B, T, Hp, Wp, C)
+
+
+@pytest.mark.parametrize("pattern", ["none", "all", "batch2"])
+def test_sparse_window_attention_mask_patterns(dev, pattern):
+    """Persistent masked-window launch: empty list (no masked window), full list, and two batch entries with different
+    masked sets (the compacted list spans the batch)."""
+    from propainter_amd import hip
+    dt = torch.float16
+    g = torch.Generator().manual_seed(15)
+    B = 2 if pattern == "batch2" else 1
+    T, Hp, Wp, C = 4, 10, 18, 512
+    q, k, v = (torch.randn(B, T, Hp, Wp, C, generator=g) for _ in range(3))
+    P = (Hp // 4) * (Wp // 4)
+    pk, pv = torch.randn(B, T, P, C, generator=g), torch.randn(B, T, P, C, generator=g)
+    own_np, rolled_np = hip.window_tables(Hp, Wp)
+    own, rolled = torch.from_numpy(own_np).long(), torch.from_numpy(rolled_np).long()
+    wmask = {"none": torch.zeros(1, 4), "all": torch.ones(1, 4), "batch2": torch.tensor([[1.0, 0, 0, 1], [0, 0, 3.0, 0]])}[pattern]
+    tind = torch.tensor([0, 2])
+    cast = lambda a: a.to(dt).float()
+    ref = _attention_reference(cast(q), cast(k), cast(v), cast(pk), cast(pv), own, rolled, tind, wmask)
+    out = hip.sparse_window_attention(q.to(dev, dt), k.to(dev, dt), v.to(dev, dt), pk.to(dev, dt), pv.to(dev, dt),
+                                      torch.from_numpy(own_np).to(dev), torch.from_numpy(rolled_np).to(dev),
+                                      tind.to(dev, torch.int32), wmask.to(dev))
+    torch.cuda.synchronize()
+    check(pattern, out, ref, 6e-3)
 
 
 @pytest.mark.parametrize("variant", ["ref_f32", "ref_f16", "mfma_f16"])
