@@ -7,7 +7,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libpropainter_hip.so")
-SOURCES = ["api.hip", "conv_gemm.hip", "conv_gemm_v2.hip", "conv_gemm_v3.hip", "sampling.hip", "raft_ops.hip", "token_ops.hip", "attention.hip"]
+SOURCES = ["api.hip", "conv_gemm.hip", "conv_gemm_v2.hip", "conv_gemm_v3.hip", "conv_gemm_ast.hip", "sampling.hip", "raft_ops.hip", "token_ops.hip", "attention.hip"]
 
 
 def _hipcc():

@@ -17,7 +17,7 @@ namespace pp {
 template <int WM, int WN, typename RowMap>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[WN / 16][WM / 16], char* wave_lds, int lane,
                                               int co_wave /* first cout of the wave tile within the group */, int g,
-                                              char* outp, const RowMap rowmap) {
+                                              char* outp, const RowMap rowmap, const f32x4* bias_pre = nullptr) {
   constexpr int TM = WM / 16, TN = WN / 16;
   typedef _Float16 T;
   const int l15 = lane & 15, l4 = lane >> 4;
@@ -32,7 +32,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
     for (int a = 0; a < TN; ++a) {
       f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
       const int c0 = co_wave + a * 16 + l4 * 4;
-      if (p.bias != nullptr) {
+      if (bias_pre != nullptr) {                      // fetched by the caller ahead of time (zeros where there is no bias)
+        b4 = bias_pre[a];
+      } else if (p.bias != nullptr) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) b4[r] = c0 + r < p.cout_g ? p.bias[g * p.cout_g + c0 + r] : 0.f;
       }
@@ -63,6 +65,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
           for (int r = 0; r < 4; ++r) acc[a][b][r] = apply_act_special((acc[a][b][r] + b4[r]) * scale, act);
       }
     }
+  }
+  if (!has_res && p.act2 == PP_ACT_RELU) {          // act2 is defined as "after the residual add"; without a residual it still applies
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+      for (int b = 0; b < TM; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[a][b][r] = fmaxf(acc[a][b][r], 0.f);
   }
   constexpr int LPR = WN / 8;                       // lanes per pixel row (8 couts each)
   constexpr int RPP = 64 / LPR;                     // pixel rows per pass

@@ -435,6 +435,12 @@ extern "C" int pp_conv2d(const pp_conv_args_t* a, void* stream) {
   p.groups = a->groups; p.tiles_m = 0; p.tiles_n = 0; p.ktable_uniform = a->ktable_uniform;
   p.tap_h = a->tap_h; p.tap_w = a->tap_w;
   hipStream_t st = (hipStream_t)stream;
+  if (a->dtype == PP_F16 && !deform && (a->impl == 0 || a->impl == 80 || a->impl == 81)) {
+    // A-stationary kernel for the short-K single-source linears (transformer GEMMs)
+    const int rc = conv_ast_dispatch(p, a->impl, st);
+    if (rc != -1000) return rc;
+    PP_REQUIRE(a->impl == 0, PP_ERR_ARG, "pp_conv2d: impl 80 (A-stationary GEMM) not available for this shape");
+  }
   if (a->dtype == PP_F16 && !deform && (a->impl == 0 || (a->impl >= 70 && a->impl < 80))) {
     // halo-tile kernel family (stride-1 "same" 3x3 / 1x5 / 5x1 windows over 64-channel-multiple sources)
     const int rc = conv_v3_dispatch(p, a->impl, st);

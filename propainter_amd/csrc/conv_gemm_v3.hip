@@ -39,11 +39,11 @@ static __device__ __forceinline__ void v3_dma16(__amdgpu_buffer_rsrc_t r, char* 
 __device__ unsigned long long g_v3_prof[12];
 
 template <int TH, int TW, int KH, int KW, int BN, bool PROF = false, int STAGGER = 0>
-__global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p) {
+__global__ __launch_bounds__(TH * TW * 2) void conv_halo_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef _Float16 T;
-  constexpr int NW = 4, WAVES_N = BN >= 32 ? 2 : 1, WAVES_M = NW / WAVES_N;   // BN 16 (tiny cout): 4 waves along the pixels
-  constexpr int BM = TH * TW;
+  constexpr int BM = TH * TW;                                   // 128 px (4 waves, 2 blocks/CU) or 256 px (8 waves, 1 block/CU)
+  constexpr int NW = BM / 32, WAVES_N = BN >= 32 ? 2 : 1, WAVES_M = NW / WAVES_N;   // BN 16 (tiny cout): all waves along the pixels
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 16, TN = WN / 16;
   constexpr int PH = TH + KH - 1, PW = TW + KW - 1, P = PH * PW;
@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p) {
   constexpr int EPI_LD = WN + 4;
   constexpr int EPI_BYTES = NW * WM * EPI_LD * 4;
   constexpr int LDS_BYTES = PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES;
-  static_assert(BM == 128 && (TW == 16 || TW == 8) && PPW <= NTAPS && (BN % 32 == 0 || BN == 16) && LDS_BYTES <= 80 * 1024, "tile");
+  static_assert((BM == 128 || BM == 256) && (TW == 16 || TW == 8) && PPW <= NTAPS && (BN % 32 == 0 || BN == 16) &&
+                    LDS_BYTES <= (BM == 128 ? 80 : 160) * 1024, "tile");
 
   __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
   unsigned long long pf_start = 0;
@@ -189,7 +190,8 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p) {
       __builtin_amdgcn_s_barrier();          // weights of step ks (and, at t == 0, the whole patch of this block) are in LDS
       if constexpr (PROF) { pf_c = __builtin_readcyclecounter(); pf_wait += pf_c - pf_b; }
       if (t == 0 && have_next) v3_entry_ready(en);
-      if (ks + 1 < nk) V3_ISSUE_B(ks + 1, par ^ 1);
+      const bool more_b = ks + 1 < nk;
+      if constexpr (STAGGER != 3) { if (more_b) V3_ISSUE_B(ks + 1, par ^ 1); }
       if (t < PPW && have_next) V3_ISSUE_PIECE(t, pnext, en);
       if constexpr (PROF) { pf_a = __builtin_readcyclecounter(); pf_issue += pf_a - pf_c; }
       const int sh = (t / KW) * PW + (t % KW);          // compile-time after unrolling
@@ -206,10 +208,20 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p) {
         for (int f = 0; f < TN; ++f)
           bf[f] = *reinterpret_cast<const f16x8*>(sb + b_off + f * 16 * 128 + (((kk * 4 + l4) ^ bswz) << 4));
 #pragma unroll
-        for (int a = 0; a < TN; ++a)
+        for (int a = 0; a < TN; ++a) {
 #pragma unroll
           for (int b = 0; b < TM; ++b)
             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[a], af[b], acc[a][b], 0, 0, 0);
+          if constexpr (STAGGER == 3) {
+            // [variant] next step's weight DMA interleaved with the MFMA groups of kk == 0 (one instruction per group) instead
+            // of a burst after the barrier: the TA queue is shared by 8 waves, a burst costs ~100 cycles per instruction
+            if (kk == 0 && a < B_PER_WAVE && more_b && (!B_RAGGED || a * NW + wave < B_INST)) {
+              __builtin_amdgcn_sched_barrier(0);
+              v3_dma16(rw, bst0 + (par ^ 1) * BSTAGE + (a * NW + wave) * 1024, wvoff[a], (ks + 1) * 128);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
       }
       if constexpr (PROF) { asm volatile("s_nop 0" ::: "memory"); pf_comp += __builtin_readcyclecounter() - pf_a; }
       ++ks;
@@ -254,7 +266,7 @@ static int launch_v3(ConvParams p, hipStream_t stream) {
   const long long tiles = (long long)p.N * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
   const long long nblk = tiles * p.tiles_n;
   if (nblk >= (1ll << 31)) return -1000;
-  hipLaunchKernelGGL((conv_halo_kernel<TH, TW, KH, KW, BN, PROF, STAGGER>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL((conv_halo_kernel<TH, TW, KH, KW, BN, PROF, STAGGER>), dim3((unsigned)nblk), dim3(TH * TW * 2), 0, stream, p);
   return launch_status("pp_conv2d(v3)");
 }
 
@@ -281,6 +293,18 @@ int conv_v3_dispatch(const ConvParams& p, int cfg, hipStream_t stream) {
     if (kh == 3 && kw == 3) return cfg == 76 ? launch_v3<8, 16, 3, 3, 128, false, 1>(p, stream) : launch_v3<8, 16, 3, 3, 128, true, 2>(p, stream);
     if (kh == 1 && kw == 5) return cfg == 76 ? launch_v3<8, 16, 1, 5, 128, false, 1>(p, stream) : launch_v3<8, 16, 1, 5, 128, true, 2>(p, stream);
     if (kh == 5 && kw == 1) return cfg == 76 ? launch_v3<16, 8, 5, 1, 128, false, 1>(p, stream) : launch_v3<16, 8, 5, 1, 128, true, 2>(p, stream);
+    return -1000;
+  }
+  if (cfg == 74 || cfg == 78) {   // variant: weight DMA interleaved with the MFMAs (74) / + phase timing (78)
+    if (kh == 3 && kw == 3) return cfg == 74 ? launch_v3<8, 16, 3, 3, 128, false, 3>(p, stream) : launch_v3<8, 16, 3, 3, 128, true, 3>(p, stream);
+    if (kh == 1 && kw == 5) return cfg == 74 ? launch_v3<8, 16, 1, 5, 128, false, 3>(p, stream) : launch_v3<8, 16, 1, 5, 128, true, 3>(p, stream);
+    if (kh == 5 && kw == 1) return cfg == 74 ? launch_v3<16, 8, 5, 1, 128, false, 3>(p, stream) : launch_v3<16, 8, 5, 1, 128, true, 3>(p, stream);
+    return -1000;
+  }
+  if (cfg == 79) {   // 256-pixel tiles, 8 waves, one block per CU: the weight tile is fetched from L2 once per CU and step
+    if (kh == 3 && kw == 3) return launch_v3<16, 16, 3, 3, 128>(p, stream);
+    if (kh == 1 && kw == 5) return launch_v3<16, 16, 1, 5, 128>(p, stream);
+    if (kh == 5 && kw == 1) return launch_v3<16, 16, 5, 1, 128>(p, stream);
     return -1000;
   }
   if (cfg == 75) {   // diagnostic: phase timing (BN 128)

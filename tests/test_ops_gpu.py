@@ -138,6 +138,28 @@ def test_conv_kernel_families_are_bit_identical(dev, k, pad):
     check("families", outs[70][..., 64:].permute(0, 3, 1, 2), ref, 1e-2)
 
 
+@pytest.mark.parametrize("residual", [False, True], ids=["plain", "residual"])
+def test_a_stationary_gemm_is_bit_identical_to_the_tiled_kernel(dev, residual):
+    """conv_gemm_ast.hip (impl 80: activations register-resident, weights streamed over all couts) against the tiled LDS-DMA
+    kernel (impl 12) on a Linear 512 -> 1960 with a ragged row count, bias, activation and (optionally) a residual."""
+    from propainter_amd.conv import ConvLayer
+    g = torch.Generator().manual_seed(33)
+    M, K, N = 3001, 512, 1960
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g) * 0.1
+    x = torch.randn(1, 1, M, K, generator=g).to(dev, torch.float16)
+    res = torch.randn(1, 1, M, N, generator=g).to(dev, torch.float16) if residual else None
+    layer = ConvLayer(w, b, dtype=torch.float16, device=dev)
+    outs = {}
+    for impl in (12, 80):
+        layer.impl = impl
+        outs[impl] = layer([x], act="lrelu", act_param=0.2, residual=res).clone()
+        torch.cuda.synchronize()
+    assert torch.equal(outs[12], outs[80])
+    ref = F.leaky_relu(x[0, 0].float().cpu() @ w.t() + b, 0.2) + (res[0, 0].float().cpu() if residual else 0)
+    check("ast", outs[80][0, 0], ref, 1e-2)
+
+
 def test_conv2d_output_window_and_large_m(dev):
     """writes into a channel window of a wider buffer; M not a multiple of the tile; asymmetric data (transposes)."""
     from propainter_amd.conv import ConvLayer

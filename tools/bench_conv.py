@@ -123,7 +123,7 @@ def main():
             else:
                 d = (out.float() - ref).abs().max().item()
             print(f"{name:24s} {impl:4d} {ms:9.3f} {flops / ms / 1e9:9.1f} {d:16.3e}", flush=True)
-            if impl in (75, 77):      # phase counters of the PROF build (cycles per wave)
+            if impl in (75, 77, 78):      # phase counters of the PROF build (cycles per wave)
                 import ctypes
                 buf = (ctypes.c_uint64 * 12)()
                 hip.lib().pp_debug_conv_prof(buf)
