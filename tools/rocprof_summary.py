@@ -20,6 +20,7 @@ import sys
 
 FAMILIES = [   # (substring of the demangled OR mangled kernel name, family)
     ("conv_halo_kernel", "conv_gemm_f16 (LDS-DMA implicit GEMM)"),
+    ("conv_ast_kernel", "conv_gemm_f16 (LDS-DMA implicit GEMM)"),
     ("conv_gemm_v2_kernel", "conv_gemm_f16 (LDS-DMA implicit GEMM)"),
     ("conv_gemm_kernel<_Float16", "conv_gemm_f16/dcn (register-staged)"),
     ("conv_gemm_kernelIDF16_", "conv_gemm_f16/dcn (register-staged)"),
