@@ -1,0 +1,75 @@
+"""``ProInpainter`` -- the library entry point the reference's web demos use
+(``web-demos/hugging_face/inpainter/base_inpainter.py:163-374``): same constructor and ``inpaint`` signature, same
+pre-processing (resize to even / multiple-of-8 sizes, per-frame masks dilated with scipy), same chunking of the
+device path (it is ``inference_propainter.py:298-452`` again), numpy frames out.  The device work runs on the HIP
+engine through ``pipeline.run_clip``."""
+import numpy as np
+import scipy.ndimage
+import torch
+from PIL import Image
+
+from . import hip, video_io
+from .pipeline import InferenceConfig, run_clip
+
+
+class ProInpainter:
+    def __init__(self, propainter_checkpoint, raft_checkpoint, flow_completion_checkpoint, device="cuda:0", use_half=True,
+                 raft_fp32=False):
+        """Checkpoint paths as in the reference; passing ``None`` for all three builds the deterministic seeded weights
+        (no checkpoints ship with either repository).  ``raft_fp32`` keeps the RAFT convolutions in fp32 like the
+        reference (default with ``use_half``: fp16 MFMA, fp32 correlation / coordinates)."""
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("ProInpainter runs on the HIP engine only (no CPU path in the product)")
+        self.use_half = bool(use_half)
+        hip.lib()
+        raft_dt = torch.float16 if (self.use_half and not raft_fp32) else None
+        if propainter_checkpoint is None and raft_checkpoint is None and flow_completion_checkpoint is None:
+            from .synthetic import seeded_models
+            self.fix_raft, self.fix_flow_complete, self.model = seeded_models(self.device, raft_dtype=raft_dt)
+        else:
+            from .model.modules.flow_comp_raft import RAFT_bi
+            from .model.propainter import InpaintGenerator
+            from .model.recurrent_flow_completion import RecurrentFlowCompleteNet
+            self.fix_raft = RAFT_bi(raft_checkpoint, self.device, compute_dtype=raft_dt)
+            self.fix_flow_complete = RecurrentFlowCompleteNet(flow_completion_checkpoint)
+            for p in self.fix_flow_complete.parameters():
+                p.requires_grad = False
+            self.fix_flow_complete.to(self.device).eval()
+            self.model = InpaintGenerator(model_path=propainter_checkpoint).to(self.device).eval()
+            if self.use_half:
+                self.fix_flow_complete, self.model = self.fix_flow_complete.half(), self.model.half()
+
+    @staticmethod
+    def _masks(masks, length, size, dilate):
+        """read_mask_demo (base_inpainter.py:128-160): per-frame uint8 masks -> (flow_masks, masks_dilated) {0,255}."""
+        fm, md = [], []
+        for m in masks:
+            im = Image.fromarray(np.asarray(m).astype('uint8'))
+            if size is not None:
+                im = im.resize(size, Image.NEAREST)
+            a = np.array(im.convert('L'))
+            d = (scipy.ndimage.binary_dilation(a, iterations=dilate) if dilate > 0 else a > 0.1).astype(np.uint8) * 255
+            fm.append(d)
+            md.append(d)
+        if len(fm) == 1:
+            fm, md = fm * length, md * length
+        return np.stack(fm[:length]), np.stack(md[:length])
+
+    @torch.no_grad()
+    def inpaint(self, npframes, masks, ratio=1.0, dilate_radius=4, raft_iter=20, subvideo_length=80, neighbor_length=10,
+                ref_stride=10):
+        """npframes: T x H x W x 3 uint8 (RGB); masks: T (or 1) x H x W, non-zero = hole.  Returns a list of T uint8 frames
+        at the (even-sized) output resolution."""
+        frames = [Image.fromarray(np.asarray(f).astype('uint8'), mode="RGB") for f in npframes]
+        size = frames[0].size
+        size = (int(ratio * size[0]) // 2 * 2, int(ratio * size[1]) // 2 * 2)      # even sizes for libx264 (:197-198)
+        frames, size, out_size = video_io.resize_frames(frames, size)
+        flow_masks, masks_dilated = self._masks(masks, len(frames), size, dilate_radius)
+        frames_u8 = np.stack([np.asarray(f, dtype=np.uint8) for f in frames])
+        cfg = InferenceConfig(raft_iter=raft_iter, subvideo_length=subvideo_length, neighbor_length=neighbor_length,
+                              ref_stride=ref_stride, fp16=self.use_half)
+        comp = run_clip((self.fix_raft, self.fix_flow_complete, self.model), frames_u8, flow_masks, masks_dilated, cfg,
+                        self.device)
+        comp = comp.cpu().numpy()
+        return [video_io._resize_u8(f, out_size, Image.BILINEAR) for f in comp]

@@ -202,3 +202,22 @@ def test_cli_end_to_end_on_a_frame_folder(tmp_path):
     import scipy.ndimage
     outside = ~scipy.ndimage.binary_dilation(~outside, iterations=4)
     assert np.array_equal(f0[outside], clip[0][outside])          # known pixels pass through untouched
+
+
+def test_proinpainter_api_matches_the_clip_driver():
+    """ProInpainter(None, None, None).inpaint(...) (web-demo entry point of the reference) == run_clip on the same inputs."""
+    from propainter_amd.inpainter import ProInpainter
+    from propainter_amd.pipeline import InferenceConfig, run_clip
+    from propainter_amd.synthetic import synthetic_clip, synthetic_mask
+    import scipy.ndimage
+    L, H, W = 6, 128, 192
+    clip = synthetic_clip(L, H, W, seed=8)
+    raw = synthetic_mask(H, W)
+    pi = ProInpainter(None, None, None, device="cuda:0", use_half=True)
+    out = pi.inpaint(clip, [raw] * L, raft_iter=3, neighbor_length=4, ref_stride=3)
+    assert len(out) == L and out[0].shape == (H, W, 3) and out[0].dtype == np.uint8
+    md = scipy.ndimage.binary_dilation(raw, iterations=4).astype(np.uint8) * 255
+    masks = np.repeat(md[None], L, 0)
+    cfg = InferenceConfig(raft_iter=3, subvideo_length=80, neighbor_length=4, ref_stride=3, fp16=True)
+    ref = run_clip((pi.fix_raft, pi.fix_flow_complete, pi.model), clip, masks, masks, cfg, torch.device("cuda:0")).cpu().numpy()
+    assert np.array_equal(np.stack(out), ref)
