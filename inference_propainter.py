@@ -21,29 +21,30 @@ if ROOT not in sys.path:
 
 
 def build_parser():
-    p = argparse.ArgumentParser()
-    p.add_argument('-i', '--video', type=str, default='inputs/object_removal/bmx-trees', help='Path of the input video or image folder.')
-    p.add_argument('-m', '--mask', type=str, default='inputs/object_removal/bmx-trees_mask', help='Path of the mask(s) or mask folder.')
-    p.add_argument('-o', '--output', type=str, default='results', help='Output folder. Default: results')
-    p.add_argument("--resize_ratio", type=float, default=1.0, help='Resize scale for processing video.')
-    p.add_argument('--height', type=int, default=-1, help='Height of the processing video.')
-    p.add_argument('--width', type=int, default=-1, help='Width of the processing video.')
-    p.add_argument('--mask_dilation', type=int, default=4, help='Mask dilation for video and flow masking.')
-    p.add_argument("--ref_stride", type=int, default=10, help='Stride of global reference frames.')
-    p.add_argument("--neighbor_length", type=int, default=10, help='Length of local neighboring frames.')
-    p.add_argument("--subvideo_length", type=int, default=80, help='Length of sub-video for long video inference.')
-    p.add_argument("--raft_iter", type=int, default=20, help='Iterations for RAFT inference.')
-    p.add_argument('--mode', default='video_inpainting', choices=['video_inpainting', 'video_outpainting'],
-                   help="Modes: video_inpainting / video_outpainting")
-    p.add_argument('--scale_h', type=float, default=1.0, help='Outpainting scale of height for video_outpainting mode.')
-    p.add_argument('--scale_w', type=float, default=1.2, help='Outpainting scale of width for video_outpainting mode.')
-    p.add_argument('--save_fps', type=int, default=24, help='Frame per second. Default: 24')
-    p.add_argument('--save_frames', action='store_true', help='Save output frames. Default: False')
-    p.add_argument('--fp16', action='store_true', help='Use fp16 (half precision) during inference. Default: fp32 (single precision).')
+    """Flags and defaults of the reference command line (inference_propainter.py:181-217); the help texts are ours."""
+    p = argparse.ArgumentParser(description="ProPainter video inpainting / outpainting on MI355X (HIP engine)")
+    a = p.add_argument
+    a('-i', '--video', type=str, default='inputs/object_removal/bmx-trees', help='input clip: a video file or a folder of frames')
+    a('-m', '--mask', type=str, default='inputs/object_removal/bmx-trees_mask', help='hole mask: one image for all frames, or a folder with one mask per frame')
+    a('-o', '--output', type=str, default='results', help='where results/<clip name>/ is created')
+    a("--resize_ratio", type=float, default=1.0, help='scale factor applied to the processing resolution')
+    a('--height', type=int, default=-1, help='processing height in pixels (with --width; -1 keeps the input size)')
+    a('--width', type=int, default=-1, help='processing width in pixels (with --height; -1 keeps the input size)')
+    a('--mask_dilation', type=int, default=4, help='binary dilation iterations applied to the masks (frames and flows)')
+    a("--ref_stride", type=int, default=10, help='distance between the global reference frames of a window')
+    a("--neighbor_length", type=int, default=10, help='number of local neighbour frames per window')
+    a("--subvideo_length", type=int, default=80, help='sub-video length used to chunk long clips (also the multi-GPU shard unit)')
+    a("--raft_iter", type=int, default=20, help='RAFT refinement iterations')
+    a('--mode', default='video_inpainting', choices=['video_inpainting', 'video_outpainting'], help="fill masked holes, or extend the field of view")
+    a('--scale_h', type=float, default=1.0, help='outpainting: height factor of the new field of view')
+    a('--scale_w', type=float, default=1.2, help='outpainting: width factor of the new field of view')
+    a('--save_fps', type=int, default=24, help='frame rate of the written videos when the input has none')
+    a('--save_frames', action='store_true', help='also write every output frame as PNG')
+    a('--fp16', action='store_true', help='half-precision stages (fp16 storage, fp32 accumulation)')
     # ---- not in the reference
-    p.add_argument('--weights_dir', type=str, default='weights', help='Folder holding raft-things.pth, recurrent_flow_completion.pth, ProPainter.pth.')
-    p.add_argument('--seeded_weights', action='store_true', help='Run with the deterministic seeded weights (no checkpoints available offline).')
-    p.add_argument('--raft_fp32', action='store_true', help='Keep the RAFT convolutions in fp32 like the reference (default with --fp16: fp16 MFMA, fp32 accumulate).')
+    a('--weights_dir', type=str, default='weights', help='folder holding raft-things.pth, recurrent_flow_completion.pth, ProPainter.pth')
+    a('--seeded_weights', action='store_true', help='run with the deterministic seeded weights (no checkpoints available offline)')
+    a('--raft_fp32', action='store_true', help='keep the RAFT convolutions in fp32 like the reference (default with --fp16: fp16 MFMA, fp32 accumulate)')
     return p
 
 
