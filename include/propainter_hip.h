@@ -152,6 +152,11 @@ int pp_img_prop_step(const void* x_prop, const void* m_prop, const void* x_cur, 
                      const void* flow_prop, const void* flow_check, void* x_out, void* m_out, int N, int C,
                      int H, int W, int mode, int dtype, void* stream);
 
+/* Mask dilation of the driver's pre-processing (scipy.ndimage.binary_dilation(mask, iterations=k) with the default
+ * cross structuring element, inference_propainter.py:96,105): uint8 planar [N,H,W], non-zero = hole; out = 255 where a
+ * non-zero pixel lies within L1 distance k, else 0 (k = 0: plain binarisation).  out must not alias mask. */
+int pp_binary_dilate(const void* mask, void* out, int N, int H, int W, int iterations, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * RAFT correlation (RAFT/corr.py:13-60, RAFT/utils/utils.py:57-71, RAFT/raft.py:73-84)
  * ---------------------------------------------------------------------------------------------- */

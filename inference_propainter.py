@@ -103,7 +103,7 @@ def main(argv=None):
     save_root = os.path.join(args.output, video_name)
     if args.mode == 'video_inpainting':
         flow_masks, masks_dilated = video_io.read_masks(args.mask, len(frames), size, flow_mask_dilates=args.mask_dilation,
-                                                        mask_dilates=args.mask_dilation)
+                                                        mask_dilates=args.mask_dilation, device=device)
     else:
         frames, flow_masks, masks_dilated, size = video_io.extrapolation(frames, (args.scale_h, args.scale_w))
     frames_u8 = np.stack([np.asarray(f, dtype=np.uint8) for f in frames])

@@ -157,6 +157,28 @@ static inline int grid_for(long long total, int block = 256) {
   return (int)(g < 1 ? 1 : (g > 256 * 16 ? 256 * 16 : g));
 }
 
+// Mask dilation of the driver (inference_propainter.py:96,105: scipy.ndimage.binary_dilation(mask, iterations=k) with the
+// default 4-connected structuring element and zero border): k iterations of the cross == the L1 ball of radius k, so
+// out = 255 iff some non-zero input pixel lies within |dy| + |dx| <= k.  uint8 planar [N,H,W]; k = 0 -> plain binarisation.
+__global__ void binary_dilate_kernel(const unsigned char* __restrict__ in, unsigned char* __restrict__ out, int N, int H, int W,
+                                     int k) {
+  const long long total = (long long)N * H * W;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const long long base = (i / ((long long)W * H)) * H * W;
+    bool hit = false;
+    for (int dy = -k; dy <= k && !hit; ++dy) {
+      const int yy = y + dy;
+      if (yy < 0 || yy >= H) continue;
+      const int r = k - (dy < 0 ? -dy : dy);
+      const int x0 = max(0, x - r), x1 = min(W - 1, x + r);
+      for (int xx = x0; xx <= x1; ++xx)
+        if (in[base + (long long)yy * W + xx] != 0) { hit = true; break; }
+    }
+    out[i] = hit ? 255 : 0;
+  }
+}
+
 }  // namespace pp
 
 using namespace pp;
@@ -219,4 +241,13 @@ extern "C" int pp_img_prop_step(const void* x_prop, const void* m_prop, const vo
                        (const float*)x_cur, (const float*)m_cur, (const float*)flow_prop, (const float*)flow_check,
                        (float*)x_out, (float*)m_out, N, C, H, W, mode);
   return launch_status("pp_img_prop_step");
+}
+
+extern "C" int pp_binary_dilate(const void* mask, void* out, int N, int H, int W, int iterations, void* stream) {
+  PP_REQUIRE(mask && out && mask != out && N > 0 && H > 0 && W > 0 && iterations >= 0 && iterations <= 64, PP_ERR_ARG,
+             "pp_binary_dilate: bad arguments (iterations %d)", iterations);
+  const int g = grid_for((long long)N * H * W);
+  hipLaunchKernelGGL(binary_dilate_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)mask,
+                     (unsigned char*)out, N, H, W, iterations);
+  return launch_status("pp_binary_dilate");
 }

@@ -262,6 +262,16 @@ def img_prop_step(x_prop, m_prop, x_cur, m_cur, flow_prop, flow_check, x_out, m_
            "pp_img_prop_step"))
 
 
+def binary_dilate(mask_u8, iterations):
+    """uint8 [N,H,W] (non-zero = hole) on the GPU -> uint8 {0,255}, == scipy.ndimage.binary_dilation(mask, iterations) * 255."""
+    N, H, W = mask_u8.shape
+    assert mask_u8.dtype == torch.uint8 and mask_u8.is_contiguous()
+    out = torch.empty_like(mask_u8)
+    timed("binary_dilate", 0, 2 * mask_u8.numel(), lambda: _check(lib().pp_binary_dilate(_p(mask_u8), _p(out), _i(N), _i(H), _i(W),
+                                                                                       _i(iterations), _stream()), "pp_binary_dilate"))
+    return out
+
+
 def corr_avgpool(x, M, H, W):
     out = torch.empty((M, H // 2, W // 2), dtype=torch.float32, device=x.device)
     timed("corr_avgpool", 0, _nbytes(out) * 5, lambda: _check(lib().pp_corr_avgpool(_p(x), _p(out), C.c_int64(M), _i(H), _i(W), _stream()),

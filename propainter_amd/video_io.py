@@ -48,13 +48,27 @@ def read_frames(path):
     return frames, fps, frames[0].size, name
 
 
-def read_masks(path, length, size, flow_mask_dilates=8, mask_dilates=5):
+def read_masks(path, length, size, flow_mask_dilates=8, mask_dilates=5, device=None):
     """Single mask image or folder of per-frame masks -> (flow_masks, masks_dilated): lists of uint8 {0,255} arrays
-    [h,w] (:81-115: nearest resize, grey conversion, scipy binary dilation, or the 0.1 threshold when dilation is 0)."""
+    [h,w] (:81-115: nearest resize, grey conversion, scipy binary dilation, or the 0.1 threshold when dilation is 0).
+    With ``device`` (a GPU) the dilation runs in pp_binary_dilate (bit-identical to scipy, tests/test_ops_gpu.py)."""
     if path.endswith(IMAGE_EXT):
         imgs = [Image.open(path)]
     else:
         imgs = [Image.open(os.path.join(path, f)) for f in sorted(os.listdir(path)) if f.endswith(IMAGE_EXT)]
+    if device is not None:
+        import torch
+        from . import hip
+        raw = np.stack([np.array((im.resize(size, Image.NEAREST) if size is not None else im).convert('L')) for im in imgs])
+        t = torch.from_numpy(np.ascontiguousarray(raw)).to(device)
+        fm = hip.binary_dilate(t, flow_mask_dilates).cpu().numpy()
+        md = fm if mask_dilates == flow_mask_dilates else hip.binary_dilate(t, mask_dilates).cpu().numpy()
+        flow_masks, masks_dilated = list(fm), list(md)
+        if len(imgs) == 1:
+            flow_masks, masks_dilated = flow_masks * length, masks_dilated * length
+        if len(flow_masks) < length:
+            raise RuntimeError(f"{len(flow_masks)} masks for {length} frames")
+        return flow_masks[:length], masks_dilated[:length]
 
     def dil(a, it):
         if it > 0:

@@ -445,3 +445,18 @@ def test_elementwise_ops(dev, dt):
     torch.cuda.synchronize()
     ref = F.max_pool2d(mask, (5, 9), (5, 9)).view(1, 3, -1).sum(1)
     assert torch.equal(wm.cpu(), ref)
+
+
+@pytest.mark.parametrize("k", [0, 1, 4, 7])
+def test_binary_dilate_is_bit_identical_to_scipy(dev, k):
+    """pp_binary_dilate == scipy.ndimage.binary_dilation(mask, iterations=k) (cross element, zero border) -- the mask
+    pre-processing of the driver (inference_propainter.py:96,105); blobs touching every border, isolated pixels, empty frame."""
+    import scipy.ndimage
+    from propainter_amd import hip
+    rng = np.random.RandomState(3 + k)
+    m = (rng.rand(3, 37, 53) > 0.985).astype(np.uint8) * 200
+    m[0, :3, :5] = 255; m[0, -1, -1] = 1; m[1, 17:22, 0] = 9; m[2] = 0
+    out = hip.binary_dilate(torch.from_numpy(m).to(dev), k).cpu().numpy()
+    for i in range(3):
+        want = (scipy.ndimage.binary_dilation(m[i], iterations=k) if k > 0 else m[i] > 0).astype(np.uint8) * 255
+        assert np.array_equal(out[i], want), (k, i, int((out[i] != want).sum()))
