@@ -81,3 +81,34 @@ def test_save_results_layout(tmp_path):
     wrote = video_io.save_results(str(tmp_path / "clip"), comp, comp, (24, 16), 24, True)
     assert os.path.exists(tmp_path / "clip" / "frames" / "0002.png")
     assert any("inpaint_out" in w for w in wrote) and any("masked_in" in w for w in wrote)
+
+
+def test_flow_files_use_the_reference_format(tmp_path):
+    """PIEH + int32 w, h + float16 data (utils/flow_util.py:28-89); cross-checked with the real reference when present."""
+    from propainter_amd import flow_io
+    rng = np.random.RandomState(0)
+    flow = (rng.randn(12, 20, 2) * 7).astype(np.float32)
+    p = str(tmp_path / "a" / "00000_f.flo")
+    flow_io.flowwrite(flow, p)
+    raw = open(p, "rb").read()
+    assert raw[:4] == b"PIEH" and np.frombuffer(raw[4:12], np.int32).tolist() == [20, 12] and len(raw) == 12 + 12 * 20 * 2 * 2
+    back = flow_io.flowread(p)
+    assert back.dtype == np.float32 and np.array_equal(back, flow.astype(np.float16).astype(np.float32))
+    bad = str(tmp_path / "bad.flo")
+    with open(bad, "wb") as f:
+        f.write(b"XXXX" + raw[4:])
+    with pytest.raises(IOError):
+        flow_io.flowread(bad)
+    ff, fb = rng.randn(3, 2, 8, 16).astype(np.float32), rng.randn(3, 2, 8, 16).astype(np.float32)
+    flow_io.save_clip_flows(ff, fb, str(tmp_path / "clip"))
+    lf, lb = flow_io.load_clip_flows(str(tmp_path / "clip"))
+    assert np.array_equal(lf, ff.astype(np.float16).astype(np.float32)) and lb.shape == fb.shape
+    if os.path.exists("/root/reference/utils/flow_util.py"):
+        from oracle.ref_shims import load_reference
+        load_reference()
+        import importlib
+        ref = importlib.import_module("utils.flow_util")
+        q = str(tmp_path / "ref.flo")
+        ref.flowwrite(flow, q)
+        assert open(q, "rb").read() == raw
+        assert np.array_equal(ref.flowread(q), back) and np.array_equal(flow_io.flowread(q), back)
