@@ -105,9 +105,11 @@ def test_flow_files_use_the_reference_format(tmp_path):
     assert np.array_equal(lf, ff.astype(np.float16).astype(np.float32)) and lb.shape == fb.shape
     if os.path.exists("/root/reference/utils/flow_util.py"):
         from oracle.ref_shims import load_reference
-        load_reference()
-        import importlib
-        ref = importlib.import_module("utils.flow_util")
+        load_reference()                                  # installs the cv2 stub the reference module imports
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("_ref_flow_util", "/root/reference/utils/flow_util.py")
+        ref = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(ref)
         q = str(tmp_path / "ref.flo")
         ref.flowwrite(flow, q)
         assert open(q, "rb").read() == raw
