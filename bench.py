@@ -73,7 +73,7 @@ def parse():
     ap.add_argument("--detail", action="store_true", help="split the per-kernel table by convolution layer shape (diagnostic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the instrumented (per-kernel HIP events) step")
-    ap.add_argument("--cpu-sample-frames", type=int, default=4)
+    ap.add_argument("--cpu-sample-frames", type=int, default=16, help="frames of the 432x240 CPU-oracle sample (about 10-15 s on 16 threads)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
