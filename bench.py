@@ -188,8 +188,13 @@ def main():
     if not args.eager:
         from propainter_amd.pipeline import ClipGraph
         t_c = time.perf_counter()
-        graph = ClipGraph(models, L, H, W, cfg, dev, example=(frames_dev, masks_dev, masks_dev))
-        torch.cuda.synchronize()
+        try:
+            graph = ClipGraph(models, L, H, W, cfg, dev, example=(frames_dev, masks_dev, masks_dev))
+            torch.cuda.synchronize()
+        except Exception as e:       # capture refused (driver / runtime state): measure the eager submission instead of dying
+            sys.stderr.write(f"[bench] hipGraph capture failed on rank {rank} ({type(e).__name__}: {e}); falling back to eager launches\n")
+            graph = None
+            torch.cuda.synchronize()
         capture_s = time.perf_counter() - t_c
 
     def step(stage_hook=None):

@@ -237,7 +237,9 @@ class ClipGraph:
         if release_eager_pool:                   # hand the eager pass's cached blocks back before the graph pool grows
             torch.cuda.empty_cache()             # (default: keep them -- 288 GB holds both pools and later eager passes stay warm)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: helper threads of the process (e.g. the RCCL watchdog polling its events in a multi-GPU job) must
+        # not invalidate the capture; this thread itself issues nothing but kernel launches and pool allocations
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.out = run()
 
     def _load(self, frames_u8, flow_masks_u8, masks_dilated_u8):
