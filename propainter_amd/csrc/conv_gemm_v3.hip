@@ -185,6 +185,23 @@ __global__ __launch_bounds__(TH * TW * 2) void conv_halo_kernel(const ConvParams
 #pragma unroll
     for (int t = 0; t < NTAPS; ++t) {
       if constexpr (PROF) pf_a = __builtin_readcyclecounter();
+      // [variant STAGGER == 4, impl 83, NOT yet run on a GPU] the patch is resident for the whole channel block, so for
+      // t > 0 the A fragments of this step can be requested BEFORE the barrier: their LDS latency hides behind the wait
+      // for the weight tile.  (t == 0 reads a patch other waves may still be receiving: after the barrier.)
+      const int sh = (t / KW) * PW + (t % KW);          // compile-time after unrolling
+      f16x8 afp[2][TM];
+      if constexpr (STAGGER == 4) {
+        if (t > 0) {
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int f = 0; f < TM; ++f) {
+              const int row = pp0[f] + sh;
+              afp[kk][f] = *reinterpret_cast<const f16x8*>(pcur + row * 128 + (((kk * 4 + l4) ^ ((row >> 1) & 7)) << 4));
+            }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if constexpr (PROF) { pf_b = __builtin_readcyclecounter(); pf_vm += pf_b - pf_a; }
       __builtin_amdgcn_s_barrier();          // weights of step ks (and, at t == 0, the whole patch of this block) are in LDS
@@ -194,15 +211,18 @@ __global__ __launch_bounds__(TH * TW * 2) void conv_halo_kernel(const ConvParams
       if constexpr (STAGGER != 3) { if (more_b) V3_ISSUE_B(ks + 1, par ^ 1); }
       if (t < PPW && have_next) V3_ISSUE_PIECE(t, pnext, en);
       if constexpr (PROF) { pf_a = __builtin_readcyclecounter(); pf_issue += pf_a - pf_c; }
-      const int sh = (t / KW) * PW + (t % KW);          // compile-time after unrolling
       const char* sb = bst0 + par * BSTAGE;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         f16x8 af[TM], bf[TN];
 #pragma unroll
         for (int f = 0; f < TM; ++f) {
-          const int row = pp0[f] + sh;
-          af[f] = *reinterpret_cast<const f16x8*>(pcur + row * 128 + (((kk * 4 + l4) ^ ((row >> 1) & 7)) << 4));
+          if (STAGGER == 4 && t > 0) {
+            af[f] = afp[kk][f];
+          } else {
+            const int row = pp0[f] + sh;
+            af[f] = *reinterpret_cast<const f16x8*>(pcur + row * 128 + (((kk * 4 + l4) ^ ((row >> 1) & 7)) << 4));
+          }
         }
 #pragma unroll
         for (int f = 0; f < TN; ++f)
@@ -299,6 +319,12 @@ int conv_v3_dispatch(const ConvParams& p, int cfg, hipStream_t stream) {
     if (kh == 3 && kw == 3) return cfg == 74 ? launch_v3<8, 16, 3, 3, 128, false, 3>(p, stream) : launch_v3<8, 16, 3, 3, 128, true, 3>(p, stream);
     if (kh == 1 && kw == 5) return cfg == 74 ? launch_v3<8, 16, 1, 5, 128, false, 3>(p, stream) : launch_v3<8, 16, 1, 5, 128, true, 3>(p, stream);
     if (kh == 5 && kw == 1) return cfg == 74 ? launch_v3<16, 8, 5, 1, 128, false, 3>(p, stream) : launch_v3<16, 8, 5, 1, 128, true, 3>(p, stream);
+    return -1000;
+  }
+  if (cfg == 83) {   // A fragments requested ahead of the step barrier (experimental: compile-checked only)
+    if (kh == 3 && kw == 3) return launch_v3<8, 16, 3, 3, 128, false, 4>(p, stream);
+    if (kh == 1 && kw == 5) return launch_v3<8, 16, 1, 5, 128, false, 4>(p, stream);
+    if (kh == 5 && kw == 1) return launch_v3<16, 8, 5, 1, 128, false, 4>(p, stream);
     return -1000;
   }
   if (cfg == 79) {   // 256-pixel tiles, 8 waves, one block per CU: the weight tile is fetched from L2 once per CU and step
