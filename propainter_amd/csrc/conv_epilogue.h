@@ -14,8 +14,10 @@
 namespace pp {
 
 // RowMap: prow (0..WM-1, pixel row of the wave tile) -> flat output pixel index, or -1 when the row is outside the image.
-template <int WM, int WN, typename RowMap>
-__device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[WN / 16][WM / 16], char* wave_lds, int lane,
+// TNT / A0: the accumulator array may be wider than the WN couts handled by this call (128-cout wave tiles are drained in
+// two calls of 64): tiles A0 .. A0 + WN/16 - 1 of acc[TNT][TM] are used.
+template <int WM, int WN, int TNT = WN / 16, int A0 = 0, typename RowMap>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc_)[TNT][WM / 16], char* wave_lds, int lane,
                                               int co_wave /* first cout of the wave tile within the group */, int g,
                                               char* outp, const RowMap rowmap, const f32x4* bias_pre = nullptr) {
   constexpr int TM = WM / 16, TN = WN / 16;
@@ -43,26 +45,26 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
         for (int b = 0; b < TM; ++b)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float v = (acc[a][b][r] + b4[r]) * scale;
-            acc[a][b][r] = v > 0.f ? v : v * slope;
+            const float v = (acc_[A0 + a][b][r] + b4[r]) * scale;
+            acc_[A0 + a][b][r] = v > 0.f ? v : v * slope;
           }
       } else if (act == PP_ACT_SIGMOID) {             // 1 / (1 + e^-v): v_exp + v_rcp (1 ulp; the result is rounded to fp16)
 #pragma unroll
         for (int b = 0; b < TM; ++b)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            acc[a][b][r] = __builtin_amdgcn_rcpf(1.f + __expf(-(acc[a][b][r] + b4[r]) * scale));
+            acc_[A0 + a][b][r] = __builtin_amdgcn_rcpf(1.f + __expf(-(acc_[A0 + a][b][r] + b4[r]) * scale));
       } else if (act == PP_ACT_TANH) {                // 1 - 2 / (e^2v + 1); saturates correctly at +-inf
 #pragma unroll
         for (int b = 0; b < TM; ++b)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            acc[a][b][r] = 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * (acc[a][b][r] + b4[r]) * scale) + 1.f);
+            acc_[A0 + a][b][r] = 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * (acc_[A0 + a][b][r] + b4[r]) * scale) + 1.f);
       } else {
 #pragma unroll
         for (int b = 0; b < TM; ++b)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[a][b][r] = apply_act_special((acc[a][b][r] + b4[r]) * scale, act);
+          for (int r = 0; r < 4; ++r) acc_[A0 + a][b][r] = apply_act_special((acc_[A0 + a][b][r] + b4[r]) * scale, act);
       }
     }
   }
@@ -72,7 +74,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
 #pragma unroll
       for (int b = 0; b < TM; ++b)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[a][b][r] = fmaxf(acc[a][b][r], 0.f);
+        for (int r = 0; r < 4; ++r) acc_[A0 + a][b][r] = fmaxf(acc_[A0 + a][b][r], 0.f);
   }
   constexpr int LPR = WN / 8;                       // lanes per pixel row (8 couts each)
   constexpr int RPP = 64 / LPR;                     // pixel rows per pass
@@ -89,7 +91,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
       for (int a = 0; a < TN; ++a) {
         f16x4 h;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) h[r] = (_Float16)acc[a][b][r];
+        for (int r = 0; r < 4; ++r) h[r] = (_Float16)acc_[A0 + a][b][r];
         *reinterpret_cast<f16x4*>(wave_lds + (b * 16 + l15) * LD + (a * 16 + l4 * 4) * 2) = h;
       }
     const bool vec_ok = ((p.out_cstride | out_cbase) & 7) == 0;
@@ -117,7 +119,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
 #pragma unroll
   for (int b = 0; b < TM; ++b)
 #pragma unroll
-    for (int a = 0; a < TN; ++a) *reinterpret_cast<f32x4*>(et + (b * 16 + l15) * LDF + a * 16 + l4 * 4) = acc[a][b];
+    for (int a = 0; a < TN; ++a) *reinterpret_cast<f32x4*>(et + (b * 16 + l15) * LDF + a * 16 + l4 * 4) = acc_[A0 + a][b];
   const int res_cbase = p.res_choff + g * p.out_cgroup;
   const bool res_vec_ok = ((p.res_cstride | res_cbase) & 7) == 0;
   const bool relu2 = p.act2 == PP_ACT_RELU;

@@ -56,7 +56,8 @@ __global__ __launch_bounds__(TH * TW * 2) void conv_halo_kernel(const ConvParams
   constexpr int B_PER_WAVE = (B_INST + NW - 1) / NW;
   constexpr bool B_RAGGED = (B_INST % NW) != 0;                 // BN 16: only waves 0..B_INST-1 fetch weights
   constexpr int PIPE_BYTES = 2 * PATCH_BYTES + 2 * BSTAGE;
-  constexpr int EPI_LD = WN + 4;
+  constexpr int EPI_WN = WN > 64 ? 64 : WN;                    // the epilogue stages at most 64 couts of the wave tile at a time
+  constexpr int EPI_LD = EPI_WN + 4;
   constexpr int EPI_BYTES = NW * WM * EPI_LD * 4;
   constexpr int LDS_BYTES = PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES;
   static_assert((BM == 128 || BM == 256) && (TW == 16 || TW == 8) && PPW <= NTAPS && (BN % 32 == 0 || BN == 16) &&
@@ -264,7 +265,15 @@ __global__ __launch_bounds__(TH * TW * 2) void conv_halo_kernel(const ConvParams
     }
   };
   const RowMap rowmap{wm * WM, ty0, tx0, p.H, p.W, (long long)n * p.H};
-  conv_epilogue<WM, WN>(p, acc, lds + wave * (EPI_BYTES / NW), lane, n0 + wn * WN, 0, p.out, rowmap);
+  if constexpr (WN <= 64) {
+    conv_epilogue<WM, WN>(p, acc, lds + wave * (EPI_BYTES / NW), lane, n0 + wn * WN, 0, p.out, rowmap);
+  } else {
+    // 128-cout wave tiles (BN 256, experimental): two passes of 64 couts through the same wave-private staging tile
+    // (LDS operations of one wave execute in order, so the second pass cannot overtake the first pass's reads)
+    static_assert(WN == 128, "wave tiles wider than 64 couts are drained in two halves");
+    conv_epilogue<WM, 64, TN, 0>(p, acc, lds + wave * (EPI_BYTES / NW), lane, n0 + wn * WN, 0, p.out, rowmap);
+    conv_epilogue<WM, 64, TN, 4>(p, acc, lds + wave * (EPI_BYTES / NW), lane, n0 + wn * WN + 64, 0, p.out, rowmap);
+  }
   if constexpr (PROF) {
     const unsigned long long te = __builtin_readcyclecounter();
     if (lane == 0 && (blockIdx.x & 63) == 5) {        // a 1/64 sample of the blocks: the atomics must not perturb the run
@@ -319,6 +328,13 @@ int conv_v3_dispatch(const ConvParams& p, int cfg, hipStream_t stream) {
     if (kh == 3 && kw == 3) return cfg == 74 ? launch_v3<8, 16, 3, 3, 128, false, 3>(p, stream) : launch_v3<8, 16, 3, 3, 128, true, 3>(p, stream);
     if (kh == 1 && kw == 5) return cfg == 74 ? launch_v3<8, 16, 1, 5, 128, false, 3>(p, stream) : launch_v3<8, 16, 1, 5, 128, true, 3>(p, stream);
     if (kh == 5 && kw == 1) return cfg == 74 ? launch_v3<16, 8, 5, 1, 128, false, 3>(p, stream) : launch_v3<16, 8, 5, 1, 128, true, 3>(p, stream);
+    return -1000;
+  }
+  if (cfg == 84) {   // 256 px x 256 couts per block, 8 waves of 64 px x 128 couts (experimental: compile-checked only)
+    if (p.cout_g < 192) return -1000;
+    if (kh == 3 && kw == 3) return launch_v3<16, 16, 3, 3, 256>(p, stream);
+    if (kh == 1 && kw == 5) return launch_v3<16, 16, 1, 5, 256>(p, stream);
+    if (kh == 5 && kw == 1) return launch_v3<16, 16, 5, 1, 256>(p, stream);
     return -1000;
   }
   if (cfg == 83) {   // A fragments requested ahead of the step barrier (experimental: compile-checked only)
