@@ -9,17 +9,25 @@ scripts/evaluate_propainter.py:100-101,181-184: decode, mask dilation and model 
     python bench.py --gpus 1 --steps 2 --warmup 1                      # 720x1280, 80 frames, fp16 (BASELINE C3)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W                         # N independent clips, one per GPU (weak scaling)
+    ... bench.py --gpus N --sharded --frames 320                        # BASELINE C4: ONE clip, sub-video shards over N GPUs
+    ... bench.py --gpus N --sharded --height 1080 --width 1920 --frames 160 --subvideo_length 20     # BASELINE C5
 
-Rank 0 prints ONE JSON line (schema: see README / the driver contract) with two extra objects:
-  "roofline":     the dominant kernel class of the step measured live with HIP events on the launch stream
-                  (KernelProfiler in propainter_amd/hip.py) in one extra instrumented step after the timed region;
-  "cpu_baseline": the CPU oracle (oracle/propainter_oracle.py — the checker, never the product) timed on this
-                  box's host cores on a bounded sample, rank 0, N=1 only.
+Rank 0 prints ONE JSON line (schema: see README / the driver contract) with these extra objects:
+  "roofline":        the dominant kernel class of the step measured live with HIP events on the launch stream
+                     (KernelProfiler in propainter_amd/hip.py) in one extra instrumented step after the timed region;
+  "cpu_baseline":    the CPU oracle (oracle/propainter_oracle.py -- the checker, never the product) timed on this
+                     box's host cores on a bounded sample, rank 0, N=1 only;
+  "parity":          the HIP path at the TIMED precision configuration on the very clip the CPU oracle sample inpaints
+                     (432x240), compared byte for byte with the oracle's frames (PSNR, max |d|, fraction of differing bytes);
+  "raft_precisions": frames/s and parity of the same pass with RAFT at the reference's own precision class
+                     ("f16x3": fp32 tensors, products as 3 fp16 MFMAs; "f32": exact fp32 MFMA) next to the headline's;
+  "memory":          peak device memory of the pass (the reference publishes only memory: README.md:192-195).
 """
 import argparse
 import json
 import os
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -32,21 +40,24 @@ PEAK_HBM_GBS = 8000.0
 TRAFFIC_FAMILY = {"conv_gemm_f16": "conv_gemm_f16 (LDS-DMA implicit GEMM)", "conv_gemm_f32": "conv_gemm_f32",
                   "conv_gemm_dcn": "conv_gemm_f16/dcn (register-staged)", "sparse_window_attention": "sparse_window_attention",
                   "fold_tokens": "fold_tokens", "corr_lookup": "corr_lookup"}
+# minimal algorithmic FLOPs of BASELINE config 3 (720x1280x80, 25 % of the windows masked)
+C3_ALGORITHMIC_TFLOP = 599.0
 
 
 def pmc_traffic(kernel_class):
-    """HBM bytes per launch of a kernel class from the committed rocprofv3 --pmc summary (FETCH_SIZE / WRITE_SIZE in
-    separate passes, gfx950 correction applied by tools/rocprof_summary.py); None when no summary is present."""
+    """HBM bytes per launch of a kernel class from the newest committed rocprofv3 --pmc summary (FETCH_SIZE / WRITE_SIZE
+    in separate passes, gfx950 correction applied by tools/rocprof_summary.py).  Returns (bytes or None, source file):
+    PMC counters cannot be collected inside this process, so the figure is the committed profile's, not this run's."""
     import glob
     fam = TRAFFIC_FAMILY.get(kernel_class)
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_traffic*.json")), reverse=True):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_traffic*.json")), key=os.path.getmtime, reverse=True):
         try:
             rec = json.load(open(f))["families"].get(fam)
         except Exception:
             continue
         if rec:
-            return rec["hbm_bytes_per_launch"]
-    return None
+            return rec["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
+    return None, None
 
 
 def parse():
@@ -62,76 +73,137 @@ def parse():
     ap.add_argument("--subvideo_length", type=int, default=80)
     ap.add_argument("--raft_iter", type=int, default=20)
     ap.add_argument("--fp32", action="store_true", help="run stages B-D in fp32 instead of fp16")
-    ap.add_argument("--raft-dtype", default="f16", choices=["f32", "f16"],
-                    help="RAFT engine dtype: f16 (default) = fp16 activations/weights on MFMA with fp32 accumulation, fp32 "
-                         "correlation volume, coordinates and flow (SURVEY.md section 7; measured EPE vs the fp32 reference "
-                         "in tests/test_modules_gpu.py); f32 = exact fp32 MFMA like the reference, which keeps RAFT fp32 "
-                         "under --fp16 (inference_propainter.py:311)")
+    ap.add_argument("--raft-dtype", default="f16", choices=["f32", "f16x3", "f16"],
+                    help="RAFT precision of the TIMED pass: f16 (default) = fp16 activations/weights on MFMA with fp32 "
+                         "accumulation, fp32 correlation values, coordinates and flow; f16x3 = fp32 tensors, every product as "
+                         "three fp16 MFMAs (hi*hi + hi*lo + lo*hi, ~2^-21); f32 = exact fp32 MFMA.  The reference keeps RAFT "
+                         "fp32 under --fp16 (inference_propainter.py:311): the other two modes are timed once each and "
+                         "reported under raft_precisions")
+    ap.add_argument("--sharded", action="store_true",
+                    help="ONE clip of --frames frames sharded by sub-video over the ranks (propainter_amd/sharding.py, RCCL "
+                         "point-to-point halo exchange; BASELINE configs 4 / 5) instead of one clip per rank; strong scaling")
     ap.add_argument("--eager", action="store_true",
                     help="issue every launch from Python each step instead of replaying the captured hipGraph of the pass "
                          "(pipeline.ClipGraph); the kernels and their order are identical, only the submission differs")
     ap.add_argument("--detail", action="store_true", help="split the per-kernel table by convolution layer shape (diagnostic)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU-oracle sample (and with it the parity block)")
     ap.add_argument("--no-profile", action="store_true", help="skip the instrumented (per-kernel HIP events) step")
-    ap.add_argument("--cpu-sample-frames", type=int, default=16, help="frames of the 432x240 CPU-oracle sample (about 10-15 s on 16 threads)")
-    ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-precisions", action="store_true", help="skip the extra timed steps at the other RAFT precisions")
+    ap.add_argument("--cpu-sample-frames", type=int, default=16, help="frames of the 432x240 CPU-oracle sample (about 10-25 s on 16 threads)")
+    ap.add_argument("--cpu-baseline-worker", default=None, help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
-def _cpu_baseline_worker(args):
-    """Runs in a child process (bounded by a timeout in the parent): the CPU oracle, fp32, on the host cores."""
+SAMPLE_H, SAMPLE_W = 240, 432
+
+
+def sample_clip(args):
+    """The bounded sample both the CPU oracle and the parity check run on: a short 432x240 synthetic clip."""
     import numpy as np
     import scipy.ndimage
+    from propainter_amd.synthetic import synthetic_clip, synthetic_mask
+    L = args.cpu_sample_frames
+    clip = synthetic_clip(L, SAMPLE_H, SAMPLE_W)
+    m = scipy.ndimage.binary_dilation(synthetic_mask(SAMPLE_H, SAMPLE_W), iterations=4).astype(np.uint8) * 255
+    return clip, np.repeat(m[None], L, 0)
+
+
+def _cpu_baseline_worker(args):
+    """Runs in a child process (bounded by a timeout in the parent): the CPU oracle, fp32, on the host cores.  Writes the
+    composited frames to the .npy path given on the command line (the parity check of the parent reads them)."""
+    import numpy as np
     import torch
     from oracle import propainter_oracle as O
-    from propainter_amd.synthetic import seeded_models, synthetic_clip, synthetic_mask
+    from propainter_amd.synthetic import seeded_models
     cores = int(os.environ.get("PP_CPU_THREADS", "1"))
     torch.set_num_threads(cores)
-    H, W, L = 240, 432, args.cpu_sample_frames
-    clip = synthetic_clip(L, H, W)
-    m = scipy.ndimage.binary_dilation(synthetic_mask(H, W), iterations=4).astype(np.uint8) * 255
-    masks = np.repeat(m[None], L, 0)
+    clip, masks = sample_clip(args)
     raft, fc, gen = seeded_models("cpu")
     sds = {"raft": {k: v.float() for k, v in raft.fix_raft.state_dict().items()},
            "fc": {k: v.float() for k, v in fc.state_dict().items()},
            "gen": {k: v.float() for k, v in gen.state_dict().items()}}
     t0 = time.perf_counter()
     with torch.no_grad():
-        O.inpaint_video(sds, clip, masks, masks, raft_iter=args.raft_iter, subvideo_length=args.subvideo_length,
-                        neighbor_length=args.neighbor_length, ref_stride=args.ref_stride)
+        frames = O.inpaint_video(sds, clip, masks, masks, raft_iter=args.raft_iter, subvideo_length=args.subvideo_length,
+                                 neighbor_length=args.neighbor_length, ref_stride=args.ref_stride)
     dt = time.perf_counter() - t0
-    print(json.dumps({"seconds": dt, "frames": L, "cores": cores, "H": H, "W": W}))
+    np.save(args.cpu_baseline_worker, np.stack(frames))
+    print(json.dumps({"seconds": dt, "frames": len(frames), "cores": cores, "H": SAMPLE_H, "W": SAMPLE_W}))
 
 
-def cpu_baseline(args, timeout=240):
+class CpuBaseline:
     """CPU oracle (fp32) on a bounded sample: the full path over a short 432x240 clip in a child process with a hard
-    timeout, scaled to the bench resolution by the algorithmic FLOPs per frame."""
-    import subprocess
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    cores = max(1, min(avail, 16))          # the oracle's small ops stop scaling (and oversubscribe) beyond ~16 threads
-    env = dict(os.environ, PP_CPU_THREADS=str(cores), OMP_NUM_THREADS=str(cores), MKL_NUM_THREADS=str(cores),
-               HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--cpu-sample-frames", str(args.cpu_sample_frames),
-           "--raft_iter", str(args.raft_iter), "--subvideo_length", str(args.subvideo_length),
-           "--neighbor_length", str(args.neighbor_length), "--ref_stride", str(args.ref_stride)]
-    try:
-        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
-        rec = json.loads(r.stdout.decode().strip().splitlines()[-1])
-    except Exception as e:  # timeout / crash: report it instead of blocking the bench
-        return {"value": None, "unit": "frames/s", "cores": cores, "kind": "port",
-                "sample": f"CPU oracle sample did not finish within {timeout} s on {cores} threads ({type(e).__name__})"}
-    dt, L, H, W = rec["seconds"], rec["frames"], rec["H"], rec["W"]
-    fps_sample = L / dt
-    # per-frame algorithmic work: 7.49 TFLOP at 720x1280 vs 0.80 TFLOP at 240x432 (BASELINE.md section 3), ~ linear in pixels
-    scale = (args.height * args.width) / float(720 * 1280) * (7.49 / 0.80)
-    return {"value": fps_sample / scale, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"CPU oracle fp32, full path on a {L}-frame {W}x{H} synthetic clip: {dt:.1f} s = {fps_sample:.4f} frames/s "
-                      f"on {cores} threads ({avail} available); scaled to {args.width}x{args.height} by algorithmic "
-                      f"FLOPs/frame (/{scale:.2f})",
-            "measured_sample_seconds": dt}
+    timeout, started next to the GPU work (it uses host cores only) and collected at the end; scaled to the bench
+    resolution by the algorithmic FLOPs per frame."""
+
+    def __init__(self, args, timeout=300):
+        import subprocess
+        self.args, self.timeout = args, timeout
+        try:
+            self.avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            self.avail = os.cpu_count() or 1
+        self.cores = max(1, min(self.avail - 1, 16))    # the oracle's small ops stop scaling (and oversubscribe) beyond ~16 threads
+        env = dict(os.environ, PP_CPU_THREADS=str(self.cores), OMP_NUM_THREADS=str(self.cores), MKL_NUM_THREADS=str(self.cores),
+                   HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        fd, self.out_path = tempfile.mkstemp(suffix=".npy", prefix="pp_oracle_")
+        os.close(fd)
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", self.out_path,
+               "--cpu-sample-frames", str(args.cpu_sample_frames), "--raft_iter", str(args.raft_iter),
+               "--subvideo_length", str(args.subvideo_length), "--neighbor_length", str(args.neighbor_length),
+               "--ref_stride", str(args.ref_stride)]
+        self.t_start = time.perf_counter()
+        self.proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+
+    def collect(self):
+        """-> (cpu_baseline dict, oracle frames uint8 [L,H,W,3] or None)"""
+        import numpy as np
+        import subprocess
+        args, cores = self.args, self.cores
+        try:
+            left = max(1.0, self.timeout - (time.perf_counter() - self.t_start))
+            so, _ = self.proc.communicate(timeout=left)
+            rec = json.loads(so.decode().strip().splitlines()[-1])
+            frames = np.load(self.out_path)
+        except Exception as e:  # timeout / crash: report it instead of blocking the bench
+            try:
+                self.proc.kill()
+            except Exception:
+                pass
+            return ({"value": None, "unit": "frames/s", "cores": cores, "kind": "port",
+                     "sample": f"CPU oracle sample did not finish within {self.timeout} s on {cores} threads ({type(e).__name__})"}, None)
+        finally:
+            try:
+                os.unlink(self.out_path)
+            except OSError:
+                pass
+        dt, L, H, W = rec["seconds"], rec["frames"], rec["H"], rec["W"]
+        fps_sample = L / dt
+        # per-frame algorithmic work: 7.49 TFLOP at 720x1280 vs 0.80 TFLOP at 240x432 (BASELINE.md section 3), ~ linear in pixels
+        scale = (args.height * args.width) / float(720 * 1280) * (7.49 / 0.80)
+        return ({"value": fps_sample / scale, "unit": "frames/s", "cores": cores, "kind": "port",
+                 "sample": f"CPU oracle fp32, full path on a {L}-frame {W}x{H} synthetic clip: {dt:.1f} s = {fps_sample:.4f} frames/s "
+                           f"on {cores} threads ({self.avail} available), measured while the GPU legs of this bench ran; "
+                           f"EXTRAPOLATED to {args.width}x{args.height} by algorithmic FLOPs/frame (/{scale:.2f}), not measured "
+                           f"at that size",
+                 "measured_sample_seconds": dt, "measured_sample_fps": fps_sample}, frames)
+
+
+def parity_of(got_u8, ref_u8, masks_u8):
+    """Byte-level comparison of composited frames with the oracle's (uint8 [L,H,W,3]); the PSNR is also given over the
+    hole only (outside the dilated mask both are the input frame, which inflates a whole-frame PSNR)."""
+    import numpy as np
+    from oracle import propainter_oracle as O
+    d = np.abs(got_u8.astype(np.int16) - ref_u8.astype(np.int16))
+    hole = np.broadcast_to((masks_u8 > 0)[..., None], got_u8.shape)
+    mse_h = float((d[hole].astype(np.float64) ** 2).mean()) if hole.any() else 0.0
+    return {"psnr_db": round(O.psnr(got_u8, ref_u8), 2),
+            "psnr_hole_db": round(float("inf") if mse_h == 0 else 20.0 * np.log10(255.0 / np.sqrt(mse_h)), 2),
+            "max_abs": int(d.max()), "bytes_differ_frac": float((d > 0).mean()),
+            "bytes_differ_frac_hole": float((d[hole] > 0).mean()) if hole.any() else 0.0,
+            "bytes_off_by_more_than_1_frac_hole": float((d[hole] > 1).mean()) if hole.any() else 0.0}
 
 
 def main():
@@ -154,24 +226,49 @@ def main():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    cpu_job = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_job = CpuBaseline(args)           # host cores only; runs while the GPU legs below execute
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
     hip.lib()
 
     H, W, L = args.height, args.width, args.frames
     fp16 = not args.fp32
-    raft_dt = torch.float16 if args.raft_dtype == "f16" else None
-    models = seeded_models(dev, raft_dtype=raft_dt)
-    # every rank inpaints its own clip (sub-video sharding of a long video = independent windows per GPU; weak scaling)
-    clip = synthetic_clip(L, H, W, seed=2023 + rank)
-    m = scipy.ndimage.binary_dilation(synthetic_mask(H, W), iterations=4).astype(np.uint8) * 255
-    frames_dev = torch.from_numpy(clip).to(dev)
-    masks_dev = torch.from_numpy(np.repeat(m[None], L, 0)).to(dev)
-    host_out = torch.empty((L, H, W, 3), dtype=torch.uint8).pin_memory()
+    models = seeded_models(dev, raft_precision=args.raft_dtype)
     cfg = InferenceConfig(raft_iter=args.raft_iter, subvideo_length=args.subvideo_length,
                           neighbor_length=args.neighbor_length, ref_stride=args.ref_stride, fp16=fp16)
+    m = scipy.ndimage.binary_dilation(synthetic_mask(H, W), iterations=4).astype(np.uint8) * 255
+    sharded = bool(args.sharded)
+    exchange_stats = {}
+    if sharded:
+        from propainter_amd.sharding import ShardPlan, can_shard, run_clip_sharded
+        # ONE clip for the whole job (same seed on every rank: the raw input is host-resident everywhere, as in the CLI)
+        clip = synthetic_clip(L, H, W, seed=2023)
+        masks_np = np.repeat(m[None], L, 0)
+        use_ranks = world > 1 and can_shard(L, cfg, world)
+        if world > 1 and not use_ranks:
+            raise SystemExit(f"--sharded: a {L}-frame clip does not split into sub-videos of {args.subvideo_length} over {world} ranks")
+        clip_pin, masks_pin = torch.from_numpy(clip).pin_memory(), torch.from_numpy(masks_np).pin_memory()
+        own = ShardPlan(L, cfg, world).own[rank] if use_ranks else (0, L)
+        host_out = torch.empty((max(1, own[1] - own[0]), H, W, 3), dtype=torch.uint8).pin_memory()
+        frames_dev = masks_dev = None
+        if not use_ranks:
+            frames_dev, masks_dev = clip_pin.to(dev), masks_pin.to(dev)
+    else:
+        # every rank inpaints its own clip (independent windows per GPU; weak scaling)
+        clip = synthetic_clip(L, H, W, seed=2023 + rank)
+        frames_dev = torch.from_numpy(clip).to(dev)
+        masks_dev = torch.from_numpy(np.repeat(m[None], L, 0)).to(dev)
+        host_out = torch.empty((L, H, W, 3), dtype=torch.uint8).pin_memory()
+        use_ranks = False
 
     def eager_step(stage_hook=None):
+        if use_ranks:       # sub-video shards: every rank uploads the slice of the raw input it needs inside the step
+            lo, comp = run_clip_sharded(models, clip_pin, masks_pin, masks_pin, cfg, dev, stats=exchange_stats)
+            if comp.shape[0]:
+                host_out[:comp.shape[0]].copy_(comp, non_blocking=True)
+            return
         comp = run_clip(models, frames_dev, masks_dev, masks_dev, cfg, dev, stage_hook=stage_hook)
         host_out.copy_(comp, non_blocking=True)
 
@@ -180,12 +277,16 @@ def main():
     eager_step()
     eager_step()                      # the allocator settles on the second pass (its blocks are carved during the first)
     torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats(dev)
     t_e = time.perf_counter()
     eager_step()
     torch.cuda.synchronize()
     eager_ms = (time.perf_counter() - t_e) * 1e3
+    peak_eager = torch.cuda.max_memory_allocated(dev)
+    exchange_stats.clear()
     graph = None
-    if not args.eager:
+    capture_s = None
+    if not args.eager and not use_ranks:      # (the sharded pass interleaves RCCL exchanges with the stages: eager submission)
         from propainter_amd.pipeline import ClipGraph
         t_c = time.perf_counter()
         try:
@@ -211,6 +312,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    exchange_stats.clear()
     # per-step markers (diagnostic only, no synchronisation inside the timed region): a HIP event after each step's
     # last launch and the host clock when the step has been fully *submitted*
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -230,11 +332,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
-    fps = world * L * args.steps / elapsed
+    fps = (L if sharded else world * L) * args.steps / elapsed
+    peak_total = torch.cuda.max_memory_allocated(dev)
+    exch = {k: dict(v, ms_per_step=v["ms"] / args.steps, sent_bytes_per_step=v["sent_bytes"] // args.steps,
+                    recv_bytes_per_step=v["recv_bytes"] // args.steps) for k, v in exchange_stats.items()} if use_ranks else None
 
     # ---- one instrumented step: stage split + per-kernel-class HIP-event timing (not part of `value`)
     stages, kernels, roof = None, None, None
-    if rank == 0 and not args.no_profile:
+    if rank == 0 and not args.no_profile and not use_ranks:
         marks = []
 
         def hook(name):
@@ -255,38 +360,94 @@ def main():
             v["gbs"] = v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0.0
         dom = max(kernels.items(), key=lambda kv: kv[1]["ms"])
         name, v = dom
+        traffic, traffic_src = pmc_traffic(name)
+        common = {"kernel": name, "traffic": traffic,
+                  "traffic_source": (f"committed rocprofv3 --pmc profile {traffic_src} (not collected in this run)" if traffic_src else None),
+                  "launches": v["launches"], "avg_launch_us": v["avg_us"],
+                  "algorithmic_bytes_per_launch": v["bytes"] / max(1, v["launches"]),
+                  "share_of_kernel_time": v["ms"] / sum(x["ms"] for x in kernels.values())}
         if name.startswith("conv_gemm") or name == "sparse_window_attention":
             peak = PEAK_TFLOPS["f32" if name.endswith("f32") else "f16"]
-            roof = {"kernel": name, "bound": "mfma", "achieved": v["tflops"], "peak": peak, "unit": "TFLOP/s",
-                    "frac": v["tflops"] / peak, "traffic": pmc_traffic(name), "launches": v["launches"], "avg_launch_us": v["avg_us"],
-                    "algorithmic_flop_per_launch": v["flops"] / max(1, v["launches"]),
-                    "algorithmic_bytes_per_launch": v["bytes"] / max(1, v["launches"]),
-                    "share_of_kernel_time": v["ms"] / sum(x["ms"] for x in kernels.values())}
+            roof = dict(common, bound="mfma", achieved=v["tflops"], peak=peak, unit="TFLOP/s", frac=v["tflops"] / peak,
+                        algorithmic_flop_per_launch=v["flops"] / max(1, v["launches"]))
         else:
-            roof = {"kernel": name, "bound": "hbm", "achieved": v["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": v["gbs"] / PEAK_HBM_GBS, "traffic": pmc_traffic(name), "launches": v["launches"], "avg_launch_us": v["avg_us"],
-                    "algorithmic_bytes_per_launch": v["bytes"] / max(1, v["launches"]),
-                    "share_of_kernel_time": v["ms"] / sum(x["ms"] for x in kernels.values())}
+            roof = dict(common, bound="hbm", achieved=v["gbs"], peak=PEAK_HBM_GBS, unit="GB/s", frac=v["gbs"] / PEAK_HBM_GBS)
         stages["instrumented_step_wall_ms"] = prof_wall * 1e3
 
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args)
+    # ---- the pass at the other RAFT precisions (one settled eager step each; the reference's own RAFT arithmetic is fp32)
+    raft_precisions = None
+    raft = models[0]
+    if rank == 0 and world == 1 and not args.no_precisions and not sharded:
+        raft_precisions = {args.raft_dtype: {"value": fps, "ms_per_step": ms_per_step, "timed": "headline (see value)"}}
+        for prec in ("f16x3", "f32"):
+            if prec == args.raft_dtype:
+                continue
+            raft.precision = prec
+            try:
+                eager_step()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                eager_step()
+                torch.cuda.synchronize()
+                dt1 = time.perf_counter() - t1
+                raft_precisions[prec] = {"value": L / dt1, "ms_per_step": dt1 * 1e3, "timed": "1 settled eager step"}
+            except Exception as e:
+                raft_precisions[prec] = {"value": None, "error": f"{type(e).__name__}: {e}"}
+            finally:
+                raft.precision = args.raft_dtype
+        torch.cuda.empty_cache()
+
+    # ---- parity of the timed configuration (and of the other RAFT precisions) against the CPU oracle's frames
+    cpu, parity = None, None
+    if cpu_job is not None:
+        sclip, smasks = sample_clip(args)
+        got = {}
+        for prec in ([args.raft_dtype] + ([p for p in ("f16x3", "f32") if p != args.raft_dtype] if raft_precisions else [])):
+            raft.precision = prec
+            try:
+                got[prec] = run_clip(models, sclip, smasks, smasks, cfg, dev).cpu().numpy()
+            except Exception as e:
+                got[prec] = f"{type(e).__name__}: {e}"
+            finally:
+                raft.precision = args.raft_dtype
+        torch.cuda.synchronize()
+        cpu, ref_frames = cpu_job.collect()
+        if ref_frames is not None:
+            desc = {"clip": f"{len(sclip)}-frame {SAMPLE_W}x{SAMPLE_H} synthetic clip of the cpu_baseline sample, seeded weights",
+                    "reference": "CPU oracle fp32 (oracle/propainter_oracle.py)", "stages_dtype": "f16" if fp16 else "f32"}
+            for prec, g in got.items():
+                rec = parity_of(g, ref_frames, smasks) if not isinstance(g, str) else {"error": g}
+                if prec == args.raft_dtype:
+                    parity = dict(desc, raft_dtype=prec, dtype="f16" if fp16 else "f32", **rec)
+                if raft_precisions and prec in raft_precisions:
+                    raft_precisions[prec]["parity"] = rec
 
     if rank == 0:
         sched = window_schedule(L, args.neighbor_length, args.ref_stride, args.subvideo_length)
+        par = (f"sub-video shards of one clip x{world}" if sharded else f"clip-sharded x{world}")
+        work = (f"{H}x{W} {L}-frame clip, neighbor_length={args.neighbor_length} ref_stride={args.ref_stride} "
+                f"subvideo_length={args.subvideo_length} raft_iter={args.raft_iter}, "
+                + ("ONE clip sharded by sub-video over the ranks" if sharded else "one clip per GPU"))
+        if roof is not None and roof["bound"] == "mfma" and (H, W, L) == (720, 1280, 80) and not sharded:
+            # whole-pass figure on SURVEY 8(d)'s minimal algorithmic FLOPs (independent of how the engine executes them)
+            roof["whole_pass_algorithmic_tflops"] = C3_ALGORITHMIC_TFLOP / (ms_per_step * 1e-3)
+            roof["whole_pass_frac_of_f16_peak"] = roof["whole_pass_algorithmic_tflops"] / PEAK_TFLOPS["f16"]
         out = {
             "metric": "inpainted frames/sec (whole path, 80-frame window)", "value": fps, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16" if fp16 else "f32",
+            "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
+            "dtype": "f16" if fp16 else "f32",
             "data": "synthetic (seeded clip + rectangular mask dilated x4, seeded weights of the reference architecture)",
-            "config": {"workload": f"{H}x{W} {L}-frame clip, neighbor_length={args.neighbor_length} ref_stride={args.ref_stride} "
-                                   f"subvideo_length={args.subvideo_length} raft_iter={args.raft_iter}, one clip per GPU",
-                       "height": H, "width": W, "frames": L, "windows": len(sched), "raft_dtype": args.raft_dtype,
-                       "stages_dtype": "f16" if fp16 else "f32", "parallelism": f"clip-sharded x{world}"},
-            "roofline": roof, "cpu_baseline": cpu, "stages_ms": stages,
+            "config": {"workload": work, "height": H, "width": W, "frames": L, "windows": len(sched),
+                       "raft_dtype": args.raft_dtype, "stages_dtype": "f16" if fp16 else "f32", "parallelism": par},
+            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "raft_precisions": raft_precisions,
+            "memory": {"peak_allocated_GB_eager_pass": peak_eager / 1e9, "peak_allocated_GB_process": peak_total / 1e9,
+                       "note": "torch.cuda.max_memory_allocated; the eager pass is what a one-shot CLI run needs, the process "
+                               "figure adds the hipGraph's private pool; reference README.md:192 quotes 25 GB fp16 at 720x1280x80 "
+                               "(it runs RAFT in 4-frame clips; this engine batches all 158 pair-directions)"},
+            "exchange": exch, "stages_ms": stages,
             "submission": "eager (Python launches)" if graph is None else "hipGraph replay of the whole pass (pipeline.ClipGraph)",
-            "eager_ms_per_step": eager_ms, "graph_capture_s": None if graph is None else capture_s,
+            "eager_ms_per_step": eager_ms, "graph_capture_s": capture_s,
             "step_ms": step_ms, "host_submit_ms": host_submit, "kernels": kernels,
         }
         print(json.dumps(out))

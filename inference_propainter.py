@@ -8,7 +8,8 @@
 The device path (RAFT, flow completion, image propagation, sliding-window generator, uint8 composite) runs on the
 HIP engine (libpropainter_hip.so); with several processes (one per GPU) a long clip is sharded by sub-video
 (propainter_amd/sharding.py).  Extra flags that the reference does not have: ``--weights_dir``, ``--seeded_weights``
-(no checkpoints ship with either repository), ``--raft_fp32``.
+(no checkpoints ship with either repository), ``--raft_fp16`` / ``--raft_fp32`` (RAFT arithmetic; the default keeps
+RAFT at the reference's precision class under ``--fp16``, see ``raft_precision`` below).
 """
 import argparse
 import os
@@ -44,8 +45,20 @@ def build_parser():
     # ---- not in the reference
     a('--weights_dir', type=str, default='weights', help='folder holding raft-things.pth, recurrent_flow_completion.pth, ProPainter.pth')
     a('--seeded_weights', action='store_true', help='run with the deterministic seeded weights (no checkpoints available offline)')
-    a('--raft_fp32', action='store_true', help='keep the RAFT convolutions in fp32 like the reference (default with --fp16: fp16 MFMA, fp32 accumulate)')
+    a('--raft_fp16', action='store_true', help='opt in to fp16 RAFT activations/weights (fp32 accumulation, correlation, coordinates and flow): '
+      'fastest, ~0.004 px mean end-point error against fp32 at 720p; only with --fp16')
+    a('--raft_fp32', action='store_true', help='exact fp32 RAFT products on the fp32 matrix instructions (slowest)')
     return p
+
+
+def raft_precision(args):
+    """The reference keeps RAFT in fp32 even under --fp16 (inference_propainter.py:311,333-337).  So does this command
+    line: by default RAFT tensors stay fp32 and the products run as three fp16 MFMAs with fp32 accumulation ("f16x3",
+    ~2^-21 per product); --raft_fp32 selects the exact fp32 matrix instructions, --raft_fp16 (with --fp16) the fp16
+    engine.  Without --fp16 everything is exact fp32."""
+    if args.raft_fp32 or not args.fp16:
+        return "f32"
+    return "f16" if args.raft_fp16 else "f16x3"
 
 
 def load_models(args, device):
@@ -53,16 +66,16 @@ def load_models(args, device):
     from propainter_amd.model.modules.flow_comp_raft import RAFT_bi
     from propainter_amd.model.propainter import InpaintGenerator
     from propainter_amd.model.recurrent_flow_completion import RecurrentFlowCompleteNet
-    raft_dt = torch.float16 if (args.fp16 and not args.raft_fp32) else None
+    prec = raft_precision(args)
     if args.seeded_weights:
         from propainter_amd.synthetic import seeded_models
-        return seeded_models(device, raft_dtype=raft_dt)
+        return seeded_models(device, raft_precision=prec)
     paths = {n: os.path.join(args.weights_dir, n) for n in ('raft-things.pth', 'recurrent_flow_completion.pth', 'ProPainter.pth')}
     missing = [p for p in paths.values() if not os.path.exists(p)]
     if missing:
         raise SystemExit(f"missing checkpoints {missing}: place the released .pth files in {args.weights_dir}/ "
                          "(the reference downloads them from its GitHub release) or pass --seeded_weights")
-    fix_raft = RAFT_bi(paths['raft-things.pth'], device, compute_dtype=raft_dt)
+    fix_raft = RAFT_bi(paths['raft-things.pth'], device, precision=prec)
     fix_flow_complete = RecurrentFlowCompleteNet(paths['recurrent_flow_completion.pth'])
     for p in fix_flow_complete.parameters():
         p.requires_grad = False
@@ -115,12 +128,17 @@ def main(argv=None):
     cfg = InferenceConfig(raft_iter=args.raft_iter, subvideo_length=args.subvideo_length, neighbor_length=args.neighbor_length,
                           ref_stride=args.ref_stride, fp16=bool(args.fp16))
     if rank == 0:
-        print(f'\nProcessing: {video_name} [{L} frames]...')
+        print(f'\nProcessing: {video_name} [{L} frames]...  (RAFT precision {models[0].precision}, stages {"fp16" if args.fp16 else "fp32"})')
     t0 = time.perf_counter()
+    comp = None
     if world > 1:
-        from propainter_amd.sharding import gather_frames, run_clip_sharded
-        lo, part = run_clip_sharded(models, frames_u8, flow_masks, masks_dilated, cfg, device)
-        comp = gather_frames(lo, part, L, dst=0)
+        from propainter_amd.sharding import can_shard, gather_frames, run_clip_sharded
+        if can_shard(L, cfg, world):
+            lo, part = run_clip_sharded(models, frames_u8, flow_masks, masks_dilated, cfg, device)
+            comp = gather_frames(lo, part, L, dst=0)
+        elif rank == 0:      # a single sub-video: nothing to shard, rank 0 runs the unsharded pass, the others idle
+            print(f'{L} frames are a single sub-video at --subvideo_length {cfg.subvideo_length}: running on one GPU')
+            comp = run_clip(models, frames_u8, flow_masks, masks_dilated, cfg, device)
     else:
         comp = run_clip(models, frames_u8, flow_masks, masks_dilated, cfg, device)
     torch.cuda.synchronize()

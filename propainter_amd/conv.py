@@ -76,7 +76,7 @@ class ConvLayer:
     """One convolution / linear layer prepared for pp_conv2d (weights packed once, on the device)."""
 
     def __init__(self, weight, bias, *, stride=1, padding=0, dilation=1, groups=1, src_channels=None,
-                 pad_mode="zeros", dtype=torch.float16, device="cuda", taps=None, dcn_groups=0):
+                 pad_mode="zeros", dtype=torch.float16, device="cuda", taps=None, dcn_groups=0, split3=False):
         if weight.dim() == 2:                       # nn.Linear
             weight = weight[:, :, None, None]
         cout, cin_g, kh, kw = weight.shape
@@ -105,6 +105,11 @@ class ConvLayer:
         # K steps of 4 / 8 chunks are (tap, source)-uniform when every source is a multiple of 32 / 64 channels
         self.ktable_uniform = (4 if all(c % 32 == 0 for c in self.src_cpad) else 0) | (8 if all(c % 64 == 0 for c in self.src_cpad) else 0)
         self.impl = 0            # pp_conv_args_t.impl: 0 auto, 1 register-staged kernel, >= 10 a specific LDS-DMA tile
+        # fp32 tensors, products on the fp16 matrix cores as hi*hi + hi*lo + lo*hi (fp32 accumulate): ~2^-21 per
+        # product instead of fp32's 2^-24, 5x the rate of the exact fp32 MFMA (pp_conv_args_t.impl 3)
+        self.split3 = bool(split3)
+        if self.split3 and (dtype != torch.float32 or dcn_groups):
+            raise ValueError("split3 (3 x fp16 MFMA on fp32 data) applies to plain fp32 convolutions")
 
     def out_hw(self, H, W):
         OH = (H + 2 * self.padding[0] - self.dilation[0] * (self.kh - 1) - 1) // self.stride[0] + 1
@@ -152,18 +157,18 @@ class ConvLayer:
         if dcn_offmask is not None:
             assert self.dcn and dcn_offmask.dtype == self.dtype and dcn_offmask.is_contiguous()
             a.dcn_offmask, a.dcn_cstride, a.dcn_mask_off = dcn_offmask.data_ptr(), dcn_offmask.shape[-1], 288
-        a.impl = self.impl
+        a.impl = 3 if self.split3 else self.impl
         a.ktable_uniform = self.ktable_uniform
         a.tap_h, a.tap_w = self.tap_hw
         self._keep = (srcs, out, residual, dcn_offmask)
-        hip.conv2d_raw(a, cin_read=sum(self.src_cpad) * self.groups)
+        hip.conv2d_raw(a, cin_read=sum(self.src_cpad) * self.groups, on=x0)
         return out
 
 
 _gemm_tables = {}
 
 
-def batched_gemm_nt(a, bt, out_scale=1.0):
+def batched_gemm_nt(a, bt, out_scale=1.0, split3=False):
     """out[b, m, n] = out_scale * sum_k a[b, m, k] * bt[b, n, k]   (fp32 output; a, bt same dtype, K % 32 == 0).
     Used for the RAFT all-pairs correlation volume (RAFT/corr.py:52-60)."""
     B, M, K = a.shape
@@ -184,7 +189,8 @@ def batched_gemm_nt(a, bt, out_scale=1.0):
     g.act, g.out_scale, g.act2 = hip.ACT_NONE, float(out_scale), hip.ACT_NONE
     g.out_dtype = hip.PP_F32
     g.ktable_uniform = 12
+    g.impl = 3 if split3 else 0
     g.out, g.out_cstride, g.out_choff, g.out_cgroup = out.data_ptr(), Nn, 0, 0
     g.src_gstride, g.out_gstride = M * K, M * Nn
-    hip.conv2d_raw(g, cin_read=K * B)
+    hip.conv2d_raw(g, cin_read=K * B, on=a)
     return out

@@ -59,8 +59,29 @@ template <typename T> __device__ __forceinline__ Chunk<T> chunk_from_f32(const f
   return c;
 }
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool DEFORM>
+// hi/lo fp16 split of 8 fp32 values into an LDS row (hi halves at byte chunk*16, lo halves at 64 + chunk*16)
+__device__ __forceinline__ void store_split(char* row, int chunk, const Chunk<float>& c) {
+  const float* f = reinterpret_cast<const float*>(&c);
+  f16x8 h, l;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    h[i] = (_Float16)f[i];
+    l[i] = (_Float16)(f[i] - (float)h[i]);
+  }
+  *reinterpret_cast<f16x8*>(row + chunk * 16) = h;
+  *reinterpret_cast<f16x8*>(row + 64 + chunk * 16) = l;
+}
+__device__ __forceinline__ void store_split(char*, int, const Chunk<_Float16>&) {}
+
+// SPLIT (T = float only): the tensors stay fp32 in memory, every value is split on its way into LDS into
+// hi = fp16(x) and lo = fp16(x - hi) (together 22 significand bits), and each product runs on the fp16 matrix cores as
+// hi*hi + hi*lo + lo*hi with fp32 accumulation (the dropped lo*lo term is < 2^-22 relative): ~2^-21 per product instead
+// of fp32's 2^-24, at 3 fp16 MFMAs (48 cycles per 32-deep k step and 16x16 tile) instead of 8 fp32 MFMAs (256 cycles).
+// An LDS row holds the 32 hi halves (64 B), then the 32 lo halves (64 B), then 16 B of padding: the fp32 row size.
+// Values beyond the fp16 range (|x| > 65504) are not representable by the split; the RAFT activations it serves are O(10).
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool DEFORM, bool SPLIT = false>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
+  static_assert(!SPLIT || (sizeof(T) == 4 && !DEFORM), "split mode: plain fp32 convolutions");
   constexpr int LDK = Mma<T>::LDK;
   constexpr int A_ROWS = BM / 64;                 // A rows gathered per thread (4 chunks per row)
   constexpr int B_ROWS = (BN + 63) / 64;          // weight rows per thread
@@ -199,7 +220,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
 #pragma unroll
     for (int i = 0; i < A_ROWS; ++i) {
       T* dst = lds + buf * STAGE + (arow0 + 64 * i) * LDK + chunk * 8;
-      if constexpr (!DEFORM) {
+      if constexpr (SPLIT) {
+        store_split(reinterpret_cast<char*>(lds + buf * STAGE + (arow0 + 64 * i) * LDK), chunk, a_reg[i][0]);
+      } else if constexpr (!DEFORM) {
         store_chunk<T>(dst, a_reg[i][0]);
       } else {
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, f[8];
@@ -215,7 +238,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
 #pragma unroll
     for (int i = 0; i < B_ROWS; ++i) {
       const int row = arow0 + 64 * i;
-      if (row < BN) store_chunk<T>(lds + buf * STAGE + (BM + row) * LDK + chunk * 8, b_reg[i]);
+      if (row < BN) {
+        if constexpr (SPLIT) store_split(reinterpret_cast<char*>(lds + buf * STAGE + (BM + row) * LDK), chunk, b_reg[i]);
+        else store_chunk<T>(lds + buf * STAGE + (BM + row) * LDK + chunk * 8, b_reg[i]);
+      }
     }
   };
 
@@ -245,6 +271,28 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
 #pragma unroll
         for (int b = 0; b < TM; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[a], af[b], acc[a][b], 0, 0, 0);
+    } else if constexpr (SPLIT) {
+      const char* Ac = reinterpret_cast<const char*>(Ab) + (lane >> 4) * 16;
+      const char* Bc = reinterpret_cast<const char*>(Bb) + (lane >> 4) * 16;
+      f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+        ah[t] = *reinterpret_cast<const f16x8*>(Ac + t * 16 * LDK * 4);
+        al[t] = *reinterpret_cast<const f16x8*>(Ac + t * 16 * LDK * 4 + 64);
+      }
+#pragma unroll
+      for (int t = 0; t < TN; ++t) {
+        bh[t] = *reinterpret_cast<const f16x8*>(Bc + t * 16 * LDK * 4);
+        bl[t] = *reinterpret_cast<const f16x8*>(Bc + t * 16 * LDK * 4 + 64);
+      }
+#pragma unroll
+      for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) {      // small terms first
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[a], ah[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[a], al[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[a], ah[b], acc[a][b], 0, 0, 0);
+        }
     } else {
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) {
@@ -319,8 +367,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
 }
 
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
-static int launch_conv(const ConvParams& p, int groups, bool deform, hipStream_t stream) {
+static int launch_conv(const ConvParams& p, int groups, bool deform, hipStream_t stream, bool split = false) {
   dim3 grid((unsigned)((p.M + BM - 1) / BM), (unsigned)((p.cout_g + BN - 1) / BN), (unsigned)groups);
+  if constexpr (sizeof(T) == 4) {
+    if (split) {
+      hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, WAVES_M, WAVES_N, false, true>), grid, dim3(256), 0, stream, p);
+      return launch_status("pp_conv2d(split)");
+    }
+  }
   if (deform)
     hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, WAVES_M, WAVES_N, true>), grid, dim3(256), 0, stream, p);
   else
@@ -328,11 +382,11 @@ static int launch_conv(const ConvParams& p, int groups, bool deform, hipStream_t
   return launch_status("pp_conv2d");
 }
 
-template <typename T> static int dispatch_conv(const ConvParams& p, int groups, bool deform, hipStream_t stream) {
-  if (p.cout_g > 64) return launch_conv<T, 128, 128, 2, 2>(p, groups, deform, stream);
-  if (p.cout_g > 32) return launch_conv<T, 128, 64, 2, 2>(p, groups, deform, stream);
-  if (p.cout_g > 16) return launch_conv<T, 128, 32, 2, 2>(p, groups, deform, stream);
-  return launch_conv<T, 128, 16, 4, 1>(p, groups, deform, stream);
+template <typename T> static int dispatch_conv(const ConvParams& p, int groups, bool deform, hipStream_t stream, bool split = false) {
+  if (p.cout_g > 64) return launch_conv<T, 128, 128, 2, 2>(p, groups, deform, stream, split);
+  if (p.cout_g > 32) return launch_conv<T, 128, 64, 2, 2>(p, groups, deform, stream, split);
+  if (p.cout_g > 16) return launch_conv<T, 128, 32, 2, 2>(p, groups, deform, stream, split);
+  return launch_conv<T, 128, 16, 4, 1>(p, groups, deform, stream, split);
 }
 
 }  // namespace pp
@@ -454,5 +508,6 @@ extern "C" int pp_conv2d(const pp_conv_args_t* a, void* stream) {
     PP_REQUIRE(a->impl < 10, PP_ERR_ARG, "pp_conv2d: impl %d not available for this shape", a->impl);
   }
   if (a->dtype == PP_F16) return dispatch_conv<_Float16>(p, a->groups, deform, st);
-  return dispatch_conv<float>(p, a->groups, deform, st);
+  PP_REQUIRE(a->impl != 3 || !deform, PP_ERR_ARG, "pp_conv2d: impl 3 (split-fp16 products) does not apply to the deformable mode");
+  return dispatch_conv<float>(p, a->groups, deform, st, a->impl == 3);
 }

@@ -2,7 +2,7 @@
 
 There is no CPU fallback: every op below requires the HIP library, and raises if it cannot be
 loaded or if a tensor is not on a GPU.  Tensors are passed as raw ``data_ptr()`` + explicit sizes and
-all work is enqueued on ``torch.cuda.current_stream()``.
+all work is enqueued on torch's current stream of the device that owns the tensors.
 """
 import ctypes as C
 import os
@@ -57,9 +57,7 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.LIB_PATH
-    if not os.path.exists(path):
-        path = _build.build(verbose=False)
+    path = _build.build(force=False, verbose=False)      # no-op unless the sources no longer match the built library
     L = C.CDLL(path)
     L.pp_last_error_string.restype = C.c_char_p
     for name in ("pp_conv2d", "pp_sparse_window_attention"):
@@ -140,8 +138,47 @@ def dtype_code(dt):
     raise TypeError(f"unsupported dtype {dt} (libpropainter_hip supports float32 and float16)")
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(t):
+    """The stream the launch goes to: torch's current stream of the device that owns the tensors.  A launch must be
+    issued with that device current (HIP binds a launch to the current device): the module entry points wrap their work
+    in ``torch.cuda.device(x.device)``; anything else fails loudly here instead of launching on another GPU's stream."""
+    dev = t.device
+    if dev.type != "cuda":
+        raise RuntimeError("libpropainter_hip kernels need GPU tensors: there is no CPU fallback in the product path")
+    if dev.index != torch.cuda.current_device():
+        raise RuntimeError(f"tensor on {dev} but the current device is cuda:{torch.cuda.current_device()}: wrap the call in "
+                           "torch.cuda.device(tensor.device) (the drop-in modules do)")
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def on_device_of(t):
+    """Context manager: makes the device of `t` current for the launches inside (no-op when it already is)."""
+    return torch.cuda.device(t.device)
+
+
+def on_input_device(fn):
+    """Decorator for module entry points: runs the method with the device of its first tensor argument current, so that
+    ``RAFT_bi(path, 'cuda:1')(frames_on_cuda1)`` launches on GPU 1 whatever the caller's current device is."""
+    import functools
+
+    def first_tensor(objs):
+        for o in objs:
+            if torch.is_tensor(o):
+                return o
+            if isinstance(o, (tuple, list)):
+                t = first_tensor(o)
+                if t is not None:
+                    return t
+        return None
+
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kwargs):
+        t = first_tensor(args) if args else first_tensor(list(kwargs.values()))
+        if t is None or not t.is_cuda:
+            return fn(self, *args, **kwargs)
+        with torch.cuda.device(t.device):
+            return fn(self, *args, **kwargs)
+    return wrapper
 
 
 def _p(t):
@@ -203,10 +240,11 @@ def window_tables(Hp, Wp, wh=5, ww=9):
 # ----------------------------------------------------------------------------------------------
 # device ops
 # ----------------------------------------------------------------------------------------------
-def conv2d_raw(args: ConvArgs, cin_read=None):
-    """cin_read: channels read per input pixel (for the profiler's byte model; defaults to K per group x groups)."""
+def conv2d_raw(args: ConvArgs, cin_read=None, on=None):
+    """cin_read: channels read per input pixel (for the profiler's byte model; defaults to K per group x groups);
+    on: a tensor of the launch (names the device / stream)."""
     if _profiler is None:
-        _check(lib().pp_conv2d(C.byref(args), _stream()), "pp_conv2d")
+        _check(lib().pp_conv2d(C.byref(args), _stream(on)), "pp_conv2d")
         return
     # algorithmic work of this launch: 2*M*Cout*K FLOPs; bytes = sources read once + weights + output written once
     M = args.N * args.OH * args.OW
@@ -221,7 +259,7 @@ def conv2d_raw(args: ConvArgs, cin_read=None):
     name = "conv_gemm_dcn" if args.dcn_offmask else ("conv_gemm_f16" if args.dtype == PP_F16 else "conv_gemm_f32")
     if _profiler is not None and getattr(_profiler, "detail", False):      # per-layer-shape classes (bench.py --detail)
         name += f" | taps{args.tap_h}x{args.tap_w} s{args.stride_h} K{K} cout{args.cout_g}x{args.groups} M{M} {args.H}x{args.W}"
-    timed(name, flops, nbytes, lambda: _check(lib().pp_conv2d(C.byref(args), _stream()), "pp_conv2d"))
+    timed(name, flops, nbytes, lambda: _check(lib().pp_conv2d(C.byref(args), _stream(on)), "pp_conv2d"))
 
 
 def flow_warp(x, flow, out=None, mode="bilinear", x_choff=0, C_=None, fl_choff=0, out_choff=0):
@@ -233,7 +271,7 @@ def flow_warp(x, flow, out=None, mode="bilinear", x_choff=0, C_=None, fl_choff=0
     assert x.is_contiguous() and flow.is_contiguous() and out.is_contiguous() and flow.dtype == x.dtype
     timed("flow_warp", 0, _nbytes(out) * 2 + _nbytes(flow), lambda: _check(lib().pp_flow_warp(_p(x), _i(Cx), _i(x_choff), _p(flow), _i(flow.shape[-1]), _i(fl_choff), _p(out),
                               _i(out.shape[-1]), _i(out_choff), _i(N), _i(H), _i(W), _i(C_),
-                              _i(1 if mode == "nearest" else 0), _i(dtype_code(x.dtype)), _stream()),
+                              _i(1 if mode == "nearest" else 0), _i(dtype_code(x.dtype)), _stream(x)),
            "pp_flow_warp"))
     return out
 
@@ -246,7 +284,7 @@ def fb_check(flow_fw, flow_bw, out=None, out_choff=0):
     assert flow_fw.is_contiguous() and flow_bw.is_contiguous() and out.is_contiguous()
     timed("fb_check", 0, _nbytes(flow_fw) * 3, lambda: _check(lib().pp_fb_check(_p(flow_fw), _i(flow_fw.shape[-1]), _p(flow_bw), _i(flow_bw.shape[-1]), _p(out),
                              _i(out.shape[-1]), _i(out_choff), _i(N), _i(H), _i(W), _i(dtype_code(flow_fw.dtype)),
-                             _stream()),
+                             _stream(flow_fw)),
            "pp_fb_check"))
     return out
 
@@ -258,7 +296,7 @@ def img_prop_step(x_prop, m_prop, x_cur, m_cur, flow_prop, flow_check, x_out, m_
         assert t.is_contiguous() and t.dtype == x_cur.dtype
     timed("img_prop_step", 0, _nbytes(x_prop) + _nbytes(m_prop) + _nbytes(x_cur) + _nbytes(m_cur) + _nbytes(flow_prop) + _nbytes(flow_check) + _nbytes(x_out) + _nbytes(m_out), lambda: _check(lib().pp_img_prop_step(_p(x_prop), _p(m_prop), _p(x_cur), _p(m_cur), _p(flow_prop), _p(flow_check),
                                   _p(x_out), _p(m_out), _i(N), _i(Cc), _i(H), _i(W),
-                                  _i(1 if mode == "nearest" else 0), _i(dtype_code(x_cur.dtype)), _stream()),
+                                  _i(1 if mode == "nearest" else 0), _i(dtype_code(x_cur.dtype)), _stream(x_cur)),
            "pp_img_prop_step"))
 
 
@@ -268,13 +306,13 @@ def binary_dilate(mask_u8, iterations):
     assert mask_u8.dtype == torch.uint8 and mask_u8.is_contiguous()
     out = torch.empty_like(mask_u8)
     timed("binary_dilate", 0, 2 * mask_u8.numel(), lambda: _check(lib().pp_binary_dilate(_p(mask_u8), _p(out), _i(N), _i(H), _i(W),
-                                                                                       _i(iterations), _stream()), "pp_binary_dilate"))
+                                                                                       _i(iterations), _stream(mask_u8)), "pp_binary_dilate"))
     return out
 
 
 def corr_avgpool(x, M, H, W):
     out = torch.empty((M, H // 2, W // 2), dtype=torch.float32, device=x.device)
-    timed("corr_avgpool", 0, _nbytes(out) * 5, lambda: _check(lib().pp_corr_avgpool(_p(x), _p(out), C.c_int64(M), _i(H), _i(W), _stream()),
+    timed("corr_avgpool", 0, _nbytes(out) * 5, lambda: _check(lib().pp_corr_avgpool(_p(x), _p(out), C.c_int64(M), _i(H), _i(W), _stream(x)),
            "pp_corr_avgpool"))
     return out
 
@@ -285,7 +323,7 @@ def corr_lookup(levels, coords, out):
     assert coords.dtype == torch.float32 and coords.is_contiguous() and out.is_contiguous()
     timed("corr_lookup", 0, B * h * w * 4 * 100 * 4 + _nbytes(out), lambda: _check(lib().pp_corr_lookup(_p(levels[0]), _p(levels[1]), _p(levels[2]), _p(levels[3]), _p(coords), _p(out),
                                 _i(out.shape[-1]), _i(out.shape[-1]), _i(B), _i(h), _i(w), _i(dtype_code(out.dtype)),
-                                _stream()),
+                                _stream(coords)),
            "pp_corr_lookup"))
     return out
 
@@ -296,7 +334,7 @@ def convex_upsample(flow, mask):
     out = torch.empty((B, 2, 8 * h, 8 * w), dtype=torch.float32, device=flow.device)
     assert flow.dtype == torch.float32 and flow.is_contiguous() and mask.is_contiguous()
     timed("convex_upsample", 0, _nbytes(flow) + _nbytes(mask) + _nbytes(out), lambda: _check(lib().pp_convex_upsample(_p(flow), _p(mask), _i(mask.shape[-1]), _i(dtype_code(mask.dtype)), _p(out),
-                                    _i(B), _i(h), _i(w), _stream()),
+                                    _i(B), _i(h), _i(w), _stream(flow)),
            "pp_convex_upsample"))
     return out
 
@@ -307,7 +345,7 @@ def window_mask(mask, wh=5, ww=9):
     out = torch.empty((B, (Hp // wh) * (Wp // ww)), dtype=torch.float32, device=mask.device)
     assert mask.is_contiguous()
     timed("window_mask", 0, _nbytes(mask) + _nbytes(out), lambda: _check(lib().pp_window_mask(_p(mask), _p(out), _i(B), _i(Lt), _i(Hp), _i(Wp), _i(wh), _i(ww),
-                                _i(dtype_code(mask.dtype)), _stream()),
+                                _i(dtype_code(mask.dtype)), _stream(mask)),
            "pp_window_mask"))
     return out
 
@@ -340,7 +378,7 @@ def sparse_window_attention(q, k, v, pk, pv, own, rolled, tind, wmask, heads=4, 
             raise RuntimeError("sparse_window_attention needs GPU tensors")
     assert own.dtype == torch.int32 and rolled.dtype == torch.int32 and tind.dtype == torch.int32
     if _profiler is None:
-        _check(lib().pp_sparse_window_attention(C.byref(a), _stream()), "pp_sparse_window_attention")
+        _check(lib().pp_sparse_window_attention(C.byref(a), _stream(q)), "pp_sparse_window_attention")
         return out
     # algorithmic work (profiling only; reads the window flags back): QK^T + PV = 4 FLOP per (query, key, channel)
     nmask = int((wmask > 0).sum().item())
@@ -351,7 +389,7 @@ def sparse_window_attention(q, k, v, pk, pv, own, rolled, tind, wmask, heads=4, 
     esz = q.element_size()
     nbytes = (3 * B * T * Hp * Wp * C_ + 2 * B * T * a.P * C_ + B * T * Hp * Wp * C_) * esz
     timed("sparse_window_attention", flops, nbytes,
-          lambda: _check(lib().pp_sparse_window_attention(C.byref(a), _stream()), "pp_sparse_window_attention"))
+          lambda: _check(lib().pp_sparse_window_attention(C.byref(a), _stream(q)), "pp_sparse_window_attention"))
     return out
 
 
@@ -360,7 +398,7 @@ def fold_tokens(tokens, BT, fh, fw, Cc, H, W, normalize=False, act=ACT_NONE):
     out = torch.empty((BT, H, W, Cc), dtype=tokens.dtype, device=tokens.device)
     assert tokens.is_contiguous()
     timed("fold_tokens", 0, _nbytes(tokens) + _nbytes(out), lambda: _check(lib().pp_fold_tokens(_p(tokens), _p(out), _i(BT), _i(fh), _i(fw), _i(Cc), _i(H), _i(W),
-                                _i(1 if normalize else 0), _i(act), _i(dtype_code(tokens.dtype)), _stream()),
+                                _i(1 if normalize else 0), _i(act), _i(dtype_code(tokens.dtype)), _stream(tokens)),
            "pp_fold_tokens"))
     return out
 
@@ -371,7 +409,7 @@ def layernorm(x, gamma, beta, eps=1e-5):
     out = torch.empty_like(x)
     assert x.is_contiguous() and gamma.dtype == torch.float32 and beta.dtype == torch.float32
     timed("layernorm", 0, _nbytes(x) + _nbytes(out), lambda: _check(lib().pp_layernorm(_p(x), _p(gamma), _p(beta), _p(out), C.c_int64(x.numel() // Cc), _i(Cc),
-                              C.c_float(eps), _i(dtype_code(x.dtype)), _stream()),
+                              C.c_float(eps), _i(dtype_code(x.dtype)), _stream(x)),
            "pp_layernorm"))
     return out
 
@@ -382,7 +420,7 @@ def depthwise_pool(x, weight, bias, k=4):
     out = torch.empty((N, H // k, W // k, Cc), dtype=x.dtype, device=x.device)
     assert x.is_contiguous() and weight.dtype == torch.float32
     timed("depthwise_pool", 0, _nbytes(x) + _nbytes(out), lambda: _check(lib().pp_depthwise_pool(_p(x), _p(weight), _p(bias), _p(out), _i(N), _i(H), _i(W), _i(Cc), _i(k),
-                                   _i(dtype_code(x.dtype)), _stream()),
+                                   _i(dtype_code(x.dtype)), _stream(x)),
            "pp_depthwise_pool"))
     return out
 
@@ -395,7 +433,7 @@ def instance_norm(x, relu=False, eps=1e-5, out=None):
     ws = torch.empty((int(L.pp_instance_norm_workspace_floats(N, H, W, Cc)),), dtype=torch.float32, device=x.device)
     assert x.is_contiguous()
     timed("instance_norm", 0, _nbytes(x) * 2 + _nbytes(out), lambda: _check(lib().pp_instance_norm(_p(x), _p(out), _p(ws), _i(N), _i(H), _i(W), _i(Cc), C.c_float(eps),
-                                  _i(1 if relu else 0), _i(dtype_code(x.dtype)), _stream()),
+                                  _i(1 if relu else 0), _i(dtype_code(x.dtype)), _stream(x)),
            "pp_instance_norm"))
     return out
 
@@ -404,7 +442,7 @@ def upsample2x(x):
     N, H, W, Cc = x.shape
     out = torch.empty((N, 2 * H, 2 * W, Cc), dtype=x.dtype, device=x.device)
     assert x.is_contiguous()
-    timed("upsample2x", 0, _nbytes(x) + _nbytes(out), lambda: _check(lib().pp_upsample2x(_p(x), _p(out), _i(N), _i(H), _i(W), _i(Cc), _i(dtype_code(x.dtype)), _stream()),
+    timed("upsample2x", 0, _nbytes(x) + _nbytes(out), lambda: _check(lib().pp_upsample2x(_p(x), _p(out), _i(N), _i(H), _i(W), _i(Cc), _i(dtype_code(x.dtype)), _stream(x)),
            "pp_upsample2x"))
     return out
 
@@ -415,7 +453,7 @@ def dcn_offset_mask_act(offmask, mag, flow=None, fl_choff=0):
     assert offmask.is_contiguous() and (flow is None or (flow.is_contiguous() and flow.dtype == offmask.dtype))
     timed("dcn_offset_mask_act", 0, _nbytes(offmask) * 2, lambda: _check(lib().pp_dcn_offset_mask_act(_p(offmask), _i(offmask.shape[-1]), _p(flow),
                                         _i(flow.shape[-1] if flow is not None else 0), _i(fl_choff), C.c_float(mag),
-                                        C.c_int64(npix), _i(dtype_code(offmask.dtype)), _stream()),
+                                        C.c_int64(npix), _i(dtype_code(offmask.dtype)), _stream(offmask)),
            "pp_dcn_offset_mask_act"))
     return offmask
 
@@ -425,7 +463,7 @@ def gru_gate(zr, h, h_choff, Cc, out, out_choff, q=None):
     npix = zr.numel() // zr.shape[-1]
     timed("gru_gate", 0, npix * Cc * 4 * zr.element_size(), lambda: _check(lib().pp_gru_gate(_p(zr), _i(zr.shape[-1]), _p(h), _i(h.shape[-1]), _i(h_choff), _p(q),
                              _i(q.shape[-1] if q is not None else 0), _p(out), _i(out.shape[-1]), _i(out_choff),
-                             C.c_int64(npix), _i(Cc), _i(0 if q is None else 1), _i(dtype_code(zr.dtype)), _stream()),
+                             C.c_int64(npix), _i(Cc), _i(0 if q is None else 1), _i(dtype_code(zr.dtype)), _stream(zr)),
            "pp_gru_gate"))
     return out
 
@@ -440,7 +478,7 @@ def nchw_to_nhwc(x, out=None, out_choff=0, out_dtype=None, cpad=None, scale=1.0)
     assert x.is_contiguous() and out.is_contiguous()
     timed("nchw_to_nhwc", 0, _nbytes(x) * 2, lambda: _check(lib().pp_nchw_to_nhwc(_p(x), _i(dtype_code(x.dtype)), _p(out), _i(dtype_code(out.dtype)),
                                  _i(out.shape[-1]), _i(out_choff), _i(N), _i(Cc), _i(H), _i(W), C.c_float(scale),
-                                 _stream()),
+                                 _stream(x)),
            "pp_nchw_to_nhwc"))
     return out
 
@@ -451,6 +489,6 @@ def nhwc_to_nchw(x, Cc=None, choff=0, out_dtype=None, act=ACT_NONE):
     out = torch.empty((N, Cc, H, W), dtype=out_dtype or x.dtype, device=x.device)
     assert x.is_contiguous()
     timed("nhwc_to_nchw", 0, _nbytes(out) * 2, lambda: _check(lib().pp_nhwc_to_nchw(_p(x), _i(dtype_code(x.dtype)), _i(Cs), _i(choff), _p(out),
-                                 _i(dtype_code(out.dtype)), _i(N), _i(Cc), _i(H), _i(W), _i(act), _stream()),
+                                 _i(dtype_code(out.dtype)), _i(N), _i(Cc), _i(H), _i(W), _i(act), _stream(x)),
            "pp_nhwc_to_nchw"))
     return out

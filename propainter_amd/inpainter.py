@@ -14,24 +14,25 @@ from .pipeline import InferenceConfig, run_clip
 
 class ProInpainter:
     def __init__(self, propainter_checkpoint, raft_checkpoint, flow_completion_checkpoint, device="cuda:0", use_half=True,
-                 raft_fp32=False):
+                 raft_precision=None):
         """Checkpoint paths as in the reference; passing ``None`` for all three builds the deterministic seeded weights
-        (no checkpoints ship with either repository).  ``raft_fp32`` keeps the RAFT convolutions in fp32 like the
-        reference (default with ``use_half``: fp16 MFMA, fp32 correlation / coordinates)."""
+        (no checkpoints ship with either repository).  ``raft_precision`` in {"f32", "f16x3", "f16"} (see ``RAFT_bi``);
+        default: "f16x3" with ``use_half`` (the reference keeps RAFT fp32 in half mode, base_inpainter.py:240-262),
+        "f32" otherwise."""
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("ProInpainter runs on the HIP engine only (no CPU path in the product)")
         self.use_half = bool(use_half)
         hip.lib()
-        raft_dt = torch.float16 if (self.use_half and not raft_fp32) else None
+        prec = raft_precision or ("f16x3" if self.use_half else "f32")
         if propainter_checkpoint is None and raft_checkpoint is None and flow_completion_checkpoint is None:
             from .synthetic import seeded_models
-            self.fix_raft, self.fix_flow_complete, self.model = seeded_models(self.device, raft_dtype=raft_dt)
+            self.fix_raft, self.fix_flow_complete, self.model = seeded_models(self.device, raft_precision=prec)
         else:
             from .model.modules.flow_comp_raft import RAFT_bi
             from .model.propainter import InpaintGenerator
             from .model.recurrent_flow_completion import RecurrentFlowCompleteNet
-            self.fix_raft = RAFT_bi(raft_checkpoint, self.device, compute_dtype=raft_dt)
+            self.fix_raft = RAFT_bi(raft_checkpoint, self.device, precision=prec)
             self.fix_flow_complete = RecurrentFlowCompleteNet(flow_completion_checkpoint)
             for p in self.fix_flow_complete.parameters():
                 p.requires_grad = False

@@ -61,9 +61,9 @@ def raft_schema(prefix=""):
 class _RaftEngine:
     """Packed layers for one (dtype, device)."""
 
-    def __init__(self, sd, dtype, device):
-        self.dtype, self.device = dtype, device
-        mk = lambda w, b, **kw: ConvLayer(w, b, dtype=dtype, device=device, **kw)
+    def __init__(self, sd, dtype, device, split3=False):
+        self.dtype, self.device, self.split3 = dtype, device, split3
+        mk = lambda w, b, **kw: ConvLayer(w, b, dtype=dtype, device=device, split3=split3, **kw)
 
         def enc(prefix, bn):
             def cv(name, norm=None, **kw):
@@ -135,7 +135,7 @@ class _RaftEngine:
         dev, dt = f1.device, self.dtype
         n8 = h * w
         # all-pairs correlation volume + pyramid (RAFT/corr.py:13-27,52-60), fp32
-        vol = batched_gemm_nt(f1.view(P, n8, 256), f2.view(P, n8, 256), out_scale=1.0 / 16.0)
+        vol = batched_gemm_nt(f1.view(P, n8, 256), f2.view(P, n8, 256), out_scale=1.0 / 16.0, split3=self.split3)
         levels = [vol.view(P * n8, h, w)]
         hh, ww = h, w
         for _ in range(3):
@@ -175,7 +175,20 @@ class _RaftEngine:
 class RAFT_bi(nn.Module):
     """Bidirectional RAFT flow of consecutive frame pairs (reference: model/modules/flow_comp_raft.py:27-55)."""
 
-    def __init__(self, model_path='weights/raft-things.pth', device='cuda', compute_dtype=None, max_pairs=None):
+    PRECISIONS = ("f32", "f16x3", "f16")
+
+    def __init__(self, model_path='weights/raft-things.pth', device='cuda', compute_dtype=None, max_pairs=None,
+                 precision=None):
+        """``precision`` (engine extension; the reference runs RAFT in fp32 even under ``--fp16``,
+        inference_propainter.py:311):
+          "f32"   exact fp32 products on ``v_mfma_f32_16x16x4_f32`` (157 TFLOP/s peak) -- the default for fp32 input;
+          "f16x3" fp32 tensors everywhere, every product on the fp16 matrix cores as hi*hi + hi*lo + lo*hi with fp32
+                  accumulation: relative error ~2^-21 per product (fp32: 2^-24) -- reference-class flows at 5x the
+                  exact-fp32 matrix rate;
+          "f16"   fp16 activations / weights, fp32 accumulation, fp32 correlation values, coordinates and flow (the
+                  10-bit mantissa of the TF32 convolutions a CUDA build of the reference runs by default) -- the default
+                  for fp16 input.
+        ``compute_dtype=torch.float16`` is the older spelling of precision="f16"."""
         super().__init__()
         self.fix_raft = ParamTree()
         populate(self.fix_raft, raft_schema())
@@ -185,31 +198,39 @@ class RAFT_bi(nn.Module):
             self.fix_raft.load_state_dict(ckpt, strict=True)
         for p in self.parameters():
             p.requires_grad = False
-        self.compute_dtype = compute_dtype     # None: follow the input dtype (the reference keeps RAFT in fp32)
+        if precision is not None and precision not in self.PRECISIONS:
+            raise ValueError(f"RAFT precision {precision!r} not in {self.PRECISIONS}")
+        self.precision = precision             # None: follow compute_dtype / the input dtype
+        self.compute_dtype = compute_dtype
         # Every pair is computed independently of its batch neighbours (InstanceNorm per sample, BatchNorm folded), so a
         # clip driver may hand over all frames at once instead of the reference's 12/8/4/2-frame clips
         # (inference_propainter.py:302-330): identical flows, each frame encoded once, larger GEMMs.
         self.batch_invariant = True
         self.max_pairs = max_pairs
-        self._engine = None
+        self._engines = {}
         self.to(device)
         self.eval()
 
-    def _get_engine(self, dtype, device):
-        key = (dtype, str(device), sum(p._version for p in self.parameters()))
-        if self._engine is None or self._engine[0] != key:
+    def _get_engine(self, precision, device):
+        key = (precision, str(device), sum(p._version for p in self.parameters()))
+        eng = self._engines.get(precision)
+        if eng is None or eng[0] != key:
             sd = {k: v.detach().float().cpu() for k, v in self.fix_raft.state_dict().items()}
-            self._engine = (key, _RaftEngine(sd, dtype, device))
-        return self._engine[1]
+            dt = torch.float16 if precision == "f16" else torch.float32
+            eng = (key, _RaftEngine(sd, dt, device, split3=(precision == "f16x3")))
+            self._engines[precision] = eng
+        return eng[1]
 
+    @hip.on_input_device
     @torch.no_grad()
     def forward(self, gt_local_frames, iters=20):
         b, l_t, c, h, w = gt_local_frames.size()
         hip.require_gpu(gt_local_frames, "RAFT_bi")
         if h % 8 or w % 8 or h < 128 or w < 128:
             raise ValueError(f"RAFT needs H, W multiples of 8 and >= 128 (got {h}x{w}; RAFT/utils/utils.py:61-62)")
-        dt = self.compute_dtype or gt_local_frames.dtype
-        eng = self._get_engine(dt, gt_local_frames.device)
+        prec = self.precision or ("f16" if (self.compute_dtype or gt_local_frames.dtype) == torch.float16 else "f32")
+        eng = self._get_engine(prec, gt_local_frames.device)
+        dt = eng.dtype
         fr = gt_local_frames.reshape(b * l_t, c, h, w)
         # encoders once per frame, in frame chunks that keep every activation below 2 GiB (32-bit buffer offsets of the
         # LDS-DMA gather; InstanceNorm statistics are per frame, so chunking does not change results)

@@ -366,6 +366,7 @@ class InpaintGenerator(nn.Module):
             self._engine = (key, _GenEngine(sd, dtype, device))
         return self._engine[1]
 
+    @hip.on_input_device
     @torch.no_grad()
     def img_propagation(self, masked_frames, completed_flows, masks, interpolation='nearest'):
         hip.require_gpu(masked_frames, "InpaintGenerator")
@@ -374,6 +375,7 @@ class InpaintGenerator(nn.Module):
         return eng.img_propagation(masked_frames, completed_flows[0].to(dt), completed_flows[1].to(dt), masks.to(dt),
                                    interpolation)
 
+    @hip.on_input_device
     @torch.no_grad()
     def encode_frames(self, masked_frames, masks_in, masks_updated):
         """Engine extension (not in the reference API): per-frame encoder features, NHWC [t,H/4,W/4,128], to be passed
@@ -383,6 +385,7 @@ class InpaintGenerator(nn.Module):
         eng = self._get_engine(dt, masked_frames.device)
         return eng.encode_frames(masked_frames, masks_in.to(dt), masks_updated.to(dt))
 
+    @hip.on_input_device
     @torch.no_grad()
     def forward(self, masked_frames, completed_flows, masks_in, masks_updated, num_local_frames,
                 interpolation='bilinear', t_dilation=2, enc_feat=None):

@@ -179,6 +179,7 @@ class RecurrentFlowCompleteNet(nn.Module):
             self._engine = (key, _FCEngine(sd, dtype, device))
         return self._engine[1]
 
+    @hip.on_input_device
     @torch.no_grad()
     def forward(self, masked_flows, masks):
         hip.require_gpu(masked_flows, "RecurrentFlowCompleteNet")

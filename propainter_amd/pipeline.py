@@ -134,8 +134,12 @@ class Compositor:
         self.done = [False] * frames_u8.shape[0]
 
     def add(self, neighbor_ids, pred_img):
-        """pred_img [l_t,3,H,W] in [-1,1]."""
-        img = ((pred_img.float() + 1) / 2).permute(0, 2, 3, 1) * 255
+        """pred_img [l_t,3,H,W] in [-1,1], fp32 or fp16.  The scaling runs in the prediction's own dtype, one rounding
+        per operation, exactly like the reference (``(pred_img + 1) / 2`` on the device, ``* 255`` on a float16 / float32
+        numpy array, truncation to uint8: inference_propainter.py:437-438,443) -- so the bytes equal the reference's
+        for identical predictions in either precision (tests/test_host_logic_cpu.py::test_compositor_*)."""
+        img = (pred_img + 1) / 2
+        img = img.permute(0, 2, 3, 1) * 255
         img = img.to(torch.uint8)
         for i, idx in enumerate(neighbor_ids):
             m = self.bin[idx]
@@ -156,6 +160,8 @@ def _dev_index(ids, device):
     key = (tuple(ids), str(device))
     t = _index_cache.get(key)
     if t is None:
+        if len(_index_cache) > 4096:          # a long-running server sees many clip lengths: keep the cache bounded
+            _index_cache.clear()
         if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
             raise RuntimeError("window index tensors must be created by an eager pass before graph capture")
         t = torch.tensor(list(ids), dtype=torch.long, device=device)
@@ -169,6 +175,10 @@ def run_clip(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg: InferenceC
     """Whole path for one clip.  frames_u8 [L,H,W,3] uint8, masks [L,H,W] uint8 {0,255} (numpy or tensors).
     models = (RAFT_bi, RecurrentFlowCompleteNet, InpaintGenerator).  Returns uint8 tensor [L,H,W,3] on `device`.
     ``stage_hook(name)`` (optional) is called at every stage boundary (bench.py records HIP events there)."""
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is not None and device.index != torch.cuda.current_device():
+        with torch.cuda.device(device):      # launches bind to the current device: make the clip's device current
+            return run_clip(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg, device, return_stages, stage_hook)
     mark = stage_hook or (lambda name: None)
     fix_raft, fix_flow_complete, model = models
     to_t = lambda a: a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))

@@ -273,7 +273,7 @@ def sharded_clip_steps(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg: 
         fl = pred.sl(nb[0], nb[-1])
         out = model(u[:, :, :3].contiguous(), (fl[0], fl[1]), masks_dilated.take(ids, device), u[:, :, 3:4].contiguous(),
                     len(nb), **kw)
-        img = (((out[0].float() + 1) / 2).permute(0, 2, 3, 1) * 255).to(torch.uint8)          # (:435-442)
+        img = (((out[0] + 1) / 2).permute(0, 2, 3, 1) * 255).to(torch.uint8)   # (:435-442) in the prediction's dtype, as pipeline.Compositor
         for i, idx in enumerate(nb):
             m = masks_dilated.sl(idx, idx + 1)[0, 0].permute(1, 2, 0).to(torch.uint8)
             ori = fr_u8[idx - r0]
@@ -301,11 +301,23 @@ def sharded_clip_steps(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg: 
 # ----------------------------------------------------------------------------------------------------------------
 # drivers
 # ----------------------------------------------------------------------------------------------------------------
-def _dist_exchange(ex, device, group=None):
+def can_shard(L, cfg, world):
+    """True when a clip of L frames splits into sub-videos over `world` > 1 ranks (see ShardPlan); a short clip is a
+    single sub-video and runs as one unsharded pass on one GPU instead."""
+    return world > 1 and cfg.subvideo_length <= 100 and L - 1 > cfg.subvideo_length
+
+
+def _dist_exchange(ex, device, group=None, stats=None):
     """Answers one Exchange with torch.distributed point-to-point ops (RCCL send/recv between the two GPUs' xGMI link;
-    gloo stages through host memory)."""
+    gloo stages through host memory).  ``stats`` (optional dict) accumulates per exchange tag the bytes sent / received
+    by this rank and the wall time of the exchange (device-synchronised on both sides when the backend is RCCL)."""
+    import time
     import torch.distributed as dist
     via_host = dist.get_backend(group) == "gloo"
+    if stats is not None:
+        if not via_host:
+            torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
     bufs, ops, keep = {}, [], []
     for q, (shape, dtype) in sorted(ex.recv.items()):
         bufs[q] = torch.empty(shape, dtype=dtype, device="cpu" if via_host else device)
@@ -317,18 +329,28 @@ def _dist_exchange(ex, device, group=None):
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
-    return {q: b.to(device) for q, b in bufs.items()}
+    out = {q: b.to(device) for q, b in bufs.items()}
+    if stats is not None:
+        if not via_host:
+            torch.cuda.synchronize(device)
+        rec = stats.setdefault(ex.tag, {"sent_bytes": 0, "recv_bytes": 0, "ms": 0.0, "calls": 0})
+        rec["sent_bytes"] += sum(t.numel() * t.element_size() for t in keep)
+        rec["recv_bytes"] += sum(b.numel() * b.element_size() for b in bufs.values())
+        rec["ms"] += (time.perf_counter() - t0) * 1e3
+        rec["calls"] += 1
+    return out
 
 
-def run_clip_sharded(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg, device, group=None):
-    """One process per GPU: this rank's part of the clip.  Returns (lo, comp_u8) -- frames [lo, lo+len) of the result."""
+def run_clip_sharded(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg, device, group=None, stats=None):
+    """One process per GPU: this rank's part of the clip.  Returns (lo, comp_u8) -- frames [lo, lo+len) of the result.
+    ``stats``: see ``_dist_exchange``."""
     import torch.distributed as dist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     gen = sharded_clip_steps(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg, device, rank, world)
     try:
         ex = next(gen)
         while True:
-            ex = gen.send(_dist_exchange(ex, device, group))
+            ex = gen.send(_dist_exchange(ex, device, group, stats))
     except StopIteration as stop:
         return stop.value
 

@@ -102,13 +102,13 @@ def synthetic_mask(height, width):
     return m
 
 
-def seeded_models(device="cpu", raft_dtype=None):
+def seeded_models(device="cpu", raft_dtype=None, raft_precision=None):
     """The three drop-in modules with the repo-wide seeded weights (the values the goldens were generated with);
     used by the parity tests, smoke() and bench.py (no pretrained checkpoints exist offline)."""
     from .model.modules.flow_comp_raft import RAFT_bi
     from .model.propainter import InpaintGenerator
     from .model.recurrent_flow_completion import RecurrentFlowCompleteNet
-    raft = RAFT_bi(model_path=None, device="cpu", compute_dtype=raft_dtype)
+    raft = RAFT_bi(model_path=None, device="cpu", compute_dtype=raft_dtype, precision=raft_precision)
     raft.fix_raft.load_state_dict(seeded_weights("raft", raft.fix_raft.state_dict()), strict=True)
     fc = RecurrentFlowCompleteNet()
     fc.load_state_dict(seeded_weights("fc", fc.state_dict()), strict=True)

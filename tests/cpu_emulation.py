@@ -76,7 +76,7 @@ def _conv_call(self, srcs, out=None, out_choff=0, act=None, act_param=0.0, out_s
     return out
 
 
-def _batched_gemm_nt(a, bt, out_scale=1.0):
+def _batched_gemm_nt(a, bt, out_scale=1.0, split3=False):
     return torch.matmul(a.float(), bt.float().transpose(1, 2)) * out_scale
 
 

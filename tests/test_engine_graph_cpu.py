@@ -17,6 +17,8 @@ def models():
 
 
 def _engine(mod, dtype=torch.float32):
+    if hasattr(mod, "PRECISIONS"):       # RAFT_bi: engines are keyed by precision mode
+        return mod._get_engine("f32" if dtype == torch.float32 else "f16", torch.device("cpu"))
     return mod._get_engine(dtype, torch.device("cpu"))
 
 

@@ -156,3 +156,36 @@ def test_models_refuse_cpu_tensors():
     with pytest.raises(RuntimeError):
         gen(torch.zeros(1, 2, 3, 64, 64), (torch.zeros(1, 1, 2, 64, 64),) * 2, torch.zeros(1, 2, 1, 64, 64),
             torch.zeros(1, 2, 1, 64, 64), 2)
+
+
+def _compositor_case(dtype, device):
+    """Three overlapping windows (frames visited 1x, 2x and 3x) of random predictions that cover the whole [-1, 1] range
+    incl. the exact end points and values whose scaled image lands within one fp16 ulp of an integer."""
+    from propainter_amd.pipeline import Compositor
+    g = torch.Generator().manual_seed(5)
+    L, H, W = 7, 24, 40
+    frames = torch.randint(0, 256, (L, H, W, 3), generator=g, dtype=torch.uint8)
+    md = (torch.rand(1, L, 1, H, W, generator=g) > 0.4).to(dtype)
+    windows = [[0, 1, 2, 3], [2, 3, 4, 5], [3, 4, 5, 6]]
+    preds = []
+    for nb in windows:
+        p = torch.rand(len(nb), 3, H, W, generator=g) * 2 - 1
+        p[0, 0, 0, :8] = torch.tensor([-1.0, 1.0, 0.0, 0.999, -0.999, 0.00392, 0.5, -0.5])
+        q = torch.randint(0, 256, (H, W), generator=g).float()       # pre-images of integers: (2k/255 - 1) +- rounding
+        p[-1, 1] = q * 2 / 255 - 1
+        preds.append(p.to(dtype))
+    comp = Compositor(frames.to(device), md.to(device))
+    ref = [None] * L
+    for nb, p in zip(windows, preds):
+        comp.add(nb, p.to(device))
+        O.composite_window(ref, nb, p, md[0, nb], frames.numpy())
+    done = [i for i in range(L) if ref[i] is not None]
+    return comp.comp.cpu().numpy()[done], np.stack([ref[i] for i in done])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["f32", "f16"])
+def test_compositor_bytes_equal_the_reference_blend(dtype):
+    """G12 is byte work: identical float predictions -> identical uint8 composites, in fp32 and in the reference's
+    --fp16 arithmetic (scaling in float16), through three overlapping windows (inference_propainter.py:435-450)."""
+    got, ref = _compositor_case(dtype, "cpu")
+    assert got.dtype == np.uint8 and np.array_equal(got, ref), f"{(got != ref).mean():.3e} of bytes differ"
