@@ -119,24 +119,109 @@ def test_generator_vs_oracle_odd_sizes_fp32(models, sds):
     check("generator_odd", out, ref, 1e-3)
 
 
-def test_end_to_end_clip_vs_golden(models):
+# end-to-end PSNR floors (dB, composited uint8 frames vs the REAL reference's golden): (stages fp16?, RAFT precision)
+# -> floor = 3 dB under the value measured on MI355X (profiles/r2_parity_e2e.json); fp32 measures > 90 dB.
+E2E_PSNR_FLOOR = {(False, "f32"): 80.0, (False, "f16x3"): 80.0, (True, "f32"): 40.0, (True, "f16x3"): 40.0, (True, "f16"): 40.0}
+
+
+@pytest.mark.parametrize("fp16,raft_prec", sorted(E2E_PSNR_FLOOR), ids=lambda v: str(v))
+def test_end_to_end_clip_vs_golden(models, fp16, raft_prec):
     """Whole path (RAFT -> completion -> image propagation -> windows -> blend) at 128x192x10 with sub-video
-    chunking active; compared with the restated driver's composited uint8 frames by PSNR."""
+    chunking active, at every precision configuration the CLI / bench can run -- incl. the headline one (fp16 stages,
+    fp16 RAFT) -- compared with the REAL reference driver's composited uint8 frames by PSNR."""
     from propainter_amd.pipeline import InferenceConfig, run_clip
     g = load_golden("e2e_128x192.npz")
     cfg = InferenceConfig(raft_iter=int(g["raft_iter"]), subvideo_length=int(g["subvideo_length"]),
-                          neighbor_length=int(g["neighbor_length"]), ref_stride=int(g["ref_stride"]), fp16=False)
-    comp, st = run_clip(models, g["frames_u8"], g["masks_u8"], g["masks_u8"], cfg, torch.device("cuda"), return_stages=True)
-    torch.cuda.synchronize()
+                          neighbor_length=int(g["neighbor_length"]), ref_stride=int(g["ref_stride"]), fp16=fp16)
+    raft = models[0]
+    raft.precision = raft_prec
+    try:
+        comp, st = run_clip(models, g["frames_u8"], g["masks_u8"], g["masks_u8"], cfg, torch.device("cuda"), return_stages=True)
+        torch.cuda.synchronize()
+    finally:
+        raft.precision = None
     comp = comp.cpu().numpy()
     ref = g["comp"]
     assert comp.shape == ref.shape and comp.dtype == np.uint8
-    um = (st["updated_masks"][0, :, 0].cpu().numpy() > 0.5).astype(np.uint8)
-    assert (um != g["upd_masks"][0, :, 0]).mean() < 5e-3
+    um = (st["updated_masks"][0, :, 0].float().cpu().numpy() > 0.5).astype(np.uint8)
+    mism = (um != g["upd_masks"][0, :, 0]).mean()
     psnr = O.psnr(comp, ref)
     outside = g["masks_u8"][..., None] == 0
     assert np.array_equal(comp[np.broadcast_to(outside, comp.shape)], g["frames_u8"][np.broadcast_to(outside, comp.shape)])
-    assert psnr > 40.0, f"end-to-end PSNR vs reference {psnr:.2f} dB"
+    print(f"E2E_PARITY fp16={fp16} raft={raft_prec} psnr={psnr:.2f} upd_mask_mismatch={mism:.3e} "
+          f"bytes_differ={(comp != ref).mean():.3e} max_abs={np.abs(comp.astype(int) - ref.astype(int)).max()}")
+    assert mism < (5e-3 if not fp16 else 2e-2), mism
+    assert psnr > E2E_PSNR_FLOOR[(fp16, raft_prec)], f"end-to-end PSNR vs reference {psnr:.2f} dB (fp16={fp16}, RAFT {raft_prec})"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["f32", "f16"])
+def test_compositor_bytes_equal_the_reference_blend_on_device(dtype):
+    """G12 on the device: the same three-window case as the CPU test, bytes equal to the oracle's numpy blend."""
+    from tests.test_host_logic_cpu import _compositor_case
+    got, ref = _compositor_case(dtype, "cuda")
+    assert np.array_equal(got, ref), f"{(got != ref).mean():.3e} of bytes differ"
+
+
+# RAFT end-point error at the HEADLINE resolution (720x1280, 20 iterations; the 720p-only paths: >2 GiB buffers, frame and
+# pair chunking) against the fp32 CPU oracle (8.5 s of CPU): limits = 3x the values measured on MI355X.
+RAFT_720P_EPE_LIMIT = {"f32": (5e-5, 5e-4), "f16x3": (2e-4, 2e-3), "f16": (0.012, 0.06)}     # (mean, max) px
+
+
+def test_raft_720p_endpoint_error_vs_oracle(models):
+    from propainter_amd.synthetic import synthetic_clip
+    H, W, iters = 720, 1280, 20
+    fr = torch.from_numpy(synthetic_clip(2, H, W)).permute(0, 3, 1, 2).float().div(255)[None] * 2 - 1
+    raft = models[0]
+    sd = {k: v.float().cpu() for k, v in raft.fix_raft.state_dict().items()}
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    with torch.no_grad():
+        ref_f, ref_b = O.raft_bi(sd, fr, iters=iters)
+    msgs, bad = [], []
+    for prec, (lim_mean, lim_max) in RAFT_720P_EPE_LIMIT.items():
+        raft.precision = prec
+        try:
+            ff, fb = raft(fr.cuda(), iters=iters)
+            torch.cuda.synchronize()
+        finally:
+            raft.precision = None
+        assert ff.dtype == torch.float32 and ff.shape == (1, 1, 2, H, W)
+        epe = torch.cat([(ff.cpu() - ref_f).pow(2).sum(2).sqrt().flatten(), (fb.cpu() - ref_b).pow(2).sum(2).sqrt().flatten()])
+        msgs.append(f"RAFT_720P_EPE {prec}: mean {epe.mean():.3e} p99 {epe.quantile(0.99):.3e} max {epe.max():.3e} px "
+                    f"(flow range {ref_f.abs().max():.1f} px)")
+        if not (epe.mean() < lim_mean and epe.max() < lim_max):
+            bad.append(msgs[-1])
+    print("\n".join(msgs))
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16], ids=["f32", "f16"])
+def test_stages_at_432x240_vs_oracle(models, sds, dt):
+    """Flow completion (t = 6) and one generator window (t = 7, l_t = 5) at BASELINE config-2 resolution against the CPU
+    oracle on seeded inputs: shapes with ragged tiles (30x54 / 60x108 maps, 20x36 token grid, 4x4 windows)."""
+    fc, gen = models[1], models[2]
+    gq = torch.Generator().manual_seed(77)
+    H, W = 240, 432
+    t = 6
+    fl = (torch.randn(1, t, 2, H, W, generator=gq) * 3, torch.randn(1, t, 2, H, W, generator=gq) * 3)
+    m = torch.zeros(1, t + 1, 1, H, W)
+    m[:, :, :, 80:160, 144:288] = 1
+    ref_p = O.fc_forward_bidirect(sds["fc"], fl, m)
+    (pf, pb), _ = fc.forward_bidirect_flow((fl[0].cuda().to(dt), fl[1].cuda().to(dt)), m.cuda().to(dt))
+    torch.cuda.synchronize()
+    rt = 1e-3 if dt == torch.float32 else 3e-2
+    check("fc240_f", pf, ref_p[0], rt)
+    check("fc240_b", pb, ref_p[1], rt)
+    tt, lt = 7, 5
+    fr = torch.rand(1, tt, 3, H, W, generator=gq) * 2 - 1
+    mk = torch.zeros(1, tt, 1, H, W)
+    mk[:, :, :, 80:160, 144:288] = 1
+    mu = torch.zeros(1, tt, 1, H, W)
+    mu[:, :, :, 100:140, 180:250] = 1
+    gfl = (torch.randn(1, lt - 1, 2, H, W, generator=gq) * 2, torch.randn(1, lt - 1, 2, H, W, generator=gq) * 2)
+    ref = O.generator_forward(sds["gen"], fr * (1 - mk), gfl, mk, mu, lt)
+    out = gen((fr * (1 - mk)).cuda().to(dt), (gfl[0].cuda().to(dt), gfl[1].cuda().to(dt)), mk.cuda().to(dt), mu.cuda().to(dt), lt)
+    torch.cuda.synchronize()
+    check("gen240", out, ref, rt)
 
 
 @pytest.mark.parametrize("fp16", [False, True], ids=["f32", "f16"])
@@ -204,20 +289,120 @@ def test_cli_end_to_end_on_a_frame_folder(tmp_path):
     assert np.array_equal(f0[outside], clip[0][outside])          # known pixels pass through untouched
 
 
-def test_proinpainter_api_matches_the_clip_driver():
-    """ProInpainter(None, None, None).inpaint(...) (web-demo entry point of the reference) == run_clip on the same inputs."""
+def test_proinpainter_api_matches_the_oracle_driver(sds):
+    """ProInpainter(None, None, None).inpaint(...) (web-demo entry point of the reference, base_inpainter.py:163-374)
+    against the CPU oracle's driver on the same frames / dilated masks: fp32 engine, PSNR floor as the e2e test."""
     from propainter_amd.inpainter import ProInpainter
-    from propainter_amd.pipeline import InferenceConfig, run_clip
     from propainter_amd.synthetic import synthetic_clip, synthetic_mask
     import scipy.ndimage
     L, H, W = 6, 128, 192
     clip = synthetic_clip(L, H, W, seed=8)
     raw = synthetic_mask(H, W)
-    pi = ProInpainter(None, None, None, device="cuda:0", use_half=True)
+    pi = ProInpainter(None, None, None, device="cuda:0", use_half=False)
     out = pi.inpaint(clip, [raw] * L, raft_iter=3, neighbor_length=4, ref_stride=3)
     assert len(out) == L and out[0].shape == (H, W, 3) and out[0].dtype == np.uint8
     md = scipy.ndimage.binary_dilation(raw, iterations=4).astype(np.uint8) * 255
     masks = np.repeat(md[None], L, 0)
-    cfg = InferenceConfig(raft_iter=3, subvideo_length=80, neighbor_length=4, ref_stride=3, fp16=True)
-    ref = run_clip((pi.fix_raft, pi.fix_flow_complete, pi.model), clip, masks, masks, cfg, torch.device("cuda:0")).cpu().numpy()
-    assert np.array_equal(np.stack(out), ref)
+    ref = O.inpaint_video(sds, clip, masks, masks, raft_iter=3, subvideo_length=80, neighbor_length=4, ref_stride=3)
+    psnr = O.psnr(np.stack(out), np.stack(ref))
+    print(f"PROINPAINTER_PARITY psnr={psnr:.2f}")
+    assert psnr > 80.0, psnr
+    # half mode runs (reference default use_half=True) and stays close to the fp32 result
+    pi16 = ProInpainter(None, None, None, device="cuda:0", use_half=True)
+    out16 = pi16.inpaint(clip, [raw] * L, raft_iter=3, neighbor_length=4, ref_stride=3)
+    p16 = O.psnr(np.stack(out16), np.stack(ref))
+    print(f"PROINPAINTER_PARITY_FP16 psnr={p16:.2f}")
+    assert p16 > 40.0, p16
+
+
+def test_evaluation_protocol_vs_oracle(models, sds):
+    """scripts/evaluate_propainter.py protocol (:103-178,265): neighbor_length = 20 (stride 10), ref_stride = 10, NO
+    sub-video chunking (subvideo_length >= clip), all reference frames -- on a 24-frame 128x192 clip vs the oracle."""
+    from propainter_amd.pipeline import InferenceConfig, run_clip
+    from propainter_amd.synthetic import synthetic_clip, synthetic_mask
+    import scipy.ndimage
+    L, H, W = 24, 128, 192
+    clip = synthetic_clip(L, H, W, seed=21)
+    m = scipy.ndimage.binary_dilation(synthetic_mask(H, W), iterations=4).astype(np.uint8) * 255
+    masks = np.repeat(m[None], L, 0)
+    cfg = InferenceConfig(raft_iter=4, subvideo_length=10 ** 6, neighbor_length=20, ref_stride=10, fp16=False)
+    comp = run_clip(models, clip, masks, masks, cfg, torch.device("cuda")).cpu().numpy()
+    ref = O.inpaint_video(sds, clip, masks, masks, raft_iter=4, subvideo_length=10 ** 6, neighbor_length=20, ref_stride=10)
+    psnr = O.psnr(comp, np.stack(ref))
+    print(f"EVAL_PROTOCOL_PARITY psnr={psnr:.2f}")
+    assert psnr > 80.0, psnr
+
+
+def test_outpainting_end_to_end_vs_oracle(models, sds):
+    """video_outpainting (inference_propainter.py:117-156,243-246): the canvas is extended and everything outside the
+    original field of view is hole -- nearly every attention window is masked (the worst case of the sparse attention
+    kernel).  Same canvas / masks into the engine and into the oracle's driver."""
+    from PIL import Image
+    from propainter_amd import video_io
+    from propainter_amd.pipeline import InferenceConfig, run_clip
+    from propainter_amd.synthetic import synthetic_clip
+    L, H, W = 6, 112, 160
+    clip = synthetic_clip(L, H, W, seed=31)
+    frames, flow_masks, masks_dilated, size = video_io.extrapolation([Image.fromarray(f) for f in clip], (1.15, 1.2))
+    fr = np.stack([np.asarray(f, dtype=np.uint8) for f in frames])
+    fm, md = np.stack(flow_masks), np.stack(masks_dilated)
+    assert fr.shape[1] % 8 == 0 and fr.shape[2] % 8 == 0 and (md > 0).mean() > 0.2
+    cfg = InferenceConfig(raft_iter=3, subvideo_length=80, neighbor_length=4, ref_stride=3, fp16=False)
+    comp = run_clip(models, fr, fm, md, cfg, torch.device("cuda")).cpu().numpy()
+    ref = O.inpaint_video(sds, fr, fm, md, raft_iter=3, subvideo_length=80, neighbor_length=4, ref_stride=3)
+    psnr = O.psnr(comp, np.stack(ref))
+    print(f"OUTPAINT_PARITY psnr={psnr:.2f} canvas={fr.shape[1]}x{fr.shape[2]} hole={(md > 0).mean():.2f}")
+    assert psnr > 70.0, psnr
+
+
+def test_module_on_a_non_current_device_or_loud_error(models):
+    """Launches bind to the tensors' device: with a second GPU the module must run there while cuda:0 is current; a raw
+    engine op issued with the wrong device current must raise instead of launching on the wrong GPU's stream."""
+    from propainter_amd import hip
+    x = torch.zeros((1, 8, 8, 8), dtype=torch.float16, device="cuda:0")
+    if torch.cuda.device_count() < 2:
+        hip.upsample2x(x)      # current device == tensor device: fine
+        pytest.skip("single GPU: the cross-device half of this test needs two devices")
+    with torch.cuda.device(1):
+        with pytest.raises(RuntimeError, match="current device"):
+            hip.upsample2x(x)
+    raft = models[0]
+    g = load_golden("raft_128x192.npz")
+    fr = torch.from_numpy(g["frames_u8"]).permute(0, 3, 1, 2).float().div(255)[None] * 2 - 1
+    from tests.helpers import seeded_models as sm
+    raft1 = sm("cuda:1")[0]
+    ff, _ = raft1(fr.to("cuda:1"), iters=int(g["iters"]))
+    torch.cuda.synchronize("cuda:1")
+    check("raft_on_cuda1", ff[0], torch.from_numpy(g["flows_f"]), 1e-3, 1e-3)
+
+
+def test_rccl_exchange_single_rank_self_send():
+    """The `nccl` branch of sharding._dist_exchange (RCCL point-to-point) with world_size 1 and a self send/recv
+    (SURVEY 8e): run in a child process with a hard timeout so that a hung collective cannot hang the suite."""
+    import subprocess
+    import sys
+    code = """
+import os, torch, torch.distributed as dist
+os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29577')
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+from propainter_amd.sharding import Exchange, _dist_exchange, gather_frames
+dev = torch.device('cuda', 0)
+t = torch.arange(2 * 3 * 64 * 96, dtype=torch.float16, device=dev).view(2, 1, 3, 64, 96) / 7
+u = torch.randint(0, 256, (5, 64, 96, 3), dtype=torch.uint8, device=dev)
+stats = {}
+got = _dist_exchange(Exchange({0: t}, {0: (tuple(t.shape), t.dtype)}, 'self_f16'), dev, None, stats)
+assert torch.equal(got[0], t), 'fp16 payload differs'
+got = _dist_exchange(Exchange({0: u}, {0: (tuple(u.shape), u.dtype)}, 'self_u8'), dev, None, stats)
+assert torch.equal(got[0], u), 'uint8 payload differs'
+out = gather_frames(0, u, 5, dst=0)
+assert torch.equal(out, u)
+assert stats['self_f16']['sent_bytes'] == t.numel() * 2 and stats['self_u8']['recv_bytes'] == u.numel()
+dist.barrier(); torch.cuda.synchronize()
+dist.destroy_process_group()
+print('RCCL_SELF_OK', stats)
+"""
+    env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 0 and "RCCL_SELF_OK" in out, out[-3000:]
