@@ -1,0 +1,310 @@
+// RAFT correlation lookup WITHOUT the all-pairs volume (fp16 engine).
+//
+// The reference builds corr = f1^T f2 / 16 for every pair of positions (n8 x n8 fp32 per pair: 829 MB at 720p, 5.6 GB
+// at 1080p), avg-pools it into a 4-level pyramid (RAFT/corr.py:13-27,52-60) and, in each of the 20 iterations, reads a
+// 9x9 bilinear window per level around the current estimate (RAFT/corr.py:29-50).  Average pooling is linear, so
+//     avg_pool(f1[p] . f2)[q] = f1[p] . avg_pool(f2)[q]
+// and the pyramid of the VOLUME equals the volume of the feature PYRAMID: pp_corr_feature_pyramid pools f2 once per
+// pair (9.8 MB fp16 at 720p, L2 / Infinity-Cache resident) and pp_corr_lookup_otf computes, per iteration, exactly the
+// (10 x 10 integer neighbourhood) x 4 levels of dot products each pixel needs -- on MFMA -- and blends them bilinearly
+// into the 324-channel NHWC tile.  No volume GEMM, no pooling of 1.1 GB per pair, no 40-byte row gathers.
+//
+// Kernel: one 512-thread block per 8x8 tile of source pixels of one pair.  Per level:
+//   1. bounding box (in level coordinates, clipped to the map) of the 64 windows -> LDS;
+//   2. the 8 waves share the box's positions in N tiles of 16 targets: B fragments (16 targets x 256 channels of the
+//      level's f2) come straight from L2 into registers -- every 64-byte sector is used in full --, A fragments (the 64
+//      pixels x 256 channels of f1) stay in registers for the whole block, S = B x A^T on v_mfma_f32_16x16x32_f16 with
+//      fp32 accumulation, results to LDS as V[pixel][position] (fp32);
+//   3. every (pixel, a, b) output blends its four neighbours of V with the reference's per-tap coordinate round trip
+//      (bilinear_sampler's 2c/(W-1)-1 normalisation, zeros outside the map) and lands in an LDS staging tile;
+//   finally the staging tile goes out as full 656-byte NHWC rows.
+// The box of a smooth flow field is ~17x17 positions at level 0 (64 pixels share 289 targets instead of 6400).  A
+// box too large for LDS (wildly divergent flow inside one tile) is handled by the same code on pixel subsets: the four
+// 4x4 quadrants one after another, and single pixels in the worst case -- slower, never wrong.  The blend order is
+// fixed, nothing is accumulated with atomics: results are deterministic and independent of the batch.
+#include "common.h"
+
+namespace pp {
+
+struct CorrOtfParams {
+  const char* f1;            // fp16 NHWC [P, h, w, 256]
+  const char* f2[4];         // fp16 NHWC [P, h >> l, w >> l, 256]
+  const float* coords;       // fp32 [P, h, w, 2] (x, y)
+  _Float16* out;             // fp16 NHWC [P, h, w, ocs]; channels [0, 324) written, [324, ocpad) zeroed
+  int P, h, w, ocs, ocpad, tiles_x, tiles_y;
+  float scale;               // 1 / sqrt(256)
+};
+
+constexpr int OTF_VTOT = 27648;                    // floats of V storage (108 KB)
+constexpr int OTF_OROW = 328;                      // staging row (fp16 elements)
+constexpr int OTF_LDS = OTF_VTOT * 4 + 64 * OTF_OROW * 2 + 64 * 8 + 64;
+
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+  return v;
+}
+
+__global__ __launch_bounds__(512) void corr_otf_kernel(const CorrOtfParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __shared__ __attribute__((aligned(16))) char lds[OTF_LDS];
+  float* const V = reinterpret_cast<float*>(lds);
+  _Float16* const stage = reinterpret_cast<_Float16*>(lds + OTF_VTOT * 4);
+  float* const cxy = reinterpret_cast<float*>(lds + OTF_VTOT * 4 + 64 * OTF_OROW * 2);     // [64][2]; x = NaN marks a pixel outside the image
+  int* const box = reinterpret_cast<int*>(lds + OTF_VTOT * 4 + 64 * OTF_OROW * 2 + 64 * 8);   // bx0, by0, bw, bh
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, l4 = lane >> 4;
+
+  // ---- XCD-aware tile order: every XCD walks a contiguous run of tiles (neighbouring tiles share f2 rows in its L2)
+  int bid = blockIdx.x;
+  {
+    const int nblk = gridDim.x;
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, loc = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int txi = bid % p.tiles_x;
+  const int tyi = (bid / p.tiles_x) % p.tiles_y;
+  const int n = bid / (p.tiles_x * p.tiles_y);
+  const int ty0 = tyi * 8, tx0 = txi * 8;
+  // pixel q of the tile: M tile (quadrant) q >> 4, inside it row (q >> 2) & 3, column q & 3
+  auto tile_xy = [&](int q, int& x, int& y) {
+    x = tx0 + ((q >> 4) & 1) * 4 + (q & 3);
+    y = ty0 + (q >> 5) * 4 + ((q >> 2) & 3);
+  };
+
+  if (tid < 64) {
+    int x, y;
+    tile_xy(tid, x, y);
+    float cx = __builtin_nanf(""), cy = 0.f;
+    if (x < p.w && y < p.h) {
+      const float* c = p.coords + (((long long)n * p.h + y) * p.w + x) * 2;
+      cx = c[0];
+      cy = c[1];
+    }
+    cxy[tid * 2] = cx;
+    cxy[tid * 2 + 1] = cy;
+  }
+
+  // ---- A fragments: the 64 pixels x 256 channels of f1, resident for the whole block (4 M tiles x 8 k steps)
+  f16x8 afrag[4][8];
+  {
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(p.f1 + (long long)n * p.h * p.w * 512), 0, p.h * p.w * 512, 0x00020000);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      int x, y;
+      tile_xy(mt * 16 + l15, x, y);
+      const int voff = (x < p.w && y < p.h) ? (y * p.w + x) * 512 + l4 * 16 : (int)0x80000000;   // out of range -> zeros
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(r1, voff, ks * 64, 0);
+        afrag[mt][ks] = __builtin_bit_cast(f16x8, raw);
+      }
+    }
+  }
+  __syncthreads();
+
+  for (int lvl = 0; lvl < 4; ++lvl) {
+    const int Hl = p.h >> lvl, Wl = p.w >> lvl;
+    const float lscale = 1.f / (float)(1 << lvl);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(p.f2[lvl] + (long long)n * Hl * Wl * 512), 0, Hl * Wl * 512, 0x00020000);
+
+    // Processes the pixel set [p0, p0 + np), np in {64, 16, 1}.  Returns false (nothing done) when the set's box does
+    // not fit the V capacity of that set size.  Block-uniform control flow throughout.
+    auto process = [&](const int p0, const int np) -> bool {
+      // -- 1. bounding box of the windows [floor(c) - 4, floor(c) + 5] of the set, clipped to the map (wave 0)
+      if (wave == 0) {
+        int x0 = 1 << 30, x1 = -(1 << 30), y0 = 1 << 30, y1 = -(1 << 30);
+        if (lane < np) {
+          const float cx = cxy[(p0 + lane) * 2], cy = cxy[(p0 + lane) * 2 + 1];
+          if (cx == cx) {
+            const int fx = (int)floorf(cx * lscale), fy = (int)floorf(cy * lscale);
+            x0 = max(fx - 4, 0); x1 = min(fx + 5, Wl - 1);
+            y0 = max(fy - 4, 0); y1 = min(fy + 5, Hl - 1);
+            if (x1 < x0 || y1 < y0) { x0 = y0 = 1 << 30; x1 = y1 = -(1 << 30); }     // window entirely outside the map
+          }
+        }
+        x0 = wave_min(x0); y0 = wave_min(y0); x1 = wave_max(x1); y1 = wave_max(y1);
+        if (lane == 0) {
+          box[0] = x0; box[1] = y0;
+          box[2] = x1 >= x0 ? x1 - x0 + 1 : 0;
+          box[3] = y1 >= y0 ? y1 - y0 + 1 : 0;
+        }
+      }
+      __syncthreads();
+      const int bx0 = box[0], by0 = box[1], bw = box[2], bh = box[3];
+      const int area = bw * bh;
+      const int vstride = np == 64 ? 420 : (np == 16 ? 1716 : 27648);       // floats per pixel row of V; 420 = 4 (mod 32)
+      if (area > vstride) {
+        __syncthreads();            // box[] is rewritten by the next call
+        return false;
+      }
+      const int mt0 = p0 >> 4;       // first M tile of the set
+      const bool one_tile = np <= 16;
+      // -- 2. S = B x A^T over the box, N tiles of 16 positions round-robin over the 8 waves
+      const int ntiles = (area + 15) >> 4;
+      auto load_b = [&](int nt, u32x4 (&b)[8]) {
+        const int pos = nt * 16 + l15;
+        const int ry = pos / bw, rx = pos - ry * bw;
+        const int voff = pos < area ? ((by0 + ry) * Wl + bx0 + rx) * 512 + l4 * 16 : (int)0x80000000;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) b[ks] = __builtin_amdgcn_raw_buffer_load_b128(r2, voff, ks * 64, 0);
+      };
+      u32x4 bcur[8], bnxt[8];
+      if (wave < ntiles) load_b(wave, bcur);
+      for (int nt = wave; nt < ntiles; nt += 8) {
+        const bool more = nt + 8 < ntiles;
+        if (more) load_b(nt + 8, bnxt);
+        f32x4 acc[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          if (one_tile && mt != mt0) continue;
+#pragma unroll
+          for (int ks = 0; ks < 8; ++ks)
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bcur[ks]), afrag[mt][ks], acc[mt], 0, 0, 0);
+        }
+        // acc[mt][r] = S[position nt*16 + l4*4 + r][pixel mt*16 + l15]
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          if (one_tile && mt != mt0) continue;
+          const int q = mt * 16 + l15 - p0;                 // pixel index inside the set
+          if (q >= 0 && q < np)
+            *reinterpret_cast<f32x4*>(V + q * vstride + nt * 16 + l4 * 4) = acc[mt];
+        }
+        if (more) {
+#pragma unroll
+          for (int ks = 0; ks < 8; ++ks) bcur[ks] = bnxt[ks];
+        }
+      }
+      __syncthreads();
+      // -- 3. bilinear blend of the 81 taps (a moves x, b moves y; RAFT/corr.py:36-43)
+      for (int o = tid; o < np * 81; o += 512) {
+        const int q = o / 81, i = o - q * 81;
+        const float cx0 = cxy[(p0 + q) * 2];
+        if (!(cx0 == cx0)) continue;
+        const float cx = cx0 * lscale, cy = cxy[(p0 + q) * 2 + 1] * lscale;
+        const int a = i / 9, b = i - a * 9;
+        const float px = grid_roundtrip(cx + (float)(a - 4), Wl);
+        const float py = grid_roundtrip(cy + (float)(b - 4), Hl);
+        const float fx = floorf(px), fy = floorf(py);
+        const float lx = px - fx, ly = py - fy;
+        const int c0 = (int)fx - bx0, r0 = (int)fy - by0;
+        const float* vrow = V + q * vstride;
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int rr = r0 + (k >> 1), cc = c0 + (k & 1);
+          const float wgt = ((k & 1) ? lx : 1.f - lx) * ((k >> 1) ? ly : 1.f - ly);
+          float s = 0.f;
+          if (rr >= 0 && rr < bh && cc >= 0 && cc < bw) s = vrow[rr * bw + cc];
+          v += wgt * s;
+        }
+        stage[(p0 + q) * OTF_OROW + lvl * 81 + i] = (_Float16)(v * p.scale);
+      }
+      __syncthreads();              // V and box[] are reused
+      return true;
+    };
+
+    if (!process(0, 64)) {
+      for (int g = 0; g < 4; ++g) {
+        if (!process(g * 16, 16)) {
+          for (int q = 0; q < 16; ++q) process(g * 16 + q, 1);       // a single window (<= 100 positions) always fits
+        }
+      }
+    }
+  }
+
+  // ---- staging tile -> NHWC rows (16-byte chunks; channels [324, ocpad) are zero)
+  if (tid < 64) {
+#pragma unroll
+    for (int c = 324; c < OTF_OROW; ++c) stage[tid * OTF_OROW + c] = (_Float16)0.f;
+  }
+  __syncthreads();
+  const int chunks = p.ocpad / 8;
+  for (int o = tid; o < 64 * chunks; o += 512) {
+    const int q = o / chunks, c = o - q * chunks;
+    int x, y;
+    tile_xy(q, x, y);
+    if (x < p.w && y < p.h)
+      *reinterpret_cast<u32x4*>(p.out + (((long long)n * p.h + y) * p.w + x) * p.ocs + c * 8) =
+          *reinterpret_cast<const u32x4*>(stage + q * OTF_OROW + c * 8);
+  }
+#endif
+}
+
+// Level l of the f2 feature pyramid: mean over the 2^l x 2^l block at (y << l, x << l) -- what l nested
+// F.avg_pool2d(2, 2) (floor sizes) compute --, accumulated in fp32 from level 0 and rounded to fp16 once.
+__global__ void corr_feature_pool_kernel(const _Float16* __restrict__ f2, _Float16* __restrict__ out, int P, int h, int w, int lvl) {
+  const int Hl = h >> lvl, Wl = w >> lvl, s = 1 << lvl;
+  const long long total = (long long)P * Hl * Wl * 32;           // 8-channel chunks
+  const float inv = 1.f / (float)(s * s);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i & 31);
+    long long r = i >> 5;
+    const int x = (int)(r % Wl); r /= Wl;
+    const int y = (int)(r % Hl);
+    const long long n = r / Hl;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, v[8];
+    for (int dy = 0; dy < s; ++dy)
+      for (int dx = 0; dx < s; ++dx) {
+        load8<_Float16>(f2 + ((n * h + (y * s + dy)) * (long long)w + (x * s + dx)) * 256 + c * 8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += v[j];
+      }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] *= inv;
+    store8<_Float16>(out + ((n * Hl + y) * (long long)Wl + x) * 256 + c * 8, acc);
+  }
+}
+
+}  // namespace pp
+
+using namespace pp;
+
+extern "C" int pp_corr_feature_pyramid(const void* f2, void* lvl1, void* lvl2, void* lvl3, int P, int h, int w, void* stream) {
+  PP_REQUIRE(f2 && lvl1 && lvl2 && lvl3 && P > 0, PP_ERR_ARG, "pp_corr_feature_pyramid: bad arguments");
+  PP_REQUIRE((h >> 3) >= 2 && (w >> 3) >= 2, PP_ERR_ARG,
+             "pp_corr_feature_pyramid: level-3 map would be %dx%d (RAFT needs >= 2x2: inputs of at least 128x128)", h >> 3, w >> 3);
+  void* outs[3] = {lvl1, lvl2, lvl3};
+  for (int l = 1; l <= 3; ++l) {
+    const long long total = (long long)P * (h >> l) * (w >> l) * 32;
+    long long g = (total + 255) / 256;
+    if (g > 256 * 32) g = 256 * 32;
+    hipLaunchKernelGGL(corr_feature_pool_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const _Float16*)f2,
+                       (_Float16*)outs[l - 1], P, h, w, l);
+  }
+  return launch_status("pp_corr_feature_pyramid");
+}
+
+extern "C" int pp_corr_lookup_otf(const void* f1, const void* f2_lvl0, const void* f2_lvl1, const void* f2_lvl2,
+                                  const void* f2_lvl3, const float* coords, void* out, int out_cstride, int out_cpad, int P,
+                                  int h, int w, void* stream) {
+  PP_REQUIRE(f1 && f2_lvl0 && f2_lvl1 && f2_lvl2 && f2_lvl3 && coords && out, PP_ERR_ARG, "pp_corr_lookup_otf: null pointer");
+  PP_REQUIRE(P > 0 && (h >> 3) >= 2 && (w >> 3) >= 2, PP_ERR_ARG,
+             "pp_corr_lookup_otf: level-3 map would be %dx%d (RAFT needs >= 2x2: inputs of at least 128x128)", h >> 3, w >> 3);
+  PP_REQUIRE(out_cpad >= 324 && out_cpad <= OTF_OROW && out_cpad % 8 == 0 && out_cstride >= out_cpad && out_cstride % 8 == 0, PP_ERR_ARG,
+             "pp_corr_lookup_otf: out_cpad %d (324..328, multiple of 8) / cstride %d", out_cpad, out_cstride);
+  PP_REQUIRE((long long)h * w * 512 < (1ll << 31), PP_ERR_ARG, "pp_corr_lookup_otf: feature map of %dx%d exceeds 2 GiB per pair", h, w);
+  PP_REQUIRE(((uintptr_t)f1 % 16) == 0 && ((uintptr_t)out % 16) == 0, PP_ERR_ALIGN, "pp_corr_lookup_otf: pointers must be 16-byte aligned");
+  CorrOtfParams p;
+  p.f1 = (const char*)f1;
+  p.f2[0] = (const char*)f2_lvl0; p.f2[1] = (const char*)f2_lvl1; p.f2[2] = (const char*)f2_lvl2; p.f2[3] = (const char*)f2_lvl3;
+  p.coords = coords; p.out = (_Float16*)out;
+  p.P = P; p.h = h; p.w = w; p.ocs = out_cstride; p.ocpad = out_cpad;
+  p.tiles_x = (w + 7) / 8; p.tiles_y = (h + 7) / 8;
+  p.scale = 1.f / 16.f;
+  const long long nblk = (long long)P * p.tiles_x * p.tiles_y;
+  PP_REQUIRE(nblk < (1ll << 31), PP_ERR_ARG, "pp_corr_lookup_otf: too many tiles");
+  hipLaunchKernelGGL(corr_otf_kernel, dim3((unsigned)nblk), dim3(512), 0, (hipStream_t)stream, p);
+  return launch_status("pp_corr_lookup_otf");
+}

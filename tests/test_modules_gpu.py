@@ -121,7 +121,8 @@ def test_generator_vs_oracle_odd_sizes_fp32(models, sds):
 
 # end-to-end PSNR floors (dB, composited uint8 frames vs the REAL reference's golden): (stages fp16?, RAFT precision)
 # -> floor = 3 dB under the value measured on MI355X (profiles/r2_parity_e2e.json); fp32 measures > 90 dB.
-E2E_PSNR_FLOOR = {(False, "f32"): 80.0, (False, "f16x3"): 80.0, (True, "f32"): 40.0, (True, "f16x3"): 40.0, (True, "f16"): 40.0}
+# measured: f32/f32 94.0, f32/f16x3 92.8, f16 stages 67.3 with any RAFT precision (max |d| = 1 byte in every configuration)
+E2E_PSNR_FLOOR = {(False, "f32"): 91.0, (False, "f16x3"): 89.8, (True, "f32"): 64.3, (True, "f16x3"): 64.3, (True, "f16"): 64.3}
 
 
 @pytest.mark.parametrize("fp16,raft_prec", sorted(E2E_PSNR_FLOOR), ids=lambda v: str(v))
@@ -164,7 +165,8 @@ def test_compositor_bytes_equal_the_reference_blend_on_device(dtype):
 
 # RAFT end-point error at the HEADLINE resolution (720x1280, 20 iterations; the 720p-only paths: >2 GiB buffers, frame and
 # pair chunking) against the fp32 CPU oracle (8.5 s of CPU): limits = 3x the values measured on MI355X.
-RAFT_720P_EPE_LIMIT = {"f32": (5e-5, 5e-4), "f16x3": (2e-4, 2e-3), "f16": (0.012, 0.06)}     # (mean, max) px
+# measured (mean / max px): f32 7.2e-6 / 5.7e-5, f16x3 2.3e-5 / 2.1e-4, f16 3.7e-3 / 1.8e-2
+RAFT_720P_EPE_LIMIT = {"f32": (2.5e-5, 2e-4), "f16x3": (7e-5, 7e-4), "f16": (0.012, 0.06)}     # (mean, max) px
 
 
 def test_raft_720p_endpoint_error_vs_oracle(models):
@@ -306,13 +308,13 @@ def test_proinpainter_api_matches_the_oracle_driver(sds):
     ref = O.inpaint_video(sds, clip, masks, masks, raft_iter=3, subvideo_length=80, neighbor_length=4, ref_stride=3)
     psnr = O.psnr(np.stack(out), np.stack(ref))
     print(f"PROINPAINTER_PARITY psnr={psnr:.2f}")
-    assert psnr > 80.0, psnr
+    assert psnr > 90.4, psnr              # measured 93.45
     # half mode runs (reference default use_half=True) and stays close to the fp32 result
     pi16 = ProInpainter(None, None, None, device="cuda:0", use_half=True)
     out16 = pi16.inpaint(clip, [raw] * L, raft_iter=3, neighbor_length=4, ref_stride=3)
     p16 = O.psnr(np.stack(out16), np.stack(ref))
     print(f"PROINPAINTER_PARITY_FP16 psnr={p16:.2f}")
-    assert p16 > 40.0, p16
+    assert p16 > 64.2, p16              # measured 67.19
 
 
 def test_evaluation_protocol_vs_oracle(models, sds):
@@ -330,7 +332,7 @@ def test_evaluation_protocol_vs_oracle(models, sds):
     ref = O.inpaint_video(sds, clip, masks, masks, raft_iter=4, subvideo_length=10 ** 6, neighbor_length=20, ref_stride=10)
     psnr = O.psnr(comp, np.stack(ref))
     print(f"EVAL_PROTOCOL_PARITY psnr={psnr:.2f}")
-    assert psnr > 80.0, psnr
+    assert psnr > 88.4, psnr              # measured 91.42
 
 
 def test_outpainting_end_to_end_vs_oracle(models, sds):
@@ -352,7 +354,7 @@ def test_outpainting_end_to_end_vs_oracle(models, sds):
     ref = O.inpaint_video(sds, fr, fm, md, raft_iter=3, subvideo_length=80, neighbor_length=4, ref_stride=3)
     psnr = O.psnr(comp, np.stack(ref))
     print(f"OUTPAINT_PARITY psnr={psnr:.2f} canvas={fr.shape[1]}x{fr.shape[2]} hole={(md > 0).mean():.2f}")
-    assert psnr > 70.0, psnr
+    assert psnr > 92.5, psnr              # measured 95.56
 
 
 def test_module_on_a_non_current_device_or_loud_error(models):
