@@ -115,7 +115,28 @@ typedef struct {
                                     multiple of 32 / 64 channels); 0 = unknown (always correct)                   */
   int32_t tap_h, tap_w;          /* > 0: the table describes a dense, dilation-1 tap_h x tap_w window in row-major tap order
                                     (enables the halo-tile kernel for stride-1 "same" convolutions); 0 = unknown    */
+  /* ---- fused recurrent-cell epilogue (SepConvGRU, RAFT/update.py:45-60); all optional, groups == 1 ------------
+   * v = act((acc + bias) * out_scale + preadd[pixel, co]) -- `preadd` is a partial sum computed ahead of time by
+   * another pp_conv2d over the iteration-invariant input channels (NHWC, dtype = dtype), added BEFORE the activation;
+   * fuse == PP_FUSE_GRU_ZR (cout_g = 2C, fuse_split = C): co <  C: out[pixel, out_choff + co]      = v           (z)
+   *                                                       co >= C: out2[pixel, out2_choff + co - C] = v * a[co-C] (r*h)
+   * fuse == PP_FUSE_GRU_H  (cout_g = C):  out[pixel, out_choff + co] = (1 - b[co]) * a[co] + b[co] * v    (new h)
+   *   with a = fuse_a (h), b = fuse_b (z), NHWC windows of dtype; `out` may alias fuse_a (element-wise in place).   */
+  const void* preadd;
+  int32_t preadd_cstride, preadd_choff;
+  int32_t fuse;                  /* PP_FUSE_NONE / PP_FUSE_GRU_ZR / PP_FUSE_GRU_H                                 */
+  int32_t fuse_split;
+  const void* fuse_a;
+  int32_t fuse_a_cstride, fuse_a_choff;
+  const void* fuse_b;
+  int32_t fuse_b_cstride, fuse_b_choff;
+  void* out2;
+  int32_t out2_cstride, out2_choff;
 } pp_conv_args_t;
+
+#define PP_FUSE_NONE 0
+#define PP_FUSE_GRU_ZR 1
+#define PP_FUSE_GRU_H 2
 
 /* Host helper: fill `out` (kchunks_padded x 4 int32) for `ntaps` taps (dy[i], dx[i] are input
  * offsets added to out*stride - pad) over `nsrc` sources of src_channels[i] channels each (each a
@@ -168,6 +189,18 @@ int pp_corr_avgpool(const float* in, float* out, int64_t M, int H, int W, void* 
  * (x/2^l + a - 4, y/2^l + b - 4) (first index moves x; RAFT/corr.py:36-43); channels 324..C_out_pad-1 = 0. */
 int pp_corr_lookup(const float* lvl0, const float* lvl1, const float* lvl2, const float* lvl3, const float* coords,
                    void* out, int out_cstride, int out_cpad, int B, int h, int w, int out_dtype, void* stream);
+
+/* RAFT correlation WITHOUT the all-pairs volume (fp16 engine; replaces CorrBlock.__init__ + __call__,
+ * RAFT/corr.py:13-60, as a pair): avg_pool(f1 . f2) = f1 . avg_pool(f2), so
+ *   pp_corr_feature_pyramid pools f2 (fp16 NHWC [P,h,w,256]) once per pair into levels 1..3
+ *     ([P, h>>l, w>>l, 256], mean over the 2^l x 2^l block = l nested avg_pool2d(2,2) with floor sizes), and
+ *   pp_corr_lookup_otf computes per iteration the 4 x 100 dot products each pixel's 9x9 windows touch (MFMA) and
+ *     blends them (bilinear, zeros padding, the reference's coordinate round trip) into out NHWC [P,h,w,out_cstride]
+ *     fp16: channel l*81 + a*9 + b samples (x/2^l + a - 4, y/2^l + b - 4), scaled by 1/sqrt(256); channels
+ *     [324, out_cpad) are zeroed.  coords fp32 [P,h,w,2] = (x, y).  Deterministic, batch-invariant. */
+int pp_corr_feature_pyramid(const void* f2, void* lvl1, void* lvl2, void* lvl3, int P, int h, int w, void* stream);
+int pp_corr_lookup_otf(const void* f1, const void* f2_lvl0, const void* f2_lvl1, const void* f2_lvl2, const void* f2_lvl3,
+                       const float* coords, void* out, int out_cstride, int out_cpad, int P, int h, int w, void* stream);
 
 /* convex 8x upsampling: flow fp32 NHWC [B,h,w,2]; mask NHWC [B,h,w,576] (channel k*64 + i*8 + j, already
  * scaled by 0.25); out fp32 planar [B,2,8h,8w]. */

@@ -117,8 +117,12 @@ class ConvLayer:
         return OH, OW
 
     def __call__(self, srcs, out=None, out_choff=0, act=None, act_param=0.0, out_scale=1.0, residual=None,
-                 res_choff=0, act2=None, out_dtype=None, dcn_offmask=None, out_hw=None):
-        """srcs: list of tensors or (tensor, choff) (NHWC, dtype == layer dtype).  Returns `out` NHWC."""
+                 res_choff=0, act2=None, out_dtype=None, dcn_offmask=None, out_hw=None, preadd=None, fuse=None):
+        """srcs: list of tensors or (tensor, choff) (NHWC, dtype == layer dtype).  Returns `out` NHWC.
+        preadd: tensor or (tensor, choff) added to (acc + bias) * out_scale BEFORE the activation (a partial sum another
+        convolution computed ahead of time).  fuse: fused SepConvGRU gating (pp_conv_args_t.fuse), one of
+          dict(kind="gru_zr", h=(t, choff), out2=(t, choff), split=C)   out <- z = act(v)[:C], out2 <- act(v)[C:] * h
+          dict(kind="gru_h", h=(t, choff), z=(t, choff))                 out <- (1 - z) * h + z * act(v)"""
         srcs = [(s, 0) if torch.is_tensor(s) else s for s in srcs]
         assert len(srcs) == len(self.src_channels), (len(srcs), self.src_channels)
         x0 = srcs[0][0]
@@ -157,10 +161,31 @@ class ConvLayer:
         if dcn_offmask is not None:
             assert self.dcn and dcn_offmask.dtype == self.dtype and dcn_offmask.is_contiguous()
             a.dcn_offmask, a.dcn_cstride, a.dcn_mask_off = dcn_offmask.data_ptr(), dcn_offmask.shape[-1], 288
+        win = lambda x: (x, 0) if torch.is_tensor(x) else x
+        if preadd is not None:
+            t, co = win(preadd)
+            assert t.dtype == self.dtype and t.is_contiguous() and t.shape[:3] == (N, OH, OW)
+            a.preadd, a.preadd_cstride, a.preadd_choff = t.data_ptr(), t.shape[-1], co
+        if fuse is not None:
+            (ht, hc) = win(fuse["h"])
+            assert ht.dtype == self.dtype and ht.is_contiguous() and out.dtype == self.dtype
+            a.fuse_a, a.fuse_a_cstride, a.fuse_a_choff = ht.data_ptr(), ht.shape[-1], hc
+            if fuse["kind"] == "gru_zr":
+                (ot, oc) = win(fuse["out2"])
+                assert ot.dtype == self.dtype and ot.is_contiguous()
+                a.fuse, a.fuse_split = hip.FUSE_GRU_ZR, int(fuse["split"])
+                a.out2, a.out2_cstride, a.out2_choff = ot.data_ptr(), ot.shape[-1], oc
+            elif fuse["kind"] == "gru_h":
+                (zt, zc) = win(fuse["z"])
+                assert zt.dtype == self.dtype and zt.is_contiguous()
+                a.fuse = hip.FUSE_GRU_H
+                a.fuse_b, a.fuse_b_cstride, a.fuse_b_choff = zt.data_ptr(), zt.shape[-1], zc
+            else:
+                raise ValueError(fuse["kind"])
         a.impl = 3 if self.split3 else self.impl
         a.ktable_uniform = self.ktable_uniform
         a.tap_h, a.tap_w = self.tap_hw
-        self._keep = (srcs, out, residual, dcn_offmask)
+        self._keep = (srcs, out, residual, dcn_offmask, preadd, fuse)
         hip.conv2d_raw(a, cin_read=sum(self.src_cpad) * self.groups, on=x0)
         return out
 

@@ -105,4 +105,18 @@ __device__ __forceinline__ float grid_roundtrip(float c, int size) {
 
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// Buffer descriptor over [base, base + bytes) whose inputs are PROVABLY wave-uniform to the compiler (readfirstlane on
+// the pointer halves and the size): without this hipcc wraps every buffer op that uses a descriptor derived from
+// block-id arithmetic in a "waterfall" loop (4 x v_readfirstlane + compare + saveexec per memory op), which serialises
+// consecutive loads.  The caller guarantees that base / bytes really are the same in every lane of the wave.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_buffer_rsrc(const void* base, int bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  const int nb = __builtin_amdgcn_readfirstlane(bytes);
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, nb, 0x00020000);
+}
+#endif
+
 }  // namespace pp

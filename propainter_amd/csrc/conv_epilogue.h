@@ -24,11 +24,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc_)
   typedef _Float16 T;
   const int l15 = lane & 15, l4 = lane >> 4;
   const bool has_res = p.residual != nullptr;
-  const bool stage16 = p.out_f16 && !has_res;
+  // "late" path (partial-sum pre-add and / or fused GRU gating): phase 1 only adds the bias, the activation and the gate
+  // arithmetic run in phase 2 on 8 consecutive couts per lane, where preadd / h / z are read with 16-byte loads
+  const bool late = p.preadd != nullptr || p.fuse != PP_FUSE_NONE;
+  const bool stage16 = p.out_f16 && !has_res && !late;
   // ---- phase 1: bias, scale, activation in registers (each lane: 4 consecutive couts of 16 pixel rows per tile)
   {
     const float scale = p.out_scale;
-    const int act = p.act;
+    const int act = late ? PP_ACT_NONE : p.act;
     const float slope = act == PP_ACT_NONE ? 1.f : (act == PP_ACT_LRELU ? p.act_param : 0.f);
 #pragma unroll
     for (int a = 0; a < TN; ++a) {
@@ -68,7 +71,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc_)
       }
     }
   }
-  if (!has_res && p.act2 == PP_ACT_RELU) {          // act2 is defined as "after the residual add"; without a residual it still applies
+  if (!has_res && !late && p.act2 == PP_ACT_RELU) {          // act2 is defined as "after the residual add"; without a residual it still applies
 #pragma unroll
     for (int a = 0; a < TN; ++a)
 #pragma unroll
@@ -133,6 +136,43 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc_)
     const f32x4 hi = *reinterpret_cast<const f32x4*>(et + prow * LDF + cl + 4);
 #pragma unroll
     for (int r = 0; r < 4; ++r) { v[r] = lo[r]; v[4 + r] = hi[r]; }
+    if (late) {
+      if (p.preadd != nullptr) {
+        float pv[8];
+        const T* pp_ = reinterpret_cast<const T*>(p.preadd) + m * p.preadd_cstride + p.preadd_choff + co;
+        if (nval == 8 && ((p.preadd_cstride | p.preadd_choff) & 7) == 0) load8<T>(pp_, pv);
+        else {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) pv[r] = r < nval ? to_f32(pp_[r]) : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += pv[r];
+      }
+      const float slope2 = p.act == PP_ACT_NONE ? 1.f : (p.act == PP_ACT_LRELU ? p.act_param : 0.f);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] = act_late(v[r], p.act, slope2);
+      if (p.fuse == PP_FUSE_GRU_ZR) {
+        if (co >= p.fuse_split) {                       // r half: r * h -> out2 (8-cout chunks never straddle the split)
+          const int cr = co - p.fuse_split;
+          float hv[8];
+          load8<T>(reinterpret_cast<const T*>(p.fuse_a) + m * p.fuse_a_cstride + p.fuse_a_choff + cr, hv);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[r] *= hv[r];
+          store8<T>(reinterpret_cast<T*>(p.out2) + m * p.out2_cstride + p.out2_choff + cr, v);
+          continue;
+        }
+      } else if (p.fuse == PP_FUSE_GRU_H) {
+        float hv[8], zv[8];
+        load8<T>(reinterpret_cast<const T*>(p.fuse_a) + m * p.fuse_a_cstride + p.fuse_a_choff + co, hv);
+        load8<T>(reinterpret_cast<const T*>(p.fuse_b) + m * p.fuse_b_cstride + p.fuse_b_choff + co, zv);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = (1.f - zv[r]) * hv[r] + zv[r] * v[r];
+      }
+      if (!has_res && relu2) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
+    }
     if (has_res) {
       const T* rp = reinterpret_cast<const T*>(p.residual) + m * p.res_cstride + res_cbase + co;
       if (nval == 8 && res_vec_ok) {

@@ -324,11 +324,34 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
       const int co = n0 + wn * WCO + a * 16 + (lane >> 4) * 4;
       if (co >= p.cout_g) continue;
       float v[4];
+      const bool late = p.preadd != nullptr || p.fuse != PP_FUSE_NONE;     // fused recurrent-cell epilogue (groups == 1)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float x = acc[a][b][r];
         if (p.bias != nullptr && co + r < p.cout_g) x += p.bias[g * p.cout_g + co + r];
-        v[r] = apply_act(x * p.out_scale, p.act, p.act_param);
+        x *= p.out_scale;
+        if (late && p.preadd != nullptr && co + r < p.cout_g)
+          x += to_f32(reinterpret_cast<const T*>(p.preadd)[m * p.preadd_cstride + p.preadd_choff + co + r]);
+        v[r] = apply_act(x, p.act, p.act_param);
+      }
+      if (p.fuse == PP_FUSE_GRU_ZR && co >= p.fuse_split) {          // r half: r * h -> out2
+        const int cr = co - p.fuse_split;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (co + r < p.cout_g) {
+            const float hv = to_f32(reinterpret_cast<const T*>(p.fuse_a)[m * p.fuse_a_cstride + p.fuse_a_choff + cr + r]);
+            reinterpret_cast<T*>(p.out2)[m * p.out2_cstride + p.out2_choff + cr + r] = from_f32<T>(v[r] * hv);
+          }
+        continue;
+      }
+      if (p.fuse == PP_FUSE_GRU_H) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (co + r < p.cout_g) {
+            const float hv = to_f32(reinterpret_cast<const T*>(p.fuse_a)[m * p.fuse_a_cstride + p.fuse_a_choff + co + r]);
+            const float zv = to_f32(reinterpret_cast<const T*>(p.fuse_b)[m * p.fuse_b_cstride + p.fuse_b_choff + co + r]);
+            v[r] = (1.f - zv) * hv + zv * v[r];
+          }
       }
       if (p.residual != nullptr) {
         const T* rp = reinterpret_cast<const T*>(p.residual) + m * p.res_cstride + p.res_choff + g * p.out_cgroup + co;
@@ -488,6 +511,30 @@ extern "C" int pp_conv2d(const pp_conv_args_t* a, void* stream) {
   const bool deform = a->dcn_offmask != nullptr;
   p.groups = a->groups; p.tiles_m = 0; p.tiles_n = 0; p.ktable_uniform = a->ktable_uniform;
   p.tap_h = a->tap_h; p.tap_w = a->tap_w;
+  p.preadd = (const char*)a->preadd; p.preadd_cstride = a->preadd_cstride; p.preadd_choff = a->preadd_choff;
+  p.fuse = a->fuse; p.fuse_split = a->fuse_split;
+  p.fuse_a = (const char*)a->fuse_a; p.fuse_a_cstride = a->fuse_a_cstride; p.fuse_a_choff = a->fuse_a_choff;
+  p.fuse_b = (const char*)a->fuse_b; p.fuse_b_cstride = a->fuse_b_cstride; p.fuse_b_choff = a->fuse_b_choff;
+  p.out2 = (char*)a->out2; p.out2_cstride = a->out2_cstride; p.out2_choff = a->out2_choff;
+  if (a->preadd != nullptr || a->fuse != PP_FUSE_NONE) {
+    PP_REQUIRE(a->groups == 1 && !deform && a->out_dtype == a->dtype && a->cout_g % 8 == 0, PP_ERR_ARG,
+               "pp_conv2d: the fused epilogue (preadd / fuse) needs groups == 1, no deformable sampling, out_dtype == dtype, cout_g %% 8 == 0");
+    PP_REQUIRE(a->fuse >= PP_FUSE_NONE && a->fuse <= PP_FUSE_GRU_H, PP_ERR_ARG, "pp_conv2d: fuse %d", a->fuse);
+    PP_REQUIRE(a->preadd == nullptr || (((uintptr_t)a->preadd % 16) == 0 && ((a->preadd_cstride | a->preadd_choff) & 7) == 0),
+               PP_ERR_ALIGN, "pp_conv2d: preadd must be 16-byte aligned with cstride / choff multiples of 8");
+    if (a->fuse != PP_FUSE_NONE) {
+      PP_REQUIRE(a->fuse_a != nullptr && ((uintptr_t)a->fuse_a % 16) == 0 && ((a->fuse_a_cstride | a->fuse_a_choff) & 7) == 0,
+                 PP_ERR_ALIGN, "pp_conv2d: fuse_a must be set, 16-byte aligned, cstride / choff multiples of 8");
+      PP_REQUIRE(a->residual == nullptr, PP_ERR_ARG, "pp_conv2d: fuse and residual are exclusive");
+    }
+    if (a->fuse == PP_FUSE_GRU_ZR)
+      PP_REQUIRE(a->out2 != nullptr && a->fuse_split > 0 && a->fuse_split % 8 == 0 && a->fuse_split < a->cout_g &&
+                     ((uintptr_t)a->out2 % 16) == 0 && ((a->out2_cstride | a->out2_choff) & 7) == 0,
+                 PP_ERR_ARG, "pp_conv2d: PP_FUSE_GRU_ZR needs out2 (aligned) and 0 < fuse_split < cout_g, multiple of 8");
+    if (a->fuse == PP_FUSE_GRU_H)
+      PP_REQUIRE(a->fuse_b != nullptr && ((uintptr_t)a->fuse_b % 16) == 0 && ((a->fuse_b_cstride | a->fuse_b_choff) & 7) == 0,
+                 PP_ERR_ALIGN, "pp_conv2d: PP_FUSE_GRU_H needs fuse_b (z), 16-byte aligned, cstride / choff multiples of 8");
+  }
   hipStream_t st = (hipStream_t)stream;
   if (a->dtype == PP_F16 && !deform && (a->impl == 0 || a->impl == 80 || a->impl == 81)) {
     // A-stationary kernel for the short-K single-source linears (transformer GEMMs)

@@ -31,7 +31,25 @@ struct ConvParams {
   int tiles_m, tiles_n, groups;   // v2 only: 1-D grid decomposition
   int ktable_uniform;             // v2 only: bit 4 / bit 8 set when every 4- / 8-chunk K step is one (tap, source) run
   int tap_h, tap_w;               // v3 only: rectangular dilation-1 tap window (0 = unknown)
+  // fused recurrent-cell epilogue (pp_conv_args_t: preadd / fuse*)
+  const char* preadd;
+  int preadd_cstride, preadd_choff;
+  int fuse, fuse_split;
+  const char* fuse_a;
+  int fuse_a_cstride, fuse_a_choff;
+  const char* fuse_b;
+  int fuse_b_cstride, fuse_b_choff;
+  char* out2;
+  int out2_cstride, out2_choff;
 };
+
+// activation of the late (post-staging) epilogue path: same fast forms as the register path of conv_epilogue.h
+__device__ __forceinline__ float act_late(float v, int act, float slope) {
+  if (act < PP_ACT_SIGMOID) return v > 0.f ? v : v * slope;
+  if (act == PP_ACT_SIGMOID) return __builtin_amdgcn_rcpf(1.f + __expf(-v));
+  if (act == PP_ACT_TANH) return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * v) + 1.f);
+  return apply_act_special(v, act);
+}
 
 // conv_gemm_v2.hip; returns -1000 when the shape is outside that family (caller falls back to conv_gemm.hip)
 int conv_v2_dispatch(const ConvParams& p, int cfg, hipStream_t stream);

@@ -35,7 +35,7 @@ struct CorrOtfParams {
   float scale;               // 1 / sqrt(256)
 };
 
-constexpr int OTF_VTOT = 27648;                    // floats of V storage (108 KB)
+constexpr int OTF_VTOT = 28928;                    // floats of V storage (113 KB): 64 x 452, 16 x 1808, 1 x 28928
 constexpr int OTF_OROW = 328;                      // staging row (fp16 elements)
 constexpr int OTF_LDS = OTF_VTOT * 4 + 64 * OTF_OROW * 2 + 64 * 8 + 64;
 
@@ -95,8 +95,7 @@ __global__ __launch_bounds__(512) void corr_otf_kernel(const CorrOtfParams p) {
   // ---- A fragments: the 64 pixels x 256 channels of f1, resident for the whole block (4 M tiles x 8 k steps)
   f16x8 afrag[4][8];
   {
-    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(p.f1 + (long long)n * p.h * p.w * 512), 0, p.h * p.w * 512, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r1 = uniform_buffer_rsrc(p.f1 + (long long)n * p.h * p.w * 512, p.h * p.w * 512);
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       int x, y;
@@ -114,8 +113,7 @@ __global__ __launch_bounds__(512) void corr_otf_kernel(const CorrOtfParams p) {
   for (int lvl = 0; lvl < 4; ++lvl) {
     const int Hl = p.h >> lvl, Wl = p.w >> lvl;
     const float lscale = 1.f / (float)(1 << lvl);
-    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(p.f2[lvl] + (long long)n * Hl * Wl * 512), 0, Hl * Wl * 512, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2 = uniform_buffer_rsrc(p.f2[lvl] + (long long)n * Hl * Wl * 512, Hl * Wl * 512);
 
     // Processes the pixel set [p0, p0 + np), np in {64, 16, 1}.  Returns false (nothing done) when the set's box does
     // not fit the V capacity of that set size.  Block-uniform control flow throughout.
@@ -142,15 +140,15 @@ __global__ __launch_bounds__(512) void corr_otf_kernel(const CorrOtfParams p) {
       __syncthreads();
       const int bx0 = box[0], by0 = box[1], bw = box[2], bh = box[3];
       const int area = bw * bh;
-      const int vstride = np == 64 ? 420 : (np == 16 ? 1716 : 27648);       // floats per pixel row of V; 420 = 4 (mod 32)
-      if (area > vstride) {
+      const int vstride = OTF_VTOT / np;       // floats per pixel row of V: 452 (= 4 mod 32: conflict-free tile stores) / 1808 / 28928
+      const int ntiles = (area + 15) >> 4;       // N tiles of 16 positions; whole tiles are stored, so they must fit the row
+      if (ntiles * 16 > vstride) {
         __syncthreads();            // box[] is rewritten by the next call
         return false;
       }
       const int mt0 = p0 >> 4;       // first M tile of the set
       const bool one_tile = np <= 16;
       // -- 2. S = B x A^T over the box, N tiles of 16 positions round-robin over the 8 waves
-      const int ntiles = (area + 15) >> 4;
       auto load_b = [&](int nt, u32x4 (&b)[8]) {
         const int pos = nt * 16 + l15;
         const int ry = pos / bw, rx = pos - ry * bw;

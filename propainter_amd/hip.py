@@ -15,6 +15,7 @@ from . import build as _build
 PP_F32, PP_F16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID, ACT_TANH, ACT_GELU = 0, 1, 2, 3, 4, 5
 MAX_SRC = 4
+FUSE_NONE, FUSE_GRU_ZR, FUSE_GRU_H = 0, 1, 2
 
 
 class ConvSrc(C.Structure):
@@ -35,6 +36,11 @@ class ConvArgs(C.Structure):
         ("src_gstride", C.c_int64), ("out_gstride", C.c_int64), ("dcn_offmask", C.c_void_p),
         ("dcn_cstride", C.c_int32), ("dcn_mask_off", C.c_int32), ("impl", C.c_int32), ("ktable_uniform", C.c_int32),
         ("tap_h", C.c_int32), ("tap_w", C.c_int32),
+        ("preadd", C.c_void_p), ("preadd_cstride", C.c_int32), ("preadd_choff", C.c_int32),
+        ("fuse", C.c_int32), ("fuse_split", C.c_int32),
+        ("fuse_a", C.c_void_p), ("fuse_a_cstride", C.c_int32), ("fuse_a_choff", C.c_int32),
+        ("fuse_b", C.c_void_p), ("fuse_b_cstride", C.c_int32), ("fuse_b_choff", C.c_int32),
+        ("out2", C.c_void_p), ("out2_cstride", C.c_int32), ("out2_choff", C.c_int32),
     ]
 
 
@@ -325,6 +331,32 @@ def corr_lookup(levels, coords, out):
                                 _i(out.shape[-1]), _i(out.shape[-1]), _i(B), _i(h), _i(w), _i(dtype_code(out.dtype)),
                                 _stream(coords)),
            "pp_corr_lookup"))
+    return out
+
+
+def corr_feature_pyramid(f2):
+    """f2 fp16 NHWC [P,h,w,256] -> [f2, level1, level2, level3]: the avg-pooled FEATURE pyramid whose correlation with
+    f1 equals the avg-pooled correlation pyramid of RAFT/corr.py:21-27 (pooling is linear)."""
+    P, h, w, c = f2.shape
+    assert f2.dtype == torch.float16 and c == 256 and f2.is_contiguous()
+    lv = [torch.empty((P, h >> l, w >> l, 256), dtype=f2.dtype, device=f2.device) for l in (1, 2, 3)]
+    timed("corr_feature_pyramid", 0, _nbytes(f2) * 3 + sum(_nbytes(t) for t in lv),
+          lambda: _check(lib().pp_corr_feature_pyramid(_p(f2), _p(lv[0]), _p(lv[1]), _p(lv[2]), _i(P), _i(h), _i(w), _stream(f2)),
+                         "pp_corr_feature_pyramid"))
+    return [f2] + lv
+
+
+def corr_lookup_otf(f1, f2_levels, coords, out):
+    """Correlation lookup without the all-pairs volume (fp16): f1 [P,h,w,256], f2_levels from corr_feature_pyramid,
+    coords fp32 [P,h,w,2]; writes out NHWC [P,h,w,328] (channels l*81 + a*9 + b as pp_corr_lookup, 324.. zero)."""
+    P, h, w, _ = coords.shape
+    assert coords.dtype == torch.float32 and coords.is_contiguous() and out.is_contiguous() and out.dtype == torch.float16
+    assert f1.dtype == torch.float16 and f1.is_contiguous() and f1.shape == (P, h, w, 256) and all(t.is_contiguous() for t in f2_levels)
+    npix = P * h * w
+    timed("corr_lookup_otf", 2.0 * 256 * 400 * npix, _nbytes(f1) + sum(_nbytes(t) for t in f2_levels) + _nbytes(coords) + _nbytes(out),
+          lambda: _check(lib().pp_corr_lookup_otf(_p(f1), _p(f2_levels[0]), _p(f2_levels[1]), _p(f2_levels[2]), _p(f2_levels[3]),
+                                                  _p(coords), _p(out), _i(out.shape[-1]), _i(out.shape[-1]), _i(P), _i(h), _i(w),
+                                                  _stream(f1)), "pp_corr_lookup_otf"))
     return out
 
 

@@ -63,6 +63,7 @@ class _RaftEngine:
 
     def __init__(self, sd, dtype, device, split3=False):
         self.dtype, self.device, self.split3 = dtype, device, split3
+        self.corr_otf = dtype == torch.float16       # on-the-fly correlation (fp16 MFMA); fp32 modes keep the exact volume
         mk = lambda w, b, **kw: ConvLayer(w, b, dtype=dtype, device=device, split3=split3, **kw)
 
         def enc(prefix, bn):
@@ -94,13 +95,22 @@ class _RaftEngine:
         self.convf1 = mk(*g("encoder.convf1"), padding=3, src_channels=[2])
         self.convf2 = mk(*g("encoder.convf2"), padding=1)
         self.convm = mk(*g("encoder.conv"), padding=1, src_channels=[192, 64])
+        # SepConvGRU (RAFT/update.py:45-60).  Every gate convolution reads cat[h, x], x = cat[inp, motion, flow]; inp (the
+        # context features) does not change over the iterations, so its share of each convolution (1/3 of the K range) is
+        # computed ONCE per pair (`*_pre`, bias included) and enters the per-iteration convolution over [h | motion, flow]
+        # as a pre-activation addend.  The gate arithmetic (r * h, (1 - z) * h + z * q) runs in the epilogues.
         self.gru = []
         for s, pad in (("1", (0, 2)), ("2", (2, 0))):
             wz, bz = g("gru.convz" + s)
             wr, br = g("gru.convr" + s)
-            zr = mk(torch.cat([wz, wr], 0), torch.cat([bz, br], 0), padding=pad, src_channels=[128, 256])
-            q = mk(*g("gru.convq" + s), padding=pad, src_channels=[128, 256])
-            self.gru.append((zr, q))
+            wq, bq = g("gru.convq" + s)
+            wzr, bzr = torch.cat([wz, wr], 0), torch.cat([bz, br], 0)
+            it = lambda w: torch.cat([w[:, :128], w[:, 256:]], 1)
+            self.gru.append(dict(
+                zr_pre=mk(wzr[:, 128:256], bzr, padding=pad, src_channels=[128]),
+                q_pre=mk(wq[:, 128:256], bq, padding=pad, src_channels=[128]),
+                zr=mk(it(wzr), None, padding=pad, src_channels=[128, 128]),
+                q=mk(it(wq), None, padding=pad, src_channels=[128, 128])))
         self.fh1 = mk(*g("flow_head.conv1"), padding=1)
         self.fh2 = mk(*g("flow_head.conv2"), padding=1)
         self.mask0 = mk(*g("mask.0"), padding=1)
@@ -134,38 +144,46 @@ class _RaftEngine:
         P, h, w, _ = f1.shape
         dev, dt = f1.device, self.dtype
         n8 = h * w
-        # all-pairs correlation volume + pyramid (RAFT/corr.py:13-27,52-60), fp32
-        vol = batched_gemm_nt(f1.view(P, n8, 256), f2.view(P, n8, 256), out_scale=1.0 / 16.0, split3=self.split3)
-        levels = [vol.view(P * n8, h, w)]
-        hh, ww = h, w
-        for _ in range(3):
-            levels.append(hip.corr_avgpool(levels[-1], P * n8, hh, ww))
-            hh, ww = hh // 2, ww // 2
+        if self.corr_otf:
+            # fp16 engine: no all-pairs volume.  avg_pool(f1 . f2) = f1 . avg_pool(f2), so f2 is pooled once per pair and
+            # every iteration computes exactly the dot products its 9x9x4 windows touch (csrc/raft_corr_otf.hip)
+            f2_levels = hip.corr_feature_pyramid(f2)
+            lookup = lambda coords, out: hip.corr_lookup_otf(f1, f2_levels, coords, out)
+        else:
+            # all-pairs correlation volume + pyramid (RAFT/corr.py:13-27,52-60), fp32
+            vol = batched_gemm_nt(f1.view(P, n8, 256), f2.view(P, n8, 256), out_scale=1.0 / 16.0, split3=self.split3)
+            levels = [vol.view(P * n8, h, w)]
+            hh, ww = h, w
+            for _ in range(3):
+                levels.append(hip.corr_avgpool(levels[-1], P * n8, hh, ww))
+                hh, ww = hh // 2, ww // 2
+            lookup = lambda coords, out: hip.corr_lookup(levels, coords, out)
         net = torch.tanh(ctx[..., :128]).contiguous()
-        xbuf = torch.empty((P, h, w, 256), dtype=dt, device=dev)           # [inp | motion(126) | flow(2)]
-        xbuf[..., :128] = torch.relu(ctx[..., 128:])
+        inp = torch.relu(ctx[..., 128:]).contiguous()
+        pre = [(G["zr_pre"]([inp]), G["q_pre"]([inp])) for G in self.gru]     # iteration-invariant partial sums
+        xbuf = torch.empty((P, h, w, 128), dtype=dt, device=dev)            # [motion(126) | flow(2)]
         ys, xs = torch.meshgrid(torch.arange(h, device=dev, dtype=torch.float32),
                                 torch.arange(w, device=dev, dtype=torch.float32), indexing="ij")
         coords0 = torch.stack([xs, ys], -1)[None].expand(P, h, w, 2).contiguous()
         coords1 = coords0.clone()
         corr = torch.empty((P, h, w, 328), dtype=dt, device=dev)
         flow8 = torch.zeros((P, h, w, 8), dtype=dt, device=dev)
-        zr = torch.empty((P, h, w, 256), dtype=dt, device=dev)
+        zbuf = torch.empty((P, h, w, 128), dtype=dt, device=dev)
         rh = torch.empty((P, h, w, 128), dtype=dt, device=dev)
         delta = torch.zeros((P, h, w, 8), dtype=torch.float32, device=dev)
         for it in range(iters):
-            hip.corr_lookup(levels, coords1, corr)
+            lookup(coords1, corr)
             flow = coords1 - coords0
             flow8[..., :2] = flow
-            xbuf[..., 254:] = flow
+            xbuf[..., 126:] = flow
             cor = self.convc2([self.convc1([corr], act="relu")], act="relu")
             flo = self.convf2([self.convf1([flow8], act="relu")], act="relu")
-            self.convm([cor, flo], out=xbuf, out_choff=128, act="relu")
-            for zr_l, q_l in self.gru:                                   # SepConvGRU (RAFT/update.py:45-60)
-                zr_l([net, xbuf], out=zr, act="sigmoid")
-                hip.gru_gate(zr, net, 0, 128, rh, 0)
-                q = q_l([rh, xbuf], act="tanh")
-                hip.gru_gate(zr, net, 0, 128, net, 0, q=q)
+            self.convm([cor, flo], out=xbuf, out_choff=0, act="relu")
+            for G, (pzr, pq) in zip(self.gru, pre):
+                G["zr"]([net, xbuf], out=zbuf, act="sigmoid", preadd=pzr,
+                        fuse=dict(kind="gru_zr", h=net, out2=rh, split=128))          # zbuf <- z, rh <- r * h
+                G["q"]([rh, xbuf], out=net, act="tanh", preadd=pq,
+                       fuse=dict(kind="gru_h", h=net, z=zbuf))                       # net <- (1 - z) * h + z * q
             self.fh2([self.fh1([net], act="relu")], out=delta, out_dtype=torch.float32)
             coords1 = coords1 + delta[..., :2]
         mask = self.mask2([self.mask0([net], act="relu")], out_scale=0.25)
@@ -249,7 +267,10 @@ class RAFT_bi(nn.Module):
         cx = torch.cat([c_f, c_b], 0)
         P = f1.shape[0]
         n8 = (h // 8) * (w // 8)
-        chunk = self.max_pairs or max(1, int(40e9 // (n8 * n8 * 4 * 1.34)))      # fp32 pyramid bytes per pair-direction
+        if eng.corr_otf:      # largest activation of the update block: the [P, h8, w8, 328] lookup tile, < 2 GiB (32-bit buffer offsets)
+            chunk = self.max_pairs or max(1, ((1 << 31) - 1) // (n8 * 328 * 2))
+        else:                 # fp32 all-pairs pyramid: 1.34 x n8^2 x 4 bytes per pair-direction, 40 GB per chunk
+            chunk = self.max_pairs or max(1, int(40e9 // (n8 * n8 * 4 * 1.34)))
         ups = [eng.refine(f1[i:i + chunk].contiguous(), f2[i:i + chunk].contiguous(), cx[i:i + chunk].contiguous(), iters)
                for i in range(0, P, chunk)]
         up = torch.cat(ups, 0).to(gt_local_frames.dtype)

@@ -23,7 +23,7 @@ _ACT = {hip.ACT_NONE: lambda v, p: v, hip.ACT_RELU: lambda v, p: F.relu(v), hip.
 
 
 def _conv_call(self, srcs, out=None, out_choff=0, act=None, act_param=0.0, out_scale=1.0, residual=None, res_choff=0,
-               act2=None, out_dtype=None, dcn_offmask=None, out_hw=None):
+               act2=None, out_dtype=None, dcn_offmask=None, out_hw=None, preadd=None, fuse=None):
     srcs = [(s, 0) if torch.is_tensor(s) else s for s in srcs]
     x0 = srcs[0][0]
     N, H, W = x0.shape[:3]
@@ -66,7 +66,24 @@ def _conv_call(self, srcs, out=None, out_choff=0, act=None, act_param=0.0, out_s
         if self.bias is not None:
             y = y + self.bias[g * self.cout_g:(g + 1) * self.cout_g]
         y = y * out_scale
+        win = lambda x: (x, 0) if torch.is_tensor(x) else x
+        if preadd is not None:
+            pt, pc = win(preadd)
+            y = y + pt.float()[..., pc:pc + self.cout_g].reshape(y.shape)
         y = _ACT[pconv.ACTS[act]](y, act_param)
+        if fuse is not None:
+            ht, hc = win(fuse["h"])
+            if fuse["kind"] == "gru_zr":
+                Cs = int(fuse["split"])
+                ot, oc = win(fuse["out2"])
+                hv = ht.float()[..., hc:hc + self.cout_g - Cs]
+                ot.view(N, OH, OW, -1)[..., oc:oc + self.cout_g - Cs] = (y[..., Cs:] * hv.reshape(y[..., Cs:].shape)).to(ot.dtype)
+                out.view(N, OH, OW, -1)[..., out_choff:out_choff + Cs] = y[..., :Cs].to(out.dtype)
+                continue
+            zt, zc = win(fuse["z"])
+            hv = ht.float()[..., hc:hc + self.cout_g].reshape(y.shape)
+            zv = zt.float()[..., zc:zc + self.cout_g].reshape(y.shape)
+            y = (1 - zv) * hv + zv * y
         c0 = out_choff + g * self.cout_g
         if residual is not None:
             y = y + residual.float()[..., res_choff + g * self.cout_g: res_choff + (g + 1) * self.cout_g].reshape(y.shape)
@@ -114,6 +131,30 @@ def _corr_avgpool(x, M, H, W):
 
 def _corr_lookup(levels, coords, out):
     ref = O.corr_lookup([l[:, None] for l in levels], coords.permute(0, 3, 1, 2))
+    out[..., :324] = ref.permute(0, 2, 3, 1).to(out.dtype)
+    out[..., 324:] = 0
+    return out
+
+
+def _corr_feature_pyramid(f2):
+    lv, x = [f2], f2.float().permute(0, 3, 1, 2)
+    P, _, h, w = x.shape
+    for l in (1, 2, 3):
+        s_ = 1 << l
+        y = F.avg_pool2d(x[:, :, :(h >> l) * s_, :(w >> l) * s_], s_, s_)
+        lv.append(y.permute(0, 2, 3, 1).contiguous().to(f2.dtype))
+    return lv
+
+
+def _corr_lookup_otf(f1, f2_levels, coords, out):
+    P, h, w, _ = f1.shape
+    pyr = []
+    a = f1.float().reshape(P, h * w, 256)
+    for f2 in f2_levels:
+        hl, wl = f2.shape[1], f2.shape[2]
+        vol = torch.matmul(a, f2.float().reshape(P, hl * wl, 256).transpose(1, 2)) / 16.0
+        pyr.append(vol.reshape(P * h * w, 1, hl, wl))
+    ref = O.corr_lookup(pyr, coords.permute(0, 3, 1, 2))
     out[..., :324] = ref.permute(0, 2, 3, 1).to(out.dtype)
     out[..., 324:] = 0
     return out
@@ -207,7 +248,8 @@ def emulated_device_ops():
     """Patches propainter_amd.hip / ConvLayer with the CPU emulations for the duration of the block."""
     patches = {
         "flow_warp": _flow_warp, "fb_check": _fb_check, "img_prop_step": _img_prop_step, "corr_avgpool": _corr_avgpool,
-        "corr_lookup": _corr_lookup, "convex_upsample": _convex_upsample, "window_mask": _window_mask,
+        "corr_lookup": _corr_lookup, "corr_feature_pyramid": _corr_feature_pyramid, "corr_lookup_otf": _corr_lookup_otf,
+        "convex_upsample": _convex_upsample, "window_mask": _window_mask,
         "sparse_window_attention": _attention, "fold_tokens": _fold_tokens, "layernorm": _layernorm,
         "depthwise_pool": _depthwise_pool, "instance_norm": _instance_norm, "upsample2x": _upsample2x,
         "dcn_offset_mask_act": _dcn_act, "gru_gate": _gru_gate, "nchw_to_nhwc": _nchw_to_nhwc, "nhwc_to_nchw": _nhwc_to_nchw,

@@ -104,3 +104,23 @@ def test_clip_pipeline_graph(models):
     assert comp.shape == g["comp"].shape
     assert O.psnr(comp, g["comp"]) > 50.0
     assert (comp != g["comp"]).mean() < 0.01
+
+
+def test_raft_fp16_graph_uses_the_on_the_fly_correlation(models):
+    """The fp16 RAFT engine takes the volume-free correlation path (feature pyramid + on-the-fly lookup); under the CPU
+    emulation of the device ops its flow must stay within fp16 end-point error of the real reference's golden."""
+    raft = models[0]
+    g = load_golden("raft_128x192.npz")
+    fr = torch.from_numpy(g["frames_u8"]).permute(0, 3, 1, 2).float().div(255)[None] * 2 - 1
+    with emulated_device_ops():
+        eng = _engine(raft, torch.float16)
+        assert eng.corr_otf and not _engine(raft, torch.float32).corr_otf
+        b, l_t, c, h, w = fr.shape
+        from propainter_amd import hip
+        x = hip.nchw_to_nhwc(fr.reshape(b * l_t, c, h, w), out_dtype=torch.float16, cpad=8)
+        fmap = eng.encode(eng.fnet, x, True)
+        ctx = eng.encode(eng.cnet, x, False)
+        up = eng.refine(torch.cat([fmap[:-1], fmap[1:]]).contiguous(), torch.cat([fmap[1:], fmap[:-1]]).contiguous(),
+                        torch.cat([ctx[:-1], ctx[1:]]).contiguous(), int(g["iters"]))
+    epe = (up[:2].float() - torch.from_numpy(g["flows_f"])).pow(2).sum(1).sqrt()
+    assert epe.mean() < 0.05 and epe.max() < 0.5, (epe.mean(), epe.max())

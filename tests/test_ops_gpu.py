@@ -112,6 +112,80 @@ def test_conv2d(dev, case, dt):
         assert (out[..., case["cout"]:] == 0).all(), "channel padding must stay zero"
 
 
+@pytest.mark.parametrize("mode", ["f16_halo", "f16_v2", "f16_v1", "f32", "f32_split3"])
+@pytest.mark.parametrize("k,pad", [((1, 5), (0, 2)), ((5, 1), (2, 0))], ids=["1x5", "5x1"])
+def test_conv_fused_gru_epilogue(dev, k, pad, mode):
+    """SepConvGRU half step (RAFT/update.py:45-60) as two convolutions with the fused epilogue: the iteration-invariant
+    part of the input enters as a pre-activation addend, z / r*h and (1-z)*h + z*q come out of the epilogues -- against
+    the plain formulation in torch, through every kernel family that can serve the layer."""
+    from propainter_amd.conv import ConvLayer
+    dt = torch.float16 if mode.startswith("f16") else torch.float32
+    g = torch.Generator().manual_seed(55)
+    N, H, W, C = 2, 19, 27, 128
+    h0, inp, mf = (torch.randn(N, C, H, W, generator=g) * 0.7 for _ in range(3))
+    q8 = lambda t: t.to(dt).float()
+    h0, inp, mf = q8(h0), q8(inp), q8(mf)
+    wz, wr, wq = (torch.randn(C, 3 * C, *k, generator=g) / math.sqrt(3 * C * 5) for _ in range(3))
+    bz, br, bq = (torch.randn(C, generator=g) * 0.1 for _ in range(3))
+    hx = torch.cat([h0, inp, mf], 1)
+    z = torch.sigmoid(F.conv2d(hx, wz, bz, 1, pad))
+    r = torch.sigmoid(F.conv2d(hx, wr, br, 1, pad))
+    qv = torch.tanh(F.conv2d(torch.cat([r * h0, inp, mf], 1), wq, bq, 1, pad))
+    href = (1 - z) * h0 + z * qv
+    mk = lambda w, b, sc: ConvLayer(w, b, padding=pad, src_channels=sc, dtype=dt, device=dev, split3=(mode == "f32_split3"))
+    wzr, bzr = torch.cat([wz, wr], 0), torch.cat([bz, br], 0)
+    it = lambda w: torch.cat([w[:, :C], w[:, 2 * C:]], 1)
+    zr_pre, q_pre = mk(wzr[:, C:2 * C], bzr, [C]), mk(wq[:, C:2 * C], bq, [C])
+    zr_it, q_it = mk(it(wzr), None, [C, C]), mk(it(wq), None, [C, C])
+    impl = {"f16_halo": 70, "f16_v2": 12, "f16_v1": 1}.get(mode, 0)
+    zr_it.impl = q_it.impl = impl
+    hd, inpd, mfd = nhwc(h0, dt), nhwc(inp, dt), nhwc(mf, dt)
+    pzr, pq = zr_pre([inpd]), q_pre([inpd])
+    zbuf = torch.full((N, H, W, C + 8), 5.0, dtype=dt, device=dev)
+    rh = torch.empty((N, H, W, C), dtype=dt, device=dev)
+    net = hd.clone()
+    zr_it([net, mfd], out=zbuf, out_choff=8, act="sigmoid", preadd=pzr, fuse=dict(kind="gru_zr", h=net, out2=rh, split=C))
+    q_it([rh, mfd], out=net, act="tanh", preadd=pq, fuse=dict(kind="gru_h", h=net, z=(zbuf, 8)))
+    torch.cuda.synchronize()
+    t = tol(dt, 2.0)
+    assert (zbuf[..., :8] == 5).all()
+    check("z", zbuf[..., 8:].permute(0, 3, 1, 2), z, t)
+    check("r*h", rh.permute(0, 3, 1, 2), r * h0, t)
+    check("h_new", net.permute(0, 3, 1, 2), href, t)
+
+
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c["name"] in ("3x3", "7x7s2_c3", "1x1_c324", "two_src", "1x5", "cout2_f32out", "residual_relu2")],
+                         ids=lambda c: c["name"])
+def test_conv2d_split3_is_fp32_class(dev, case):
+    """fp32 tensors with every product as three fp16 MFMAs (hi*hi + hi*lo + lo*hi, pp_conv_args_t.impl 3): the error
+    against an fp64 reference must be fp32-class (1e-5 of the range; the exact fp32 kernel measures ~2e-6, the fp16
+    engine ~1e-3)."""
+    from propainter_amd.conv import ConvLayer
+    g = torch.Generator().manual_seed(300 + [c["name"] for c in CONV_CASES].index(case["name"]))
+    cin, (kh, kw) = case["cin"], case["k"]
+    N, H, W = 2, 19, 23
+    w = torch.randn(case["cout"], sum(cin), kh, kw, generator=g) / math.sqrt(sum(cin) * kh * kw)
+    b = torch.randn(case["cout"], generator=g) * 0.1
+    srcs_nchw = [torch.randn(N, c, H, W, generator=g) * 3 for c in cin]
+    ref = F.conv2d(torch.cat(srcs_nchw, 1).double(), w.double(), b.double(), case["stride"], case["pad"])
+    act = case.get("act")
+    if act == "relu": ref = F.relu(ref)
+    elif act == "sigmoid": ref = torch.sigmoid(ref)
+    res = None
+    if case.get("residual"):
+        res = torch.randn(ref.shape, generator=g)
+        ref = F.relu(ref + res.double()) if case.get("act2") == "relu" else ref + res.double()
+    errs = {}
+    for split3 in (True, False):
+        layer = ConvLayer(w, b, stride=case["stride"], padding=case["pad"], src_channels=cin, dtype=torch.float32, device=dev,
+                          split3=split3)
+        out = layer([nhwc(s_, torch.float32) for s_ in srcs_nchw], act=act, residual=None if res is None else nhwc(res, torch.float32),
+                    act2=case.get("act2"))
+        torch.cuda.synchronize()
+        errs[split3] = ((out[..., :case["cout"]].permute(0, 3, 1, 2).double().cpu() - ref).abs().max() / ref.abs().max()).item()
+    assert errs[True] < 1e-5, f"split3 relative error {errs[True]:.2e} (exact fp32 kernel {errs[False]:.2e})"
+
+
 @pytest.mark.parametrize("k,pad", [((3, 3), 1), ((1, 5), (0, 2)), ((5, 1), (2, 0))], ids=["3x3", "1x5", "5x1"])
 def test_conv_kernel_families_are_bit_identical(dev, k, pad):
     """The register-staged kernel (impl 1), the LDS-DMA kernel (impl 12) and the halo-tile kernel (impl 70) walk K in the
@@ -295,6 +369,51 @@ def test_corr_pyramid_and_lookup(dev, dt):
     torch.cuda.synchronize()
     check("lookup", out[..., :324].permute(0, 3, 1, 2), ref, 3e-4 if dt == torch.float32 else 5e-3)
     assert (out[..., 324:] == 0).all()
+
+
+@pytest.mark.parametrize("case", ["smooth", "ragged_oob", "divergent", "chaotic"])
+def test_corr_lookup_on_the_fly_matches_the_volume_pyramid(dev, case):
+    """pp_corr_feature_pyramid + pp_corr_lookup_otf (no all-pairs volume) against the oracle's volume -> avg-pool
+    pyramid -> bilinear lookup on the same fp16-rounded features.  Cases: a smooth flow (one shared box per 8x8 tile),
+    a map with ragged tiles + coordinates far outside the map / on exact integers, a flow that diverges inside tiles
+    (quadrant fallback) and per-pixel random targets (single-pixel fallback)."""
+    from propainter_amd import hip
+    g = torch.Generator().manual_seed({"smooth": 1, "ragged_oob": 2, "divergent": 3, "chaotic": 4}[case])
+    P, h, w = (2, 24, 40) if case != "ragged_oob" else (2, 19, 29)
+    f1, f2 = torch.randn(P, 256, h, w, generator=g), torch.randn(P, 256, h, w, generator=g)
+    f1q, f2q = f1.half().float(), f2.half().float()
+    base = O.coords_grid(P, h, w)
+    if case == "smooth":
+        coords = base + torch.tensor([1.7, -2.3]).view(1, 2, 1, 1) + 0.3 * torch.randn(P, 2, h, w, generator=g)
+    elif case == "ragged_oob":
+        coords = base + torch.randn(P, 2, h, w, generator=g) * 1.5
+        coords[0, :, 0, 0] = torch.tensor([-30.3, 2.2]); coords[0, :, 0, 1] = torch.tensor([300.0, 20.5])
+        coords[0, :, 1, :] = base[0, :, 1, :] + 3.0                      # exact integers: 1-ulp round-trip effects
+        coords[1, :, 5, 5] = torch.tensor([-4.0, -4.0]); coords[1, :, 6, 6] = torch.tensor([w + 3.5, h + 3.5])
+        coords[1, :, 7, 7] = torch.tensor([-5.5, 3.0])
+    elif case == "divergent":
+        coords = base * 1.6 - 4.0 + torch.randn(P, 2, h, w, generator=g)
+    else:
+        coords = torch.rand(P, 2, h, w, generator=g) * torch.tensor([w * 1.2, h * 1.2]).view(1, 2, 1, 1) - 2.0
+    ref = O.corr_lookup(O.corr_pyramid(f1q, f2q), coords)
+    f1d, f2d = nhwc(f1, torch.float16), nhwc(f2, torch.float16)
+    lv = hip.corr_feature_pyramid(f2d)
+    assert [tuple(t.shape) for t in lv] == [(P, h >> l, w >> l, 256) for l in range(4)]
+    pooled = F.avg_pool2d(f2q[:, :, :(h >> 2) * 4, :(w >> 2) * 4], 4, 4)
+    check("f2_level2", lv[2].permute(0, 3, 1, 2), pooled, 2e-3)
+    out = torch.full((P, h, w, 328), 7.0, dtype=torch.float16, device=dev)
+    hip.corr_lookup_otf(f1d, lv, coords.permute(0, 2, 3, 1).contiguous().to(dev), out)
+    again = torch.empty_like(out)
+    hip.corr_lookup_otf(f1d, lv, coords.permute(0, 2, 3, 1).contiguous().to(dev), again)
+    torch.cuda.synchronize()
+    check("lookup_otf", out[..., :324].permute(0, 3, 1, 2), ref, 5e-3)
+    assert (out[..., 324:] == 0).all()
+    assert torch.equal(out, again), "the on-the-fly lookup is not run-to-run deterministic"
+    # batch invariance: pair 1 alone gives the same bytes as inside the batch of 2
+    solo = torch.empty((1, h, w, 328), dtype=torch.float16, device=dev)
+    hip.corr_lookup_otf(f1d[1:].contiguous(), [t[1:].contiguous() for t in lv], coords[1:].permute(0, 2, 3, 1).contiguous().to(dev), solo)
+    torch.cuda.synchronize()
+    assert torch.equal(solo[0], out[1])
 
 
 @pytest.mark.parametrize("dt", DTYPES, ids=["f32", "f16"])
