@@ -37,7 +37,7 @@ struct CorrOtfParams {
 
 constexpr int OTF_VTOT = 28928;                    // floats of V storage (113 KB): 64 x 452, 16 x 1808, 1 x 28928
 constexpr int OTF_OROW = 328;                      // staging row (fp16 elements)
-constexpr int OTF_LDS = OTF_VTOT * 4 + 64 * OTF_OROW * 2 + 64 * 8 + 64;
+constexpr int OTF_LDS = OTF_VTOT * 4 + 64 * OTF_OROW * 2 + 64 * 8 + 5 * 16;
 
 __device__ __forceinline__ int wave_min(int v) {
 #pragma unroll
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(512) void corr_otf_kernel(const CorrOtfParams p) {
   float* const V = reinterpret_cast<float*>(lds);
   _Float16* const stage = reinterpret_cast<_Float16*>(lds + OTF_VTOT * 4);
   float* const cxy = reinterpret_cast<float*>(lds + OTF_VTOT * 4 + 64 * OTF_OROW * 2);     // [64][2]; x = NaN marks a pixel outside the image
-  int* const box = reinterpret_cast<int*>(lds + OTF_VTOT * 4 + 64 * OTF_OROW * 2 + 64 * 8);   // bx0, by0, bw, bh
+  int* const boxes = reinterpret_cast<int*>(lds + OTF_VTOT * 4 + 64 * OTF_OROW * 2 + 64 * 8);   // [5][4] = {bx0, by0, bw, bh}: levels 0..3 of the whole tile, [4] = scratch
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -79,6 +79,29 @@ __global__ __launch_bounds__(512) void corr_otf_kernel(const CorrOtfParams p) {
     y = ty0 + (q >> 5) * 4 + ((q >> 2) & 3);
   };
 
+  // Bounding box (level coordinates, clipped to the map) of the windows [floor(c) - 4, floor(c) + 5] of the pixels
+  // [p0, p0 + np) -> dst[0..3]; executed by ONE whole wave.
+  auto wave_box = [&](int lvl, int p0, int np, int* dst) {
+    const int Hl = p.h >> lvl, Wl = p.w >> lvl;
+    const float lscale = 1.f / (float)(1 << lvl);
+    int x0 = 1 << 30, x1 = -(1 << 30), y0 = 1 << 30, y1 = -(1 << 30);
+    if (lane < np) {
+      const float cx = cxy[(p0 + lane) * 2], cy = cxy[(p0 + lane) * 2 + 1];
+      if (cx == cx) {
+        const int fx = (int)floorf(cx * lscale), fy = (int)floorf(cy * lscale);
+        x0 = max(fx - 4, 0); x1 = min(fx + 5, Wl - 1);
+        y0 = max(fy - 4, 0); y1 = min(fy + 5, Hl - 1);
+        if (x1 < x0 || y1 < y0) { x0 = y0 = 1 << 30; x1 = y1 = -(1 << 30); }     // window entirely outside the map
+      }
+    }
+    x0 = wave_min(x0); y0 = wave_min(y0); x1 = wave_max(x1); y1 = wave_max(y1);
+    if (lane == 0) {
+      dst[0] = x0; dst[1] = y0;
+      dst[2] = x1 >= x0 ? x1 - x0 + 1 : 0;
+      dst[3] = y1 >= y0 ? y1 - y0 + 1 : 0;
+    }
+  };
+
   if (tid < 64) {
     int x, y;
     tile_xy(tid, x, y);
@@ -91,76 +114,69 @@ __global__ __launch_bounds__(512) void corr_otf_kernel(const CorrOtfParams p) {
     cxy[tid * 2] = cx;
     cxy[tid * 2 + 1] = cy;
   }
-
-  // ---- A fragments: the 64 pixels x 256 channels of f1, resident for the whole block (4 M tiles x 8 k steps)
-  f16x8 afrag[4][8];
+  // ---- f1 tile (64 pixels x 512 B) once per block through LDS (aliases V; 16-byte chunk j of pixel q at chunk j ^ (q & 31))
   {
     const __amdgpu_buffer_rsrc_t r1 = uniform_buffer_rsrc(p.f1 + (long long)n * p.h * p.w * 512, p.h * p.w * 512);
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
+    for (int i = 0; i < 4; ++i) {
+      const int id = tid + 512 * i, q = id >> 5, j = id & 31;
       int x, y;
-      tile_xy(mt * 16 + l15, x, y);
-      const int voff = (x < p.w && y < p.h) ? (y * p.w + x) * 512 + l4 * 16 : (int)0x80000000;   // out of range -> zeros
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(r1, voff, ks * 64, 0);
-        afrag[mt][ks] = __builtin_bit_cast(f16x8, raw);
-      }
+      tile_xy(q, x, y);
+      const int voff = (x < p.w && y < p.h) ? (y * p.w + x) * 512 + j * 16 : (int)0x80000000;     // out of range -> zeros
+      const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(r1, voff, 0, 0);
+      *reinterpret_cast<u32x4*>(lds + q * 512 + ((j ^ (q & 31)) << 4)) = raw;
     }
   }
   __syncthreads();
+  if (wave < 4) wave_box(wave, 0, 64, boxes + wave * 4);
+  // ---- A fragments: resident in registers for the whole block (4 M tiles x 8 k steps)
+  f16x8 afrag[4][8];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int q = mt * 16 + l15;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+      afrag[mt][ks] = *reinterpret_cast<const f16x8*>(lds + q * 512 + (((ks * 4 + l4) ^ (q & 31)) << 4));
+  }
+  __syncthreads();             // the f1 tile is consumed (V may be written), boxes[] are visible
+
+  // B fragments of N tile nt of a box: 16 positions x 256 channels straight from L2 (64-byte sectors used in full)
+  auto load_b = [&](const __amdgpu_buffer_rsrc_t r2, int Wl, int bx0, int by0, int bw, int area, int nt, u32x4 (&b)[8]) {
+    const int pos = nt * 16 + l15;
+    const int ry = pos / bw, rx = pos - ry * bw;
+    const int voff = pos < area ? ((by0 + ry) * Wl + bx0 + rx) * 512 + l4 * 16 : (int)0x80000000;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) b[ks] = __builtin_amdgcn_raw_buffer_load_b128(r2, voff, ks * 64, 0);
+  };
+  auto level_rsrc = [&](int lvl) {
+    const int Hl = p.h >> lvl, Wl = p.w >> lvl;
+    return uniform_buffer_rsrc(p.f2[lvl] + (long long)n * Hl * Wl * 512, Hl * Wl * 512);
+  };
+
+  u32x4 bcur[8], bnxt[8];
+  bool prefetched = false;       // bcur already holds this wave's first N tile of the level (issued before the previous blend)
 
   for (int lvl = 0; lvl < 4; ++lvl) {
     const int Hl = p.h >> lvl, Wl = p.w >> lvl;
     const float lscale = 1.f / (float)(1 << lvl);
-    const __amdgpu_buffer_rsrc_t r2 = uniform_buffer_rsrc(p.f2[lvl] + (long long)n * Hl * Wl * 512, Hl * Wl * 512);
+    const __amdgpu_buffer_rsrc_t r2 = level_rsrc(lvl);
 
-    // Processes the pixel set [p0, p0 + np), np in {64, 16, 1}.  Returns false (nothing done) when the set's box does
-    // not fit the V capacity of that set size.  Block-uniform control flow throughout.
-    auto process = [&](const int p0, const int np) -> bool {
-      // -- 1. bounding box of the windows [floor(c) - 4, floor(c) + 5] of the set, clipped to the map (wave 0)
-      if (wave == 0) {
-        int x0 = 1 << 30, x1 = -(1 << 30), y0 = 1 << 30, y1 = -(1 << 30);
-        if (lane < np) {
-          const float cx = cxy[(p0 + lane) * 2], cy = cxy[(p0 + lane) * 2 + 1];
-          if (cx == cx) {
-            const int fx = (int)floorf(cx * lscale), fy = (int)floorf(cy * lscale);
-            x0 = max(fx - 4, 0); x1 = min(fx + 5, Wl - 1);
-            y0 = max(fy - 4, 0); y1 = min(fy + 5, Hl - 1);
-            if (x1 < x0 || y1 < y0) { x0 = y0 = 1 << 30; x1 = y1 = -(1 << 30); }     // window entirely outside the map
-          }
-        }
-        x0 = wave_min(x0); y0 = wave_min(y0); x1 = wave_max(x1); y1 = wave_max(y1);
-        if (lane == 0) {
-          box[0] = x0; box[1] = y0;
-          box[2] = x1 >= x0 ? x1 - x0 + 1 : 0;
-          box[3] = y1 >= y0 ? y1 - y0 + 1 : 0;
-        }
-      }
-      __syncthreads();
-      const int bx0 = box[0], by0 = box[1], bw = box[2], bh = box[3];
+    // Processes the pixel set [p0, p0 + np), np in {64, 16, 1}, whose box is bx[0..3].  Returns false (nothing done) when
+    // the box does not fit the V capacity of that set size.  Block-uniform control flow throughout.
+    auto process = [&](const int p0, const int np, const int* bx) -> bool {
+      const int bx0 = bx[0], by0 = bx[1], bw = bx[2], bh = bx[3];
       const int area = bw * bh;
       const int vstride = OTF_VTOT / np;       // floats per pixel row of V: 452 (= 4 mod 32: conflict-free tile stores) / 1808 / 28928
       const int ntiles = (area + 15) >> 4;       // N tiles of 16 positions; whole tiles are stored, so they must fit the row
-      if (ntiles * 16 > vstride) {
-        __syncthreads();            // box[] is rewritten by the next call
-        return false;
-      }
+      if (ntiles * 16 > vstride) return false;
       const int mt0 = p0 >> 4;       // first M tile of the set
       const bool one_tile = np <= 16;
-      // -- 2. S = B x A^T over the box, N tiles of 16 positions round-robin over the 8 waves
-      auto load_b = [&](int nt, u32x4 (&b)[8]) {
-        const int pos = nt * 16 + l15;
-        const int ry = pos / bw, rx = pos - ry * bw;
-        const int voff = pos < area ? ((by0 + ry) * Wl + bx0 + rx) * 512 + l4 * 16 : (int)0x80000000;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) b[ks] = __builtin_amdgcn_raw_buffer_load_b128(r2, voff, ks * 64, 0);
-      };
-      u32x4 bcur[8], bnxt[8];
-      if (wave < ntiles) load_b(wave, bcur);
+      // -- S = B x A^T over the box, N tiles of 16 positions round-robin over the 8 waves
+      if (!prefetched && wave < ntiles) load_b(r2, Wl, bx0, by0, bw, area, wave, bcur);
+      prefetched = false;
       for (int nt = wave; nt < ntiles; nt += 8) {
         const bool more = nt + 8 < ntiles;
-        if (more) load_b(nt + 8, bnxt);
+        if (more) load_b(r2, Wl, bx0, by0, bw, area, nt + 8, bnxt);
         f32x4 acc[4];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -184,40 +200,63 @@ __global__ __launch_bounds__(512) void corr_otf_kernel(const CorrOtfParams p) {
           for (int ks = 0; ks < 8; ++ks) bcur[ks] = bnxt[ks];
         }
       }
+      // -- the first N tile of the NEXT level's whole-tile box is requested now: its L2 latency hides behind the blend
+      if (np == 64 && lvl < 3) {
+        const int* nb = boxes + (lvl + 1) * 4;
+        const int narea = nb[2] * nb[3], nnt = (narea + 15) >> 4;
+        if (nnt * 16 <= OTF_VTOT / 64) {
+          if (wave < nnt) load_b(level_rsrc(lvl + 1), p.w >> (lvl + 1), nb[0], nb[1], nb[2], narea, wave, bcur);
+          prefetched = true;
+        }
+      }
       __syncthreads();
-      // -- 3. bilinear blend of the 81 taps (a moves x, b moves y; RAFT/corr.py:36-43)
-      for (int o = tid; o < np * 81; o += 512) {
-        const int q = o / 81, i = o - q * 81;
+      // -- bilinear blend (RAFT/corr.py:36-43: tap a moves x, tap b moves y; zeros outside the map).  One work item =
+      //    (pixel, a): the 10 x 2 neighbourhood columns (c, c + 1) are read once, lerped along x, then along y for the 9
+      //    taps b.  All taps of a pixel share the fractional offsets (tap = centre + integer).
+      for (int item = tid; item < np * 9; item += 512) {
+        const int q = item / 9, a = item - q * 9;
         const float cx0 = cxy[(p0 + q) * 2];
         if (!(cx0 == cx0)) continue;
         const float cx = cx0 * lscale, cy = cxy[(p0 + q) * 2 + 1] * lscale;
-        const int a = i / 9, b = i - a * 9;
-        const float px = grid_roundtrip(cx + (float)(a - 4), Wl);
-        const float py = grid_roundtrip(cy + (float)(b - 4), Hl);
-        const float fx = floorf(px), fy = floorf(py);
-        const float lx = px - fx, ly = py - fy;
-        const int c0 = (int)fx - bx0, r0 = (int)fy - by0;
+        const float fx0 = floorf(cx), fy0 = floorf(cy);
+        const float lx = cx - fx0, ly = cy - fy0;
+        const int c = (int)fx0 - 4 + a - bx0, r0 = (int)fy0 - 4 - by0;
+        const bool okc0 = (unsigned)c < (unsigned)bw, okc1 = (unsigned)(c + 1) < (unsigned)bw;
         const float* vrow = V + q * vstride;
-        float v = 0.f;
+        float hx[10];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int rr = r0 + (k >> 1), cc = c0 + (k & 1);
-          const float wgt = ((k & 1) ? lx : 1.f - lx) * ((k >> 1) ? ly : 1.f - ly);
-          float s = 0.f;
-          if (rr >= 0 && rr < bh && cc >= 0 && cc < bw) s = vrow[rr * bw + cc];
-          v += wgt * s;
+        for (int j = 0; j < 10; ++j) {
+          const int rr = r0 + j;
+          const bool okr = (unsigned)rr < (unsigned)bh;
+          const int i0 = (okr && okc0) ? rr * bw + c : 0, i1 = (okr && okc1) ? rr * bw + c + 1 : 0;   // always-valid addresses
+          float v0 = vrow[i0], v1 = vrow[i1];
+          v0 = (okr && okc0) ? v0 : 0.f;
+          v1 = (okr && okc1) ? v1 : 0.f;
+          hx[j] = (1.f - lx) * v0 + lx * v1;
         }
-        stage[(p0 + q) * OTF_OROW + lvl * 81 + i] = (_Float16)(v * p.scale);
+        _Float16* so = stage + (p0 + q) * OTF_OROW + lvl * 81 + a * 9;
+#pragma unroll
+        for (int b = 0; b < 9; ++b) so[b] = (_Float16)(((1.f - ly) * hx[b] + ly * hx[b + 1]) * p.scale);
       }
-      __syncthreads();              // V and box[] are reused
+      __syncthreads();              // V is reused
       return true;
     };
 
-    if (!process(0, 64)) {
+    if (!process(0, 64, boxes + lvl * 4)) {
+      prefetched = false;
       for (int g = 0; g < 4; ++g) {
-        if (!process(g * 16, 16)) {
-          for (int q = 0; q < 16; ++q) process(g * 16 + q, 1);       // a single window (<= 100 positions) always fits
+        if (wave == 0) wave_box(lvl, g * 16, 16, boxes + 16);
+        __syncthreads();
+        const bool ok = process(g * 16, 16, boxes + 16);
+        if (!ok) {
+          for (int q = 0; q < 16; ++q) {                       // a single window (<= 100 positions) always fits
+            __syncthreads();
+            if (wave == 0) wave_box(lvl, g * 16 + q, 1, boxes + 16);
+            __syncthreads();
+            process(g * 16 + q, 1, boxes + 16);
+          }
         }
+        __syncthreads();            // boxes[4] is rewritten by the next quadrant
       }
     }
   }
