@@ -146,6 +146,15 @@ typedef struct {
 int pp_conv_build_ktable(int ntaps, const int32_t* dy, const int32_t* dx, int nsrc,
                          const int32_t* src_channels, int dcn_groups, int32_t* out, int out_capacity);
 
+/* Host helper: pack a reference-layout weight [cout, cin_g, kh, kw] (fp32, host; cin_g = sum of src_channels, the REAL
+ * channel counts per group in source order; nn.Linear = kh = kw = 1) into the [groups][cout_pad][kchunks*8] layout
+ * pp_conv2d reads, following `ktable` (host copy of the table pp_conv_build_ktable wrote for the same taps / padded
+ * source widths; tap ids index the kh x kw window row-major).  Padded channels / rows are zero.  dtype = element type of
+ * `out` (host).  Returns cout_pad (rows per group) or a negative error; call with out == NULL to size
+ * (groups * cout_pad * kchunks * 8 elements). */
+int pp_conv_pack_weight(const float* weight, int cout, int kh, int kw, int nsrc, const int32_t* src_channels, int groups,
+                        const int32_t* ktable, int kchunks, int dtype, void* out, int64_t out_elems);
+
 int pp_conv2d(const pp_conv_args_t* args, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -16,22 +16,34 @@ namespace pp {
 // RowMap: prow (0..WM-1, pixel row of the wave tile) -> flat output pixel index, or -1 when the row is outside the image.
 // TNT / A0: the accumulator array may be wider than the WN couts handled by this call (128-cout wave tiles are drained in
 // two calls of 64): tiles A0 .. A0 + WN/16 - 1 of acc[TNT][TM] are used.
-template <int WM, int WN, int TNT = WN / 16, int A0 = 0, typename RowMap>
+// PREFETCH: issue the global reads of phase 2 for all passes at once (needs 3 x 4 x NP free VGPRs after the staging; the
+// A-stationary kernel, which sits at the register cap, turns it off and loads inside the passes).
+template <int WM, int WN, int TNT = WN / 16, int A0 = 0, bool PREFETCH = true, bool ALLOW_LATE = true, typename RowMap>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc_)[TNT][WM / 16], char* wave_lds, int lane,
                                               int co_wave /* first cout of the wave tile within the group */, int g,
-                                              char* outp, const RowMap rowmap, const f32x4* bias_pre = nullptr) {
+                                              char* outp, const RowMap rowmap, const f32x4* bias_pre = nullptr,
+                                              const bool preadd_done = false /* the caller already folded preadd into the accumulators (measured slower in the halo kernel: 8-byte accumulator-layout reads; kept for callers that have the addend in registers) */) {
   constexpr int TM = WM / 16, TN = WN / 16;
   typedef _Float16 T;
   const int l15 = lane & 15, l4 = lane >> 4;
   const bool has_res = p.residual != nullptr;
   // "late" path (partial-sum pre-add and / or fused GRU gating): phase 1 only adds the bias, the activation and the gate
   // arithmetic run in phase 2 on 8 consecutive couts per lane, where preadd / h / z are read with 16-byte loads
-  const bool late = p.preadd != nullptr || p.fuse != PP_FUSE_NONE;
+  const bool pre_late = ALLOW_LATE && p.preadd != nullptr && !preadd_done;     // the addend still has to be read (before the activation)
+  const bool late = ALLOW_LATE && (pre_late || p.fuse != PP_FUSE_NONE);       // (ALLOW_LATE false: the caller's dispatch excludes such layers)
   const bool stage16 = p.out_f16 && !has_res && !late;
+  constexpr int LPR = WN / 8;                       // lanes per pixel row (8 couts each)
+  constexpr int RPP = 64 / LPR;                     // pixel rows per pass
+  constexpr int NP = WM / RPP;                      // passes of phase 2
+  const int cl = (lane % LPR) * 8;
+  const int co = co_wave + cl;
+  const int nval = min(8, p.cout_g - co);
+  const int out_cbase = p.out_choff + g * p.out_cgroup;
+  const int res_cbase = p.res_choff + g * p.out_cgroup;
   // ---- phase 1: bias, scale, activation in registers (each lane: 4 consecutive couts of 16 pixel rows per tile)
   {
     const float scale = p.out_scale;
-    const int act = late ? PP_ACT_NONE : p.act;
+    const int act = pre_late ? PP_ACT_NONE : p.act;       // with the addend outstanding the activation moves to phase 2
     const float slope = act == PP_ACT_NONE ? 1.f : (act == PP_ACT_LRELU ? p.act_param : 0.f);
 #pragma unroll
     for (int a = 0; a < TN; ++a) {
@@ -79,12 +91,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc_)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc_[A0 + a][b][r] = fmaxf(acc_[A0 + a][b][r], 0.f);
   }
-  constexpr int LPR = WN / 8;                       // lanes per pixel row (8 couts each)
-  constexpr int RPP = 64 / LPR;                     // pixel rows per pass
-  const int cl = (lane % LPR) * 8;
-  const int co = co_wave + cl;
-  const int nval = min(8, p.cout_g - co);
-  const int out_cbase = p.out_choff + g * p.out_cgroup;
   if (stage16) {
     // ---- fp16 staging: row stride WN*2 + 16 bytes
     constexpr int LD = WN * 2 + 16;
@@ -123,39 +129,78 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc_)
   for (int b = 0; b < TM; ++b)
 #pragma unroll
     for (int a = 0; a < TN; ++a) *reinterpret_cast<f32x4*>(et + (b * 16 + l15) * LDF + a * 16 + l4 * 4) = acc_[A0 + a][b];
-  const int res_cbase = p.res_choff + g * p.out_cgroup;
-  const bool res_vec_ok = ((p.res_cstride | res_cbase) & 7) == 0;
+  // ---- every global READ of phase 2 (pre-activation addend or residual, GRU state h, gate z) is issued here for ALL passes,
+  // back to back, right after the accumulators have been staged (their registers are free now): one exposed memory
+  // latency per wave tile instead of one per pass (measured: the per-pass dependent loads made the fused GRU
+  // convolutions ~2x slower than their K loop alone)
+  const bool pre_vec = pre_late && nval == 8 && ((p.preadd_cstride | p.preadd_choff) & 7) == 0;
+  const bool res_vec = has_res && !late && nval == 8 && ((p.res_cstride | res_cbase) & 7) == 0;
+  const bool zr_r = p.fuse == PP_FUSE_GRU_ZR && co >= p.fuse_split;
+  const bool gh = p.fuse == PP_FUSE_GRU_H;
+  constexpr int NQ = PREFETCH ? NP : 1;
+  u32x4 q0[NQ], q1[NQ], q2[NQ];                     // [preadd | residual], h, z
+  if (PREFETCH && (late || has_res)) {
+#pragma unroll
+    for (int pass = 0; pass < NP; ++pass) {
+      const long long m = rowmap(pass * RPP + lane / LPR);
+      q0[pass] = q1[pass] = q2[pass] = u32x4{0, 0, 0, 0};
+      if (m < 0 || nval <= 0) continue;
+      if (pre_vec) q0[pass] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.preadd) + m * p.preadd_cstride + p.preadd_choff + co);
+      if (res_vec) q0[pass] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.residual) + m * p.res_cstride + res_cbase + co);
+      if (zr_r) q1[pass] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.fuse_a) + m * p.fuse_a_cstride + p.fuse_a_choff + co - p.fuse_split);
+      if (gh) {
+        q1[pass] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.fuse_a) + m * p.fuse_a_cstride + p.fuse_a_choff + co);
+        q2[pass] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.fuse_b) + m * p.fuse_b_cstride + p.fuse_b_choff + co);
+      }
+    }
+  }
   const bool relu2 = p.act2 == PP_ACT_RELU;
-#pragma unroll 2
-  for (int pass = 0; pass < WM / RPP; ++pass) {
+  auto unpack8 = [](const u32x4& raw, float* f) {
+    const _Float16* hh = reinterpret_cast<const _Float16*>(&raw);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) f[r] = (float)hh[r];
+  };
+#pragma unroll
+  for (int pass = 0; pass < NP; ++pass) {
     const int prow = pass * RPP + lane / LPR;
     const long long m = rowmap(prow);
     if (m < 0 || nval <= 0) continue;
+    constexpr bool PF = PREFETCH;
+    const int qi = PF ? pass : 0;
+    if constexpr (!PF) {
+      if (pre_vec) q0[0] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.preadd) + m * p.preadd_cstride + p.preadd_choff + co);
+      if (res_vec) q0[0] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.residual) + m * p.res_cstride + res_cbase + co);
+      if (zr_r) q1[0] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.fuse_a) + m * p.fuse_a_cstride + p.fuse_a_choff + co - p.fuse_split);
+      if (gh) {
+        q1[0] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.fuse_a) + m * p.fuse_a_cstride + p.fuse_a_choff + co);
+        q2[0] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.fuse_b) + m * p.fuse_b_cstride + p.fuse_b_choff + co);
+      }
+    }
     float v[8];
     const f32x4 lo = *reinterpret_cast<const f32x4*>(et + prow * LDF + cl);
     const f32x4 hi = *reinterpret_cast<const f32x4*>(et + prow * LDF + cl + 4);
 #pragma unroll
     for (int r = 0; r < 4; ++r) { v[r] = lo[r]; v[4 + r] = hi[r]; }
     if (late) {
-      if (p.preadd != nullptr) {
+      if (pre_late) {
         float pv[8];
         const T* pp_ = reinterpret_cast<const T*>(p.preadd) + m * p.preadd_cstride + p.preadd_choff + co;
-        if (nval == 8 && ((p.preadd_cstride | p.preadd_choff) & 7) == 0) load8<T>(pp_, pv);
+        if (pre_vec) unpack8(q0[qi], pv);
         else {
 #pragma unroll
           for (int r = 0; r < 8; ++r) pv[r] = r < nval ? to_f32(pp_[r]) : 0.f;
         }
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] += pv[r];
-      }
-      const float slope2 = p.act == PP_ACT_NONE ? 1.f : (p.act == PP_ACT_LRELU ? p.act_param : 0.f);
+        const float slope2 = p.act == PP_ACT_NONE ? 1.f : (p.act == PP_ACT_LRELU ? p.act_param : 0.f);
 #pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] = act_late(v[r], p.act, slope2);
+        for (int r = 0; r < 8; ++r) v[r] = act_late(v[r], p.act, slope2);
+      }
       if (p.fuse == PP_FUSE_GRU_ZR) {
         if (co >= p.fuse_split) {                       // r half: r * h -> out2 (8-cout chunks never straddle the split)
           const int cr = co - p.fuse_split;
           float hv[8];
-          load8<T>(reinterpret_cast<const T*>(p.fuse_a) + m * p.fuse_a_cstride + p.fuse_a_choff + cr, hv);
+          unpack8(q1[qi], hv);
 #pragma unroll
           for (int r = 0; r < 8; ++r) v[r] *= hv[r];
           store8<T>(reinterpret_cast<T*>(p.out2) + m * p.out2_cstride + p.out2_choff + cr, v);
@@ -163,8 +208,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc_)
         }
       } else if (p.fuse == PP_FUSE_GRU_H) {
         float hv[8], zv[8];
-        load8<T>(reinterpret_cast<const T*>(p.fuse_a) + m * p.fuse_a_cstride + p.fuse_a_choff + co, hv);
-        load8<T>(reinterpret_cast<const T*>(p.fuse_b) + m * p.fuse_b_cstride + p.fuse_b_choff + co, zv);
+        unpack8(q1[qi], hv);
+        unpack8(q2[qi], zv);
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = (1.f - zv[r]) * hv[r] + zv[r] * v[r];
       }
@@ -175,9 +220,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc_)
     }
     if (has_res) {
       const T* rp = reinterpret_cast<const T*>(p.residual) + m * p.res_cstride + res_cbase + co;
-      if (nval == 8 && res_vec_ok) {
+      if (res_vec) {
         float rv[8];
-        load8<T>(rp, rv);
+        unpack8(q0[qi], rv);
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] += rv[r];
       } else {

@@ -525,8 +525,8 @@ extern "C" int pp_conv2d(const pp_conv_args_t* a, void* stream) {
     if (a->fuse != PP_FUSE_NONE) {
       PP_REQUIRE(a->fuse_a != nullptr && ((uintptr_t)a->fuse_a % 16) == 0 && ((a->fuse_a_cstride | a->fuse_a_choff) & 7) == 0,
                  PP_ERR_ALIGN, "pp_conv2d: fuse_a must be set, 16-byte aligned, cstride / choff multiples of 8");
-      PP_REQUIRE(a->residual == nullptr, PP_ERR_ARG, "pp_conv2d: fuse and residual are exclusive");
     }
+    PP_REQUIRE(a->residual == nullptr, PP_ERR_ARG, "pp_conv2d: preadd / fuse and residual are exclusive");
     if (a->fuse == PP_FUSE_GRU_ZR)
       PP_REQUIRE(a->out2 != nullptr && a->fuse_split > 0 && a->fuse_split % 8 == 0 && a->fuse_split < a->cout_g &&
                      ((uintptr_t)a->out2 % 16) == 0 && ((a->out2_cstride | a->out2_choff) & 7) == 0,

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void conv_ast_kernel(const ConvParams p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       prewaited = true;
       if constexpr (DIAG == 0) {
-        conv_epilogue<WM, CN>(p, acc, epi + wave * EPI_W, lane, chunk * CN, 0, p.out, rowmap, bias4);
+        conv_epilogue<WM, CN, CN / 16, 0, false, false>(p, acc, epi + wave * EPI_W, lane, chunk * CN, 0, p.out, rowmap, bias4);
       } else {                                        // [diagnostic] no epilogue: keep the accumulators alive only
         float sacc = 0.f;
 #pragma unroll
@@ -170,6 +170,7 @@ __global__ __launch_bounds__(256, 2) void conv_ast_kernel(const ConvParams p) {
 // cfg: 0 = auto, 80 = force.
 int conv_ast_dispatch(const ConvParams& p, int cfg, hipStream_t stream) {
   const int K = p.kchunks * 8;
+  if (p.preadd != nullptr || p.fuse != PP_FUSE_NONE) return -1000;      // the fused recurrent-cell epilogue lives in the tiled kernels
   if (p.tap_h != 1 || p.tap_w != 1 || p.nsrc != 1 || p.groups != 1 || p.sh != 1 || p.sw != 1 || p.ph != 0 || p.pw != 0) return -1000;
   if (K > 512 || K % 64 != 0 || !(p.ktable_uniform & 8) || p.pad_mode != 0 || p.src_gstride != 0 || p.out_gstride != 0 || p.OH != p.H || p.OW != p.W) return -1000;
   if ((long long)p.cout_pad * p.kchunks * 16 >= (1ll << 31) || p.M >= (1ll << 31)) return -1000;

@@ -140,7 +140,6 @@ __global__ __launch_bounds__(TH * TW * 2) void conv_halo_kernel(const ConvParams
   for (int a = 0; a < TN; ++a)
 #pragma unroll
     for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-
   // fragment geometry: A row of fragment t = patch row pp0[t] + tap shift; B row = wn*WN + t*16 + (lane & 15)
   const int l15 = lane & 15, l4 = lane >> 4;
   int pp0[TM];

@@ -189,3 +189,37 @@ def test_compositor_bytes_equal_the_reference_blend(dtype):
     --fp16 arithmetic (scaling in float16), through three overlapping windows (inference_propainter.py:435-450)."""
     got, ref = _compositor_case(dtype, "cpu")
     assert got.dtype == np.uint8 and np.array_equal(got, ref), f"{(got != ref).mean():.3e} of bytes differ"
+
+
+@pytest.mark.parametrize("cfg", [dict(cout=126, cin=[192, 64], k=(3, 3), groups=1), dict(cout=256, cin=[32, 48], k=(3, 3), groups=8),
+                                 dict(cout=128, cin=[128, 128, 5], k=(3, 3), groups=1), dict(cout=512, cin=[40], k=(7, 7), groups=1),
+                                 dict(cout=20, cin=[324], k=(1, 1), groups=1), dict(cout=128, cin=[128], k=(3, 3), groups=1, dcn=16)],
+                         ids=lambda c: f"c{c['cout']}")
+def test_c_weight_packer_equals_the_python_packer(cfg):
+    """pp_conv_pack_weight (C, for foreign binders) == propainter_amd.conv.pack_weight on the same K table."""
+    import ctypes as C
+    from propainter_amd import hip
+    from propainter_amd.conv import pack_weight, pad8
+    g = torch.Generator().manual_seed(3)
+    kh, kw = cfg["k"]
+    groups, cin = cfg["groups"], cfg["cin"]
+    w = torch.randn(cfg["cout"], sum(cin), kh, kw, generator=g)
+    kt = hip.build_ktable([(ky, kx) for ky in range(kh) for kx in range(kw)], [pad8(c) for c in cin], cfg.get("dcn", 0))
+    ref, K, cout_g = pack_weight(w, cin, groups, ktable=kt)
+    L = hip.lib()
+    L.pp_conv_pack_weight.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                      C.c_int, C.c_void_p, C.c_int64]
+    sc = (C.c_int32 * len(cin))(*cin)
+    wn = np.ascontiguousarray(w.numpy())
+    ktn = np.ascontiguousarray(kt)
+    kchunks = kt.shape[0] - 1
+    cout_pad = L.pp_conv_pack_weight(wn.ctypes.data, cfg["cout"], kh, kw, len(cin), sc, groups, ktn.ctypes.data, kchunks, hip.PP_F32, None, 0)
+    assert cout_pad == ref.shape[1] and K == kchunks * 8
+    out = np.zeros((groups, cout_pad, K), dtype=np.float32)
+    rc = L.pp_conv_pack_weight(wn.ctypes.data, cfg["cout"], kh, kw, len(cin), sc, groups, ktn.ctypes.data, kchunks, hip.PP_F32,
+                               out.ctypes.data, out.size)
+    assert rc == cout_pad and np.array_equal(out, ref.numpy())
+    out16 = np.zeros((groups, cout_pad, K), dtype=np.float16)
+    rc = L.pp_conv_pack_weight(wn.ctypes.data, cfg["cout"], kh, kw, len(cin), sc, groups, ktn.ctypes.data, kchunks, hip.PP_F16,
+                               out16.ctypes.data, out16.size)
+    assert rc == cout_pad and np.array_equal(out16, ref.numpy().astype(np.float16))
