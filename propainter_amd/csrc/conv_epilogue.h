@@ -22,6 +22,7 @@ template <int WM, int WN, int TNT = WN / 16, int A0 = 0, bool PREFETCH = true, b
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc_)[TNT][WM / 16], char* wave_lds, int lane,
                                               int co_wave /* first cout of the wave tile within the group */, int g,
                                               char* outp, const RowMap rowmap, const f32x4* bias_pre = nullptr,
+                                              unsigned long long* stamp = nullptr /* diagnostic: cycle counter after phase 1 */,
                                               const bool preadd_done = false /* the caller already folded preadd into the accumulators (measured slower in the halo kernel: 8-byte accumulator-layout reads; kept for callers that have the addend in registers) */) {
   constexpr int TM = WM / 16, TN = WN / 16;
   typedef _Float16 T;
@@ -83,6 +84,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc_)
       }
     }
   }
+  if (stamp != nullptr) { asm volatile("s_nop 0" ::: "memory"); *stamp = __builtin_readcyclecounter(); }
   if (!has_res && !late && p.act2 == PP_ACT_RELU) {          // act2 is defined as "after the residual add"; without a residual it still applies
 #pragma unroll
     for (int a = 0; a < TN; ++a)

@@ -265,7 +265,7 @@ __global__ __launch_bounds__(TH * TW * 2) void conv_halo_kernel(const ConvParams
   };
   const RowMap rowmap{wm * WM, ty0, tx0, p.H, p.W, (long long)n * p.H};
   if constexpr (WN <= 64) {
-    conv_epilogue<WM, WN>(p, acc, lds + wave * (EPI_BYTES / NW), lane, n0 + wn * WN, 0, p.out, rowmap);
+    conv_epilogue<WM, WN>(p, acc, lds + wave * (EPI_BYTES / NW), lane, n0 + wn * WN, 0, p.out, rowmap, nullptr, PROF ? &pf_e2 : nullptr);
   } else {
     // 128-cout wave tiles (BN 256, experimental): two passes of 64 couts through the same wave-private staging tile
     // (LDS operations of one wave execute in order, so the second pass cannot overtake the first pass's reads)

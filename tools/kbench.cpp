@@ -63,6 +63,7 @@ int main(int argc, char** argv) {
   int reps = 20, act = PP_ACT_NONE;
   std::string late;
   bool res = false, prof = false;
+  int rounds = 1;
   for (int i = 9; i < argc; ++i) {
     if (!strcmp(argv[i], "--impls")) impls = parse_list(argv[++i]);
     else if (!strcmp(argv[i], "--reps")) reps = atoi(argv[++i]);
@@ -70,6 +71,7 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--late")) late = argv[++i];
     else if (!strcmp(argv[i], "--res")) res = true;
     else if (!strcmp(argv[i], "--prof")) prof = true;
+    else if (!strcmp(argv[i], "--rounds")) rounds = atoi(argv[++i]);
   }
   const int nsrc = (int)srcs.size();
   std::vector<int32_t> dy, dx, cpad(nsrc), creal(nsrc);
@@ -139,6 +141,7 @@ int main(int argc, char** argv) {
   for (int s : srcs) printf(" %d", s);
   printf(" cout %d  K %d  %.2f GFLOP  late=%s res=%d act=%d\n", COUT, K, flops / 1e9, late.empty() ? "-" : late.c_str(), (int)res, act);
   std::vector<_Float16> ref(npix * ocs), got(npix * ocs);
+  for (int round = 0; round < rounds; ++round)
   for (size_t ii = 0; ii < impls.size(); ++ii) {
     a.impl = impls[ii];
     a.out = d_out[ii];
@@ -172,8 +175,8 @@ int main(int argc, char** argv) {
       pp_debug_conv_prof(pf);
       if (pf[6]) {
         const double wv = (double)pf[6];
-        printf("      prof/wave: vmwait %.0f barrier %.0f issue %.0f compute %.0f | loop %.0f epilogue %.0f (sync %.0f) prologue %.0f | steps %.1f\n",
-               pf[0] / wv, pf[1] / wv, pf[2] / wv, pf[3] / wv, pf[4] / wv, pf[5] / wv, pf[8] / wv, pf[11] / wv, pf[7] / wv);
+        printf("      prof/wave: vmwait %.0f barrier %.0f issue %.0f compute %.0f | loop %.0f epilogue %.0f (sync %.0f) prologue %.0f | steps %.1f | epi: phase1 %.0f rest %.0f\n",
+               pf[0] / wv, pf[1] / wv, pf[2] / wv, pf[3] / wv, pf[4] / wv, pf[5] / wv, pf[8] / wv, pf[11] / wv, pf[7] / wv, pf[9] / wv, pf[10] / wv);
       }
     }
   }
