@@ -1,0 +1,268 @@
+// Modulated deformable 3x3 convolution (torchvision.ops.deform_conv2d as called at model/propainter.py:67-69 and
+// model/recurrent_flow_completion.py:42-44: stride 1, pad 1, dilation 1, 16 offset groups), fp16, PATCH-STAGED.
+//
+// The first kernel (conv_gemm.hip, DEFORM = true) gathers 4 corners x 16 bytes per (pixel, group, tap) straight from
+// HBM/L2: 64-byte sectors for 16 useful bytes, 36 reads of every input pixel per tile -- measured 672 MB of fabric traffic
+// per 69 MB-algorithmic launch and 86 TFLOP/s.  Here a block owns an 8 x 16 tile of output pixels and walks the K range in
+// blocks of 32 input channels (4 offset groups of 8 channels / 2 of 16; the table order of pp_conv_build_ktable):
+//   * the offsets (dy, dx) and modulation masks of the block's groups for all 9 taps are staged in LDS with wide loads;
+//   * the 32-channel input patch of the tile -- the tile grown by 7 + 6 pixels and SHIFTED by the tile's mean offset (the
+//     generator adds the optical flow to every offset pair, propainter.py:61-62, so the samples of a tile move together) --
+//     is staged ONCE (64 contiguous bytes per pixel = one full sector) and serves all 9 taps x 4 corners from LDS;
+//   * per tap (one 32-deep K step) each lane computes exactly its own MFMA A fragment: the bilinear, mask-modulated
+//     sample of 8 channels for pixel (lane & 15) and group slot (lane >> 4) -- no A tile in LDS at all; the weight
+//     fragments (128 couts x 32 k) come straight from L2 (the same 8 KB for every block of the launch), prefetched one
+//     step ahead;
+//   * a sample whose corners fall outside the staged patch (|offset - tile mean| >= 5) reads those corners from global
+//     memory: slower, never wrong.  Outside the image every corner contributes zero (torchvision's bilinear_interpolate).
+// 4 waves, wave tile 32 pixels x 128 couts, v_mfma_f32_16x16x32_f16, fp32 accumulation; 2 blocks per CU.
+#include "conv_params.h"
+
+namespace pp {
+
+constexpr int DCN_TH = 8, DCN_TW = 16, DCN_R0 = 6, DCN_PH = DCN_TH + 13, DCN_PW = DCN_TW + 13;   // patch rows / columns
+constexpr int DCN_PATCH_BYTES = DCN_PH * DCN_PW * 64;
+constexpr int DCN_OSTR = 112;                                // fp16 per pixel in the offset stage (>= 108, 16-byte rows)
+constexpr int DCN_OFFS_BYTES = 128 * DCN_OSTR * 2;
+constexpr int DCN_LDS = DCN_PATCH_BYTES + DCN_OFFS_BYTES + 64;
+
+// CG: channels per offset group (8 or 16).  GB = 32 / CG groups per 32-channel block.
+template <int CG>
+__global__ __launch_bounds__(256, 2) void conv_dcn_patch_kernel(const ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int GB = 32 / CG;                 // offset groups per channel block
+  constexpr int NOFF = GB * 9 * 2;            // fp16 offsets per pixel and block (dy, dx interleaved)
+  constexpr int NMSK = GB * 9;                // fp16 masks per pixel and block
+  __shared__ __attribute__((aligned(16))) char lds[DCN_LDS];
+  char* const patch = lds;
+  _Float16* const offs = reinterpret_cast<_Float16*>(lds + DCN_PATCH_BYTES);
+  float* const red = reinterpret_cast<float*>(lds + DCN_PATCH_BYTES + DCN_OFFS_BYTES);     // [4 waves][2] + shift[2]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, l4 = lane >> 4;
+
+  int bid = blockIdx.x;
+  {
+    const int nblk = gridDim.x;
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, loc = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int tn = bid % p.tiles_n;
+  int tile = bid / p.tiles_n;
+  const int tiles_x = (p.W + DCN_TW - 1) / DCN_TW, tiles_y = (p.H + DCN_TH - 1) / DCN_TH;
+  const int txi = tile % tiles_x; tile /= tiles_x;
+  const int tyi = tile % tiles_y;
+  const int n = tile / tiles_y;
+  const int ty0 = tyi * DCN_TH, tx0 = txi * DCN_TW;
+  const int n0 = tn * 128;
+  const long long img0 = (long long)n * p.H * p.W;
+
+  // the lane's two pixels (M tiles 0 / 1 of the wave): tile-local index q = wave * 32 + mt * 16 + l15
+  int oy[2], ox[2];
+  bool pin[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int q = wave * 32 + mt * 16 + l15;
+    oy[mt] = ty0 + q / DCN_TW;
+    ox[mt] = tx0 + q % DCN_TW;
+    pin[mt] = oy[mt] < p.H && ox[mt] < p.W;
+  }
+  // group slot of the lane inside a 32-channel block: CG 8 -> group l4, channels l4*8..; CG 16 -> group l4 >> 1, half l4 & 1
+  const int gi = CG == 8 ? l4 : (l4 >> 1);
+
+  const __amdgpu_buffer_rsrc_t rw = uniform_buffer_rsrc(p.weight, p.cout_pad * p.kchunks * 16);
+  // weight fragments: row (cout) = n0 + nt * 16 + l15, 16 bytes at k = step * 32 + l4 * 8
+  int wvoff[8];
+#pragma unroll
+  for (int nt = 0; nt < 8; ++nt) {
+    int row = n0 + nt * 16 + l15;
+    if (row >= p.cout_pad) row = p.cout_pad - 1;            // clamped rows feed accumulators that are never stored
+    wvoff[nt] = row * p.kchunks * 16 + l4 * 16;
+  }
+  auto load_w = [&](int step, u32x4 (&b)[8]) {
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) b[nt] = __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff[nt], step * 64, 0);
+  };
+
+  f32x4 acc[8][2];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nblocks = p.kchunks / 36;         // 32-channel blocks (9 taps x 4 chunks each)
+  u32x4 wcur[8], wnxt[8];
+  load_w(0, wcur);
+  int shift_y = 0, shift_x = 0;
+
+  for (int cb = 0; cb < nblocks; ++cb) {
+    const int4 e0 = p.ktable[cb * 36];                       // first chunk of the block: source id, first group, channel offset
+    const int s = e0.z & 0xff, g0 = (e0.z >> 8) & 0xff;
+    const char* sptr = s == 1 ? p.src[1].ptr : s == 2 ? p.src[2].ptr : s == 3 ? p.src[3].ptr : p.src[0].ptr;
+    const int scs = s == 1 ? p.src[1].cstride : s == 2 ? p.src[2].cstride : s == 3 ? p.src[3].cstride : p.src[0].cstride;
+    const int sco = (s == 1 ? p.src[1].choff : s == 2 ? p.src[2].choff : s == 3 ? p.src[3].choff : p.src[0].choff) + e0.w;
+    __syncthreads();                                         // previous block's patch / offsets fully consumed
+    // ---- stage offsets + masks of groups g0 .. g0 + GB - 1 (all 9 taps) for the 128 pixels: 8-byte / 4-byte units
+    {
+      constexpr int UO = NOFF / 4, UM = NMSK / 2;            // units per pixel: 8-byte offset units, 4-byte mask units
+      for (int i = tid; i < 128 * (UO + UM); i += 256) {
+        const int q = i / (UO + UM), u = i - q * (UO + UM);
+        const int py = ty0 + q / DCN_TW, px = tx0 + q % DCN_TW;
+        const bool ok = py < p.H && px < p.W;
+        const _Float16* om = reinterpret_cast<const _Float16*>(p.dcn) + (img0 + (long long)py * p.W + px) * p.dcn_cstride;
+        if (u < UO) {
+          u32x2 v = u32x2{0, 0};
+          if (ok) v = *reinterpret_cast<const u32x2*>(om + 2 * 9 * g0 + u * 4);
+          *reinterpret_cast<u32x2*>(offs + q * DCN_OSTR + u * 4) = v;
+        } else {
+          const int um = u - UO;
+          uint32_t v = 0;
+          if (ok) v = *reinterpret_cast<const uint32_t*>(om + p.dcn_mask_off + 9 * g0 + um * 2);
+          *reinterpret_cast<uint32_t*>(offs + q * DCN_OSTR + NOFF + um * 2) = v;
+        }
+      }
+    }
+    __syncthreads();
+    if (cb == 0) {
+      // ---- mean offset of the tile (first block's groups) -> integer patch shift, once per block
+      float sy = 0.f, sx = 0.f;
+      for (int i = tid; i < 128 * GB * 9; i += 256) {
+        const int q = i / (GB * 9), j = i - q * (GB * 9);
+        sy += (float)offs[q * DCN_OSTR + 2 * j];
+        sx += (float)offs[q * DCN_OSTR + 2 * j + 1];
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { sy += __shfl_xor(sy, o); sx += __shfl_xor(sx, o); }
+      if (lane == 0) { red[wave * 2] = sy; red[wave * 2 + 1] = sx; }
+      __syncthreads();
+      if (tid == 0) {
+        const float inv = 1.f / (float)(128 * GB * 9);
+        float my = (red[0] + red[2] + red[4] + red[6]) * inv, mx = (red[1] + red[3] + red[5] + red[7]) * inv;
+        my = fminf(fmaxf(my, -4096.f), 4096.f);
+        mx = fminf(fmaxf(mx, -4096.f), 4096.f);
+        red[8] = rintf(my);
+        red[9] = rintf(mx);
+      }
+      __syncthreads();
+      shift_y = (int)red[8];
+      shift_x = (int)red[9];
+    }
+    // ---- stage the 32-channel patch: rows [py0, py0 + PH), columns [px0, px0 + PW); 16-byte slot c of patch pixel i is
+    //      stored at slot (c + (i >> 2)) & 3 (16 consecutive positions x one slot = 16 distinct banks groups)
+    const int py0 = ty0 - 1 - DCN_R0 + 1 + shift_y - 0, px0 = tx0 - 1 - DCN_R0 + 1 + shift_x - 0;   // = tile origin - 6 + shift
+    for (int i = tid; i < DCN_PH * DCN_PW * 4; i += 256) {
+      const int pi = i >> 2, c = i & 3;
+      const int yy = py0 + pi / DCN_PW, xx = px0 + pi % DCN_PW;
+      u32x4 v = u32x4{0, 0, 0, 0};
+      if ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W)
+        v = *reinterpret_cast<const u32x4*>(sptr + ((img0 + (long long)yy * p.W + xx) * scs + sco + c * 8) * 2);
+      *reinterpret_cast<u32x4*>(patch + pi * 64 + (((c + (pi >> 2)) & 3) << 4)) = v;
+    }
+    __syncthreads();
+
+    // ---- 9 taps = 9 K steps of 32
+#pragma unroll 1
+    for (int t = 0; t < 9; ++t) {
+      const int step = cb * 9 + t;
+      const bool more = step + 1 < nblocks * 9;
+      if (more) load_w(step + 1, wnxt);
+      f16x8 af[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (pin[mt]) {
+          const int q = wave * 32 + mt * 16 + l15;
+          const _Float16* o = offs + q * DCN_OSTR;
+          const float dyv = (float)o[2 * (gi * 9 + t)], dxv = (float)o[2 * (gi * 9 + t) + 1];
+          const float mk = (float)o[NOFF + gi * 9 + t];
+          const float py = (float)(oy[mt] - 1 + t / 3) + dyv;
+          const float px = (float)(ox[mt] - 1 + t % 3) + dxv;
+          if (py > -1.f && py < (float)p.H && px > -1.f && px < (float)p.W) {
+            const float fy = floorf(py), fx = floorf(px);
+            const int y0 = (int)fy, x0 = (int)fx;
+            const float ly = py - fy, lx = px - fx;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const int yy = y0 + (c >> 1), xx = x0 + (c & 1);
+              if ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) {
+                const float wgt = ((c >> 1) ? ly : 1.f - ly) * ((c & 1) ? lx : 1.f - lx) * mk;
+                const int ry = yy - py0, rx = xx - px0;
+                u32x4 raw;
+                if ((unsigned)ry < (unsigned)DCN_PH && (unsigned)rx < (unsigned)DCN_PW) {
+                  const int pi = ry * DCN_PW + rx;
+                  raw = *reinterpret_cast<const u32x4*>(patch + pi * 64 + (((l4 + (pi >> 2)) & 3) << 4));
+                } else {                                      // outside the staged patch: straight from global memory
+                  raw = *reinterpret_cast<const u32x4*>(sptr + ((img0 + (long long)yy * p.W + xx) * scs + sco + l4 * 8) * 2);
+                }
+                const _Float16* hv = reinterpret_cast<const _Float16*>(&raw);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a8[j] += wgt * (float)hv[j];
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) af[mt][j] = (_Float16)a8[j];
+      }
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+          acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wcur[nt]), af[mt], acc[nt][mt], 0, 0, 0);
+      if (more) {
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) wcur[nt] = wnxt[nt];
+      }
+    }
+  }
+
+  // ---- epilogue: lane holds couts nt*16 + l4*4 + r (r = 0..3) of pixel mt*16 + l15
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    if (!pin[mt]) continue;
+    const long long m = img0 + (long long)oy[mt] * p.W + ox[mt];
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) {
+      const int co = n0 + nt * 16 + l4 * 4;
+      if (co >= p.cout_g) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float x = acc[nt][mt][r];
+        if (p.bias != nullptr && co + r < p.cout_g) x += p.bias[co + r];
+        v[r] = apply_act(x * p.out_scale, p.act, p.act_param);
+      }
+      _Float16* op = reinterpret_cast<_Float16*>(p.out) + m * p.out_cstride + p.out_choff + co;
+      if (co + 3 < p.cout_g && (((m * p.out_cstride + p.out_choff + co) & 3) == 0)) {
+        *reinterpret_cast<f16x4*>(op) = f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (co + r < p.cout_g) op[r] = (_Float16)v[r];
+      }
+    }
+  }
+#endif
+}
+
+// Returns -1000 when the layer is outside this kernel's family (caller falls back to the register-staged gather).
+int conv_dcn_dispatch(const ConvParams& pin_, hipStream_t stream) {
+  ConvParams p = pin_;
+  if (p.dcn == nullptr || p.groups != 1 || p.sh != 1 || p.sw != 1 || p.ph != 1 || p.pw != 1 || p.OH != p.H || p.OW != p.W) return -1000;
+  if (p.out_f16 == 0 || p.residual != nullptr || p.preadd != nullptr || p.fuse != 0 || p.act2 != 0 || p.act >= PP_ACT_SIGMOID) return -1000;
+  if (p.kchunks % 36 != 0 || p.dcn_mask_off != 288) return -1000;
+  const int cin = p.kchunks / 9 * 8;                      // total input channels (all sources)
+  if (cin != 128 && cin != 256) return -1000;             // 16 offset groups of 8 / 16 channels
+  if ((p.dcn_cstride & 3) != 0 || (long long)p.cout_pad * p.kchunks * 16 >= (1ll << 31)) return -1000;
+  for (int i = 0; i < p.nsrc; ++i)
+    if ((p.src[i].cstride & 7) != 0 || (p.src[i].choff & 7) != 0) return -1000;
+  p.tiles_n = (p.cout_g + 127) / 128;
+  const long long nblk = (long long)p.N * ((p.H + DCN_TH - 1) / DCN_TH) * ((p.W + DCN_TW - 1) / DCN_TW) * p.tiles_n;
+  if (nblk >= (1ll << 31)) return -1000;
+  if (cin == 128) hipLaunchKernelGGL((conv_dcn_patch_kernel<8>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((conv_dcn_patch_kernel<16>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
+  return launch_status("pp_conv2d(dcn)");
+}
+
+}  // namespace pp

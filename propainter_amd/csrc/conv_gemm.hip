@@ -432,18 +432,23 @@ extern "C" int pp_conv_build_ktable(int ntaps, const int32_t* dy, const int32_t*
   PP_REQUIRE(out_capacity >= padded + 1, PP_ERR_WORKSPACE, "pp_conv_build_ktable: need %d entries, got %d", padded + 1, out_capacity);
   int k = 0;
   if (dcn_groups) {
-    // deformable sampling: tap-major (every chunk carries its own offset group / tap id)
-    for (int t = 0; t < ntaps; ++t) {
-      int cglobal = 0;
-      for (int s = 0; s < nsrc; ++s)
-        for (int c = 0; c < src_channels[s]; c += 8, cglobal += 8, ++k) {
-          int grp = cglobal / (ctotal / dcn_groups);
+    // deformable sampling: GROUP-BLOCK-major.  A block of 32 consecutive channels (4 offset groups of 8 channels, or 2 of 16)
+    // runs through all taps before the next block starts: k = ((block * ntaps + tap) * 4 + slot) * 8 + c.  The patch-staged
+    // kernel (conv_dcn.hip) stages the 32-channel input patch of a tile once per block and samples all taps from LDS; every
+    // chunk still carries its own offset group / tap id, so any kernel can walk the table in order.
+    const int cg = ctotal / dcn_groups;                    // channels per offset group (multiple of 8)
+    int src_base[PP_CONV_MAX_SRC], acc_c = 0;
+    for (int s = 0; s < nsrc; ++s) { src_base[s] = acc_c; acc_c += src_channels[s]; }
+    for (int cb = 0; cb < ctotal; cb += 32)
+      for (int t = 0; t < ntaps; ++t)
+        for (int cglobal = cb; cglobal < cb + 32 && cglobal < ctotal; cglobal += 8, ++k) {
+          int s = 0;
+          while (s + 1 < nsrc && cglobal >= src_base[s + 1]) ++s;
           out[4 * k + 0] = dy[t];
           out[4 * k + 1] = dx[t];
-          out[4 * k + 2] = s | (grp << 8) | (t << 16);
-          out[4 * k + 3] = c;
+          out[4 * k + 2] = s | ((cglobal / cg) << 8) | (t << 16);
+          out[4 * k + 3] = cglobal - src_base[s];
         }
-    }
   } else {
     // channel-block-major: (source, 64-channel block, tap, 8-channel chunk).  All taps of one 128-byte channel block
     // are consecutive K steps, so the pixels a tile re-reads for its neighbouring taps are still in the XCD's L2
@@ -553,6 +558,12 @@ extern "C" int pp_conv2d(const pp_conv_args_t* a, void* stream) {
     const int rc = conv_v2_dispatch(p, a->impl >= 10 ? a->impl : (a->impl == 2 ? 100 : 0), st);
     if (rc != -1000) return rc;
     PP_REQUIRE(a->impl < 10, PP_ERR_ARG, "pp_conv2d: impl %d not available for this shape", a->impl);
+  }
+  if (a->dtype == PP_F16 && deform && (a->impl == 0 || a->impl == 90)) {
+    // patch-staged deformable kernel (16 offset groups of 8 / 16 channels, stride 1, 3x3)
+    const int rc = conv_dcn_dispatch(p, st);
+    if (rc != -1000) return rc;
+    PP_REQUIRE(a->impl == 0, PP_ERR_ARG, "pp_conv2d: impl 90 (patch-staged deformable kernel) not available for this layer");
   }
   if (a->dtype == PP_F16) return dispatch_conv<_Float16>(p, a->groups, deform, st);
   PP_REQUIRE(a->impl != 3 || !deform, PP_ERR_ARG, "pp_conv2d: impl 3 (split-fp16 products) does not apply to the deformable mode");

@@ -416,6 +416,68 @@ def test_corr_lookup_on_the_fly_matches_the_volume_pyramid(dev, case):
     assert torch.equal(solo[0], out[1])
 
 
+@pytest.mark.parametrize("case", ["gen_flow_shift", "gen_wild_offsets", "fc_two_src", "gen_channel_window"])
+def test_deform_conv_patch_staged_kernel(dev, case):
+    """The patch-staged fp16 deformable kernel (conv_dcn.hip, impl 90) against the oracle restatement and bit-compared
+    with the register-staged gather (impl 1) on the same offsets: a common flow displacement of (+7.6, -9.3) px that the
+    tile-mean patch shift must absorb, offsets of +-20 px per sample (every corner from the global fallback, many outside
+    the image), the two-source 256-channel flow-completion layer, and channel windows / ragged tiles (33 x 45 pixels)."""
+    from propainter_amd.conv import ConvLayer
+    g = torch.Generator().manual_seed({"gen_flow_shift": 41, "gen_wild_offsets": 42, "fc_two_src": 43, "gen_channel_window": 44}[case])
+    dt = torch.float16
+    cin = [128, 128] if case == "fc_two_src" else [128]
+    N, H, W = 2, 33, 45
+    ctot = sum(cin)
+    x = torch.randn(N, ctot, H, W, generator=g)
+    w = torch.randn(128, ctot, 3, 3, generator=g) / math.sqrt(ctot * 9)
+    b = torch.randn(128, generator=g) * 0.1
+    off = torch.randn(N, 288, H, W, generator=g) * 1.5
+    if case == "gen_flow_shift":
+        off[:, 0::2] += 7.6
+        off[:, 1::2] -= 9.3
+    elif case == "gen_wild_offsets":
+        off = (torch.rand(N, 288, H, W, generator=g) * 2 - 1) * 20
+    elif case == "fc_two_src":
+        off = 5 * torch.tanh(off)
+        off[:, :, 3, 4] = 5.0
+    msk = torch.rand(N, 144, H, W, generator=g)
+    om = nhwc(torch.cat([off, msk], 1), dt)
+    omc = om.float().cpu().permute(0, 3, 1, 2)
+    ref = deform_conv2d(x.to(dt).float(), omc[:, :288].contiguous(), w.to(dt).float(), b, 1, 1, 1, omc[:, 288:432].contiguous())
+    layer = ConvLayer(w, b, padding=1, src_channels=cin, dcn_groups=16, dtype=dt, device=dev)
+    if case == "gen_channel_window":         # source and output as channel windows of wider buffers
+        wide = torch.zeros(N, H, W, 160, dtype=dt, device=dev)
+        wide[..., 16:144] = x.permute(0, 2, 3, 1).to(dev, dt)
+        srcs, kw = [(wide, 16)], dict(out=torch.full((N, H, W, 144), 2.0, dtype=dt, device=dev), out_choff=8)
+    else:
+        srcs, o_, kw = [], 0, {}
+        for c in cin:
+            srcs.append(nhwc(x[:, o_:o_ + c], dt))
+            o_ += c
+    outs = {}
+    for impl in (90, 1):
+        layer.impl = impl
+        if "out" in kw:
+            kw["out"] = torch.full((N, H, W, 144), 2.0, dtype=dt, device=dev)
+        o = layer(srcs, dcn_offmask=om, **kw)
+        torch.cuda.synchronize()
+        outs[impl] = o
+    if "out" in kw:
+        assert (outs[90][..., :8] == 2).all() and (outs[90][..., 136:] == 2).all()
+        got90, got1 = outs[90][..., 8:136], outs[1][..., 8:136]
+    else:
+        got90, got1 = outs[90], outs[1]
+    check("deform_patch", got90.permute(0, 3, 1, 2), ref, tol(dt, 2))
+    d = (got90.float() - got1.float()).abs().max().item()
+    assert d <= 2e-2 * ref.abs().max().item(), f"patch-staged vs register-staged kernel: max |d| {d}"
+    again = layer(srcs, dcn_offmask=om, **({} if "out" not in kw else dict(out=torch.full((N, H, W, 144), 2.0, dtype=dt, device=dev), out_choff=8)))
+    torch.cuda.synchronize()
+    layer.impl = 90
+    a2 = layer(srcs, dcn_offmask=om, **({} if "out" not in kw else dict(out=torch.full((N, H, W, 144), 2.0, dtype=dt, device=dev), out_choff=8)))
+    torch.cuda.synchronize()
+    assert torch.equal(a2, outs[90]), "patch-staged deformable kernel is not run-to-run deterministic"
+
+
 @pytest.mark.parametrize("dt", DTYPES, ids=["f32", "f16"])
 def test_convex_upsample(dev, dt):
     from propainter_amd import hip
