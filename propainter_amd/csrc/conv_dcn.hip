@@ -10,9 +10,10 @@
 //     generator adds the optical flow to every offset pair, propainter.py:61-62, so the samples of a tile move together) --
 //     is staged ONCE (64 contiguous bytes per pixel = one full sector) and serves all 9 taps x 4 corners from LDS;
 //   * per tap (one 32-deep K step) each lane computes exactly its own MFMA A fragment: the bilinear, mask-modulated
-//     sample of 8 channels for pixel (lane & 15) and group slot (lane >> 4) -- no A tile in LDS at all; the weight
-//     fragments (128 couts x 32 k) come straight from L2 (the same 8 KB for every block of the launch), prefetched one
-//     step ahead;
+//     sample of 8 channels (corner weights in fp32, the 4-corner blend in packed fp16: the sample is an fp16 MFMA
+//     operand anyway) for pixel (lane & 15) and group slot (lane >> 4) -- no A tile in LDS at all; the weight
+//     fragments (128 couts x 32 k) come straight from L2 (the same 8 KB for every block of the launch), prefetched one K step
+//     ahead;
 //   * a sample whose corners fall outside the staged patch (|offset - tile mean| >= 5) reads those corners from global
 //     memory: slower, never wrong.  Outside the image every corner contributes zero (torchvision's bilinear_interpolate).
 // 4 waves, wave tile 32 pixels x 128 couts, v_mfma_f32_16x16x32_f16, fp32 accumulation; 2 blocks per CU.
@@ -22,8 +23,8 @@ namespace pp {
 
 constexpr int DCN_TH = 8, DCN_TW = 16, DCN_R0 = 6, DCN_PH = DCN_TH + 13, DCN_PW = DCN_TW + 13;   // patch rows / columns
 constexpr int DCN_PATCH_BYTES = DCN_PH * DCN_PW * 64;
-constexpr int DCN_OSTR = 112;                                // fp16 per pixel in the offset stage (>= 108, 16-byte rows)
-constexpr int DCN_OFFS_BYTES = 128 * DCN_OSTR * 2;
+constexpr int DCN_OSTR = 72;                                 // fp16 per pixel and stage row: 144 bytes = 9 x 16-byte units
+constexpr int DCN_OFFS_BYTES = 2 * 128 * DCN_OSTR * 2;       // one row array for (dy, dx) pairs, one for modulation masks
 constexpr int DCN_LDS = DCN_PATCH_BYTES + DCN_OFFS_BYTES + 64;
 
 // CG: channels per offset group (8 or 16).  GB = 32 / CG groups per 32-channel block.
@@ -35,7 +36,10 @@ __global__ __launch_bounds__(256, 2) void conv_dcn_patch_kernel(const ConvParams
   constexpr int NMSK = GB * 9;                // fp16 masks per pixel and block
   __shared__ __attribute__((aligned(16))) char lds[DCN_LDS];
   char* const patch = lds;
-  _Float16* const offs = reinterpret_cast<_Float16*>(lds + DCN_PATCH_BYTES);
+  _Float16* const offs = reinterpret_cast<_Float16*>(lds + DCN_PATCH_BYTES);          // [128][72]: 36 (dy, dx) pairs
+  _Float16* const msks = offs + 128 * DCN_OSTR;                                      // [128][72]: 72 masks
+  constexpr int OG = DCN_OSTR / NOFF;         // channel blocks served by one staged offset row (gen 1, flow completion 2)
+  constexpr int MG = DCN_OSTR / NMSK;         // ... by one staged mask row (2 / 4)
   float* const red = reinterpret_cast<float*>(lds + DCN_PATCH_BYTES + DCN_OFFS_BYTES);     // [4 waves][2] + shift[2]
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -103,32 +107,39 @@ __global__ __launch_bounds__(256, 2) void conv_dcn_patch_kernel(const ConvParams
     const int scs = s == 1 ? p.src[1].cstride : s == 2 ? p.src[2].cstride : s == 3 ? p.src[3].cstride : p.src[0].cstride;
     const int sco = (s == 1 ? p.src[1].choff : s == 2 ? p.src[2].choff : s == 3 ? p.src[3].choff : p.src[0].choff) + e0.w;
     __syncthreads();                                         // previous block's patch / offsets fully consumed
-    // ---- stage offsets + masks of groups g0 .. g0 + GB - 1 (all 9 taps) for the 128 pixels: 8-byte / 4-byte units
-    {
-      constexpr int UO = NOFF / 4, UM = NMSK / 2;            // units per pixel: 8-byte offset units, 4-byte mask units
-      for (int i = tid; i < 128 * (UO + UM); i += 256) {
-        const int q = i / (UO + UM), u = i - q * (UO + UM);
+    const int dbg = p.tap_w;                                 // [diagnostic] tools/bench_dcn.py ablations (impl 91..98): 0 in production
+    // ---- stage (dy, dx) pairs / masks: 144 contiguous bytes per pixel (nine 16-byte loads) hold the offsets of OG channel
+    //      blocks and the masks of MG channel blocks; loads of a thread are issued together (a rolled loop pays one memory
+    //      latency per unit: measured 42 of the kernel's 121 us with 4- and 8-byte units)
+    auto stage144 = [&](const int first_channel, _Float16* dst) {
+      constexpr int NU = 128 * 9, ITER = (NU + 255) / 256;
+      u32x4 v[ITER];
+#pragma unroll
+      for (int k = 0; k < ITER; ++k) {
+        const int i = tid + k * 256;
+        const int q = i / 9, u = i - q * 9;
         const int py = ty0 + q / DCN_TW, px = tx0 + q % DCN_TW;
-        const bool ok = py < p.H && px < p.W;
-        const _Float16* om = reinterpret_cast<const _Float16*>(p.dcn) + (img0 + (long long)py * p.W + px) * p.dcn_cstride;
-        if (u < UO) {
-          u32x2 v = u32x2{0, 0};
-          if (ok) v = *reinterpret_cast<const u32x2*>(om + 2 * 9 * g0 + u * 4);
-          *reinterpret_cast<u32x2*>(offs + q * DCN_OSTR + u * 4) = v;
-        } else {
-          const int um = u - UO;
-          uint32_t v = 0;
-          if (ok) v = *reinterpret_cast<const uint32_t*>(om + p.dcn_mask_off + 9 * g0 + um * 2);
-          *reinterpret_cast<uint32_t*>(offs + q * DCN_OSTR + NOFF + um * 2) = v;
-        }
+        v[k] = u32x4{0, 0, 0, 0};
+        if (i < NU && py < p.H && px < p.W)
+          v[k] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const _Float16*>(p.dcn) +
+                                                 (img0 + (long long)py * p.W + px) * p.dcn_cstride + first_channel + u * 8);
       }
+#pragma unroll
+      for (int k = 0; k < ITER; ++k) {
+        const int i = tid + k * 256;
+        if (i < NU) *reinterpret_cast<u32x4*>(dst + (i / 9) * DCN_OSTR + (i % 9) * 8) = v[k];
+      }
+    };
+    if (!(dbg & 1)) {
+      if (cb % OG == 0) stage144(2 * 9 * g0, offs);
+      if (cb % MG == 0) stage144(p.dcn_mask_off + 9 * g0, msks);
     }
     __syncthreads();
     if (cb == 0) {
       // ---- mean offset of the tile (first block's groups) -> integer patch shift, once per block
       float sy = 0.f, sx = 0.f;
-      for (int i = tid; i < 128 * GB * 9; i += 256) {
-        const int q = i / (GB * 9), j = i - q * (GB * 9);
+      for (int i = tid; i < 128 * 36; i += 256) {            // all 36 pairs of the staged row
+        const int q = i / 36, j = i - q * 36;
         sy += (float)offs[q * DCN_OSTR + 2 * j];
         sx += (float)offs[q * DCN_OSTR + 2 * j + 1];
       }
@@ -137,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void conv_dcn_patch_kernel(const ConvParams
       if (lane == 0) { red[wave * 2] = sy; red[wave * 2 + 1] = sx; }
       __syncthreads();
       if (tid == 0) {
-        const float inv = 1.f / (float)(128 * GB * 9);
+        const float inv = 1.f / (float)(128 * 36);
         float my = (red[0] + red[2] + red[4] + red[6]) * inv, mx = (red[1] + red[3] + red[5] + red[7]) * inv;
         my = fminf(fmaxf(my, -4096.f), 4096.f);
         mx = fminf(fmaxf(mx, -4096.f), 4096.f);
@@ -151,13 +162,28 @@ __global__ __launch_bounds__(256, 2) void conv_dcn_patch_kernel(const ConvParams
     // ---- stage the 32-channel patch: rows [py0, py0 + PH), columns [px0, px0 + PW); 16-byte slot c of patch pixel i is
     //      stored at slot (c + (i >> 2)) & 3 (16 consecutive positions x one slot = 16 distinct banks groups)
     const int py0 = ty0 - 1 - DCN_R0 + 1 + shift_y - 0, px0 = tx0 - 1 - DCN_R0 + 1 + shift_x - 0;   // = tile origin - 6 + shift
-    for (int i = tid; i < DCN_PH * DCN_PW * 4; i += 256) {
-      const int pi = i >> 2, c = i & 3;
-      const int yy = py0 + pi / DCN_PW, xx = px0 + pi % DCN_PW;
-      u32x4 v = u32x4{0, 0, 0, 0};
-      if ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W)
-        v = *reinterpret_cast<const u32x4*>(sptr + ((img0 + (long long)yy * p.W + xx) * scs + sco + c * 8) * 2);
-      *reinterpret_cast<u32x4*>(patch + pi * 64 + (((c + (pi >> 2)) & 3) << 4)) = v;
+    if (!(dbg & 2)) {
+      constexpr int NC = DCN_PH * DCN_PW * 4, ITER = (NC + 255) / 256, BATCH = 5;
+      static_assert(ITER % BATCH == 0, "patch chunks per thread");
+#pragma unroll 1
+      for (int k0 = 0; k0 < ITER; k0 += BATCH) {
+        u32x4 vp[BATCH];
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+          const int i = tid + (k0 + k) * 256;
+          const int pi = i >> 2, c = i & 3;
+          const int yy = py0 + pi / DCN_PW, xx = px0 + pi % DCN_PW;
+          vp[k] = u32x4{0, 0, 0, 0};
+          if (i < NC && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W)
+            vp[k] = *reinterpret_cast<const u32x4*>(sptr + ((img0 + (long long)yy * p.W + xx) * scs + sco + c * 8) * 2);
+        }
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+          const int i = tid + (k0 + k) * 256;
+          const int pi = i >> 2, c = i & 3;
+          if (i < NC) *reinterpret_cast<u32x4*>(patch + pi * 64 + (((c + (pi >> 2)) & 3) << 4)) = vp[k];
+        }
+      }
     }
     __syncthreads();
 
@@ -166,45 +192,61 @@ __global__ __launch_bounds__(256, 2) void conv_dcn_patch_kernel(const ConvParams
     for (int t = 0; t < 9; ++t) {
       const int step = cb * 9 + t;
       const bool more = step + 1 < nblocks * 9;
-      if (more) load_w(step + 1, wnxt);
+      if (more && !(dbg & 8)) load_w(step + 1, wnxt);        // one K step ahead: the sampling alone is too short to cover L2
       f16x8 af[2];
+      const int trow = t / 3, tcol = t - trow * 3;
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
-        float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (pin[mt]) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        h2 r2[4] = {h2{0, 0}, h2{0, 0}, h2{0, 0}, h2{0, 0}};
+        if (pin[mt] && !(dbg & 4)) {
           const int q = wave * 32 + mt * 16 + l15;
-          const _Float16* o = offs + q * DCN_OSTR;
-          const float dyv = (float)o[2 * (gi * 9 + t)], dxv = (float)o[2 * (gi * 9 + t) + 1];
-          const float mk = (float)o[NOFF + gi * 9 + t];
-          const float py = (float)(oy[mt] - 1 + t / 3) + dyv;
-          const float px = (float)(ox[mt] - 1 + t % 3) + dxv;
-          if (py > -1.f && py < (float)p.H && px > -1.f && px < (float)p.W) {
-            const float fy = floorf(py), fx = floorf(px);
-            const int y0 = (int)fy, x0 = (int)fx;
-            const float ly = py - fy, lx = px - fx;
+          const h2 dd = *reinterpret_cast<const h2*>(offs + q * DCN_OSTR + (cb % OG) * NOFF + 2 * (gi * 9 + t));
+          const float mk = (float)msks[q * DCN_OSTR + (cb % MG) * NMSK + gi * 9 + t];
+          const float py = (float)(oy[mt] - 1 + trow) + (float)dd[0];
+          const float px = (float)(ox[mt] - 1 + tcol) + (float)dd[1];
+          const float fy = floorf(py), fx = floorf(px);
+          const float ly = py - fy, lx = px - fx;
+          // corner weights (x modulation mask) in fp16 pairs; the patch is zero outside the image, so corners outside the
+          // image contribute zero by themselves (= torchvision's per-corner test and its whole-sample test)
+          const float w11 = ly * lx * mk, w10 = (ly - ly * lx) * mk, w01 = (lx - ly * lx) * mk;
+          const float w00 = mk - w11 - w10 - w01;
+          const _Float16 hw[4] = {(_Float16)w00, (_Float16)w01, (_Float16)w10, (_Float16)w11};
+          // clamp far-out samples before the int conversion (they are handled by the slow path below anyway)
+          const int ry0 = (int)fminf(fmaxf(fy, -1.0e6f), 1.0e6f) - py0, rx0 = (int)fminf(fmaxf(fx, -1.0e6f), 1.0e6f) - px0;
+          if ((unsigned)ry0 < (unsigned)(DCN_PH - 1) && (unsigned)rx0 < (unsigned)(DCN_PW - 1)) {
+            // ---- all four corners inside the staged patch (the common case): 4 LDS reads, packed fp16 blend
+            const int pi0 = ry0 * DCN_PW + rx0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const int pi = pi0 + (c >> 1) * DCN_PW + (c & 1);
+              const u32x4 raw = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(
+                  (const __attribute__((address_space(3))) char*)patch + pi * 64 + (((l4 + (pi >> 2)) & 3) << 4));
+              const h2* hv = reinterpret_cast<const h2*>(&raw);
+              const h2 wv = h2{hw[c], hw[c]};
+#pragma unroll
+              for (int j = 0; j < 4; ++j) r2[j] = __builtin_elementwise_fma(wv, hv[j], r2[j]);
+            }
+          } else {
+            // ---- some corner outside the patch (offset far from the tile mean): per-corner reads from global memory
+            const int y0 = ry0 + py0, x0 = rx0 + px0;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
               const int yy = y0 + (c >> 1), xx = x0 + (c & 1);
               if ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) {
-                const float wgt = ((c >> 1) ? ly : 1.f - ly) * ((c & 1) ? lx : 1.f - lx) * mk;
-                const int ry = yy - py0, rx = xx - px0;
-                u32x4 raw;
-                if ((unsigned)ry < (unsigned)DCN_PH && (unsigned)rx < (unsigned)DCN_PW) {
-                  const int pi = ry * DCN_PW + rx;
-                  raw = *reinterpret_cast<const u32x4*>(patch + pi * 64 + (((l4 + (pi >> 2)) & 3) << 4));
-                } else {                                      // outside the staged patch: straight from global memory
-                  raw = *reinterpret_cast<const u32x4*>(sptr + ((img0 + (long long)yy * p.W + xx) * scs + sco + l4 * 8) * 2);
-                }
-                const _Float16* hv = reinterpret_cast<const _Float16*>(&raw);
+                const u32x4 raw = *reinterpret_cast<const u32x4*>(sptr + ((img0 + (long long)yy * p.W + xx) * scs + sco + l4 * 8) * 2);
+                const h2* hv = reinterpret_cast<const h2*>(&raw);
+                const h2 wv = h2{hw[c], hw[c]};
 #pragma unroll
-                for (int j = 0; j < 8; ++j) a8[j] += wgt * (float)hv[j];
+                for (int j = 0; j < 4; ++j) r2[j] = __builtin_elementwise_fma(wv, hv[j], r2[j]);
               }
             }
           }
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) af[mt][j] = (_Float16)a8[j];
+        for (int j = 0; j < 4; ++j) { af[mt][2 * j] = r2[j][0]; af[mt][2 * j + 1] = r2[j][1]; }
       }
+      if (!(dbg & 8))
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
@@ -218,6 +260,14 @@ __global__ __launch_bounds__(256, 2) void conv_dcn_patch_kernel(const ConvParams
   }
 
   // ---- epilogue: lane holds couts nt*16 + l4*4 + r (r = 0..3) of pixel mt*16 + l15
+  float bv[8][4];
+#pragma unroll
+  for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = n0 + nt * 16 + l4 * 4 + r;
+      bv[nt][r] = (p.bias != nullptr && co < p.cout_g) ? p.bias[co] : 0.f;          // 32 independent loads: one latency
+    }
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     if (!pin[mt]) continue;
@@ -229,9 +279,7 @@ __global__ __launch_bounds__(256, 2) void conv_dcn_patch_kernel(const ConvParams
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float x = acc[nt][mt][r];
-        if (p.bias != nullptr && co + r < p.cout_g) x += p.bias[co + r];
-        v[r] = apply_act(x * p.out_scale, p.act, p.act_param);
+        v[r] = apply_act((acc[nt][mt][r] + bv[nt][r]) * p.out_scale, p.act, p.act_param);
       }
       _Float16* op = reinterpret_cast<_Float16*>(p.out) + m * p.out_cstride + p.out_choff + co;
       if (co + 3 < p.cout_g && (((m * p.out_cstride + p.out_choff + co) & 3) == 0)) {
@@ -247,14 +295,15 @@ __global__ __launch_bounds__(256, 2) void conv_dcn_patch_kernel(const ConvParams
 }
 
 // Returns -1000 when the layer is outside this kernel's family (caller falls back to the register-staged gather).
-int conv_dcn_dispatch(const ConvParams& pin_, hipStream_t stream) {
+int conv_dcn_dispatch(const ConvParams& pin_, hipStream_t stream, int dbg) {
   ConvParams p = pin_;
+  p.tap_w = dbg;
   if (p.dcn == nullptr || p.groups != 1 || p.sh != 1 || p.sw != 1 || p.ph != 1 || p.pw != 1 || p.OH != p.H || p.OW != p.W) return -1000;
   if (p.out_f16 == 0 || p.residual != nullptr || p.preadd != nullptr || p.fuse != 0 || p.act2 != 0 || p.act >= PP_ACT_SIGMOID) return -1000;
   if (p.kchunks % 36 != 0 || p.dcn_mask_off != 288) return -1000;
   const int cin = p.kchunks / 9 * 8;                      // total input channels (all sources)
   if (cin != 128 && cin != 256) return -1000;             // 16 offset groups of 8 / 16 channels
-  if ((p.dcn_cstride & 3) != 0 || (long long)p.cout_pad * p.kchunks * 16 >= (1ll << 31)) return -1000;
+  if ((p.dcn_cstride & 7) != 0 || ((uintptr_t)p.dcn & 15) != 0 || (long long)p.cout_pad * p.kchunks * 16 >= (1ll << 31)) return -1000;
   for (int i = 0; i < p.nsrc; ++i)
     if ((p.src[i].cstride & 7) != 0 || (p.src[i].choff & 7) != 0) return -1000;
   p.tiles_n = (p.cout_g + 127) / 128;
