@@ -302,6 +302,42 @@ int pp_nchw_to_nhwc(const void* in, int in_dtype, void* out, int out_dtype, int 
 int pp_nhwc_to_nchw(const void* in, int in_dtype, int in_cstride, int in_choff, void* out, int out_dtype, int N,
                     int C, int H, int W, int act, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Reference-layout entry points (csrc/ref_layout_ops.hip): the operators of the path as the reference calls them -- planar
+ * NCHW device tensors of `dtype`, weights exactly as stored in the reference's state dict (device, `dtype`), biases fp32 --
+ * for binders that do not carry the engine's NHWC / packed-weight conventions.  Each call packs its operands into the
+ * caller's workspace (size: the *_workspace_size twin; 256-byte aligned device memory), runs the engine kernels and
+ * unpacks; nothing is allocated or retained.  One small host->device copy (the K table) per call: not graph-capturable.
+ * ---------------------------------------------------------------------------------------------- */
+/* torchvision.ops.deform_conv2d(x, offset, weight, bias, stride=1, padding=1, dilation=1, mask) for 3x3 weights and 16
+ * offset groups (model/propainter.py:67-69, model/recurrent_flow_completion.py:42-44): x [N,Cin,H,W] (Cin % 128 == 0),
+ * offset [N,288,H,W] ((dy, dx) interleaved per (group, tap)), mask [N,144,H,W], weight [Cout,Cin,3,3] -> out [N,Cout,H,W]. */
+int64_t pp_deform_conv2d_workspace_size(int N, int Cin, int H, int W, int Cout, int dtype);
+int pp_deform_conv2d(const void* x, const void* offset, const void* mask, const void* weight, const float* bias, void* out,
+                     int N, int Cin, int H, int W, int Cout, int dtype, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* CorrBlock.__init__ (RAFT/corr.py:13-27,52-60): fmap1, fmap2 [B,256,h,w] -> fp32 pyramid lvl[l] = [B*h*w, h>>l, w>>l]
+ * (all-pairs dot products / sqrt(256), then three 2x2 average poolings). */
+int64_t pp_corr_pyramid_workspace_size(int B, int h, int w, int dtype);
+int pp_corr_pyramid(const void* fmap1, const void* fmap2, float* lvl0, float* lvl1, float* lvl2, float* lvl3, int B, int h, int w,
+                    int dtype, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* SoftSplit.forward (model/modules/sparse_transformer.py:19-31): x [BT,C,H,W], embedding weight [hidden, C*49] (feature index
+ * c*49 + ky*7 + kx), bias fp32 [hidden] -> tokens [BT, fh*fw, hidden], f = (n + 6 - 7) / 3 + 1. */
+int64_t pp_softsplit_workspace_size(int BT, int C, int H, int W, int hidden, int dtype);
+int pp_softsplit(const void* x, const void* weight, const float* bias, void* tokens, int BT, int C, int H, int W, int hidden,
+                 int dtype, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* SoftComp.forward (:49-61): tokens [BT, fh*fw, hidden], embedding weight [C*49, hidden] + bias fp32 [C*49], bias_conv weight
+ * [C,C,3,3] + bias fp32 [C] -> out [BT,C,H,W] (Linear -> F.fold(7, 3, 3) -> 3x3 convolution).  C, hidden multiples of 8. */
+int64_t pp_softcomp_workspace_size(int BT, int C, int H, int W, int hidden, int dtype);
+int pp_softcomp(const void* tokens, const void* emb_weight, const float* emb_bias, const void* conv_weight, const float* conv_bias,
+                void* out, int BT, int C, int H, int W, int hidden, int dtype, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* FusionFeedForward's fold -> normalise -> unfold (:82-98) on features [BT, fh*fw, C*49] in the reference order (C = 40):
+ * out = unfold(fold(in) / fold(ones)); in != out. */
+int pp_ffn_fold_unfold(const void* in, void* out, int BT, int C, int H, int W, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
