@@ -83,7 +83,8 @@ def test_corr_pyramid_reference_layout(lib):
     lv = [torch.empty(B * n8, h >> l, w >> l, dtype=torch.float32, device=dev) for l in range(4)]
     need = lib.pp_corr_pyramid_workspace_size(B, h, w, PP_F32)
     ws = torch.empty(need, dtype=torch.uint8, device=dev)
-    rc = lib.pp_corr_pyramid(ptr(f1.to(dev).contiguous()), ptr(f2.to(dev).contiguous()), ptr(lv[0]), ptr(lv[1]), ptr(lv[2]), ptr(lv[3]),
+    f1d, f2d = f1.to(dev).contiguous(), f2.to(dev).contiguous()      # (kept alive: a temporary's block would be reused)
+    rc = lib.pp_corr_pyramid(ptr(f1d), ptr(f2d), ptr(lv[0]), ptr(lv[1]), ptr(lv[2]), ptr(lv[3]),
                              B, h, w, PP_F32, ptr(ws), C.c_int64(need), stream())
     ok(lib, rc, "pp_corr_pyramid")
     torch.cuda.synchronize()
@@ -106,7 +107,8 @@ def test_softsplit_softcomp_ffn_reference_layout(lib, dt, code, tol):
     tok = torch.empty(BT, fh * fw, hidden, dtype=dt, device=dev)
     need = lib.pp_softsplit_workspace_size(BT, Cc, H, W, hidden, code)
     ws = torch.empty(need, dtype=torch.uint8, device=dev)
-    ok(lib, lib.pp_softsplit(ptr(x.to(dev, dt).contiguous()), ptr(wss.to(dev, dt).contiguous()), ptr(bss.to(dev)), ptr(tok), BT, Cc, H, W,
+    xd, wssd, bssd = x.to(dev, dt).contiguous(), wss.to(dev, dt).contiguous(), bss.to(dev)
+    ok(lib, lib.pp_softsplit(ptr(xd), ptr(wssd), ptr(bssd), ptr(tok), BT, Cc, H, W,
                              hidden, code, ptr(ws), C.c_int64(need), stream()), "pp_softsplit")
     torch.cuda.synchronize()
     assert rel(tok, ref_tok) < tol
@@ -121,8 +123,9 @@ def test_softsplit_softcomp_ffn_reference_layout(lib, dt, code, tol):
     out = torch.empty(BT, Cc, H, W, dtype=dt, device=dev)
     need = lib.pp_softcomp_workspace_size(BT, Cc, H, W, hidden, code)
     ws = torch.empty(need, dtype=torch.uint8, device=dev)
-    ok(lib, lib.pp_softcomp(ptr(t_in.to(dev, dt).contiguous()), ptr(wsc.to(dev, dt).contiguous()), ptr(bsc.to(dev)),
-                            ptr(wcv.to(dev, dt).contiguous()), ptr(bcv.to(dev)), ptr(out), BT, Cc, H, W, hidden, code, ptr(ws),
+    td, wscd, bscd, wcvd, bcvd = t_in.to(dev, dt).contiguous(), wsc.to(dev, dt).contiguous(), bsc.to(dev), wcv.to(dev, dt).contiguous(), bcv.to(dev)
+    ok(lib, lib.pp_softcomp(ptr(td), ptr(wscd), ptr(bscd),
+                            ptr(wcvd), ptr(bcvd), ptr(out), BT, Cc, H, W, hidden, code, ptr(ws),
                             C.c_int64(need), stream()), "pp_softcomp")
     torch.cuda.synchronize()
     assert rel(out, ref_sc) < 2 * tol
@@ -132,6 +135,7 @@ def test_softsplit_softcomp_ffn_reference_layout(lib, dt, code, tol):
     folded = F.fold(t, (H, W), 7, 1, 3, 3) / F.fold(torch.ones_like(t), (H, W), 7, 1, 3, 3)
     ref_ffn = F.unfold(folded, 7, 1, 3, 3).permute(0, 2, 1)
     o2 = torch.empty(BT, fh * fw, 40 * 49, dtype=dt, device=dev)
-    ok(lib, lib.pp_ffn_fold_unfold(ptr(hid.to(dev, dt).contiguous()), ptr(o2), BT, 40, H, W, code, stream()), "pp_ffn_fold_unfold")
+    hidd = hid.to(dev, dt).contiguous()
+    ok(lib, lib.pp_ffn_fold_unfold(ptr(hidd), ptr(o2), BT, 40, H, W, code, stream()), "pp_ffn_fold_unfold")
     torch.cuda.synchronize()
     assert rel(o2, ref_ffn) < tol
