@@ -8,7 +8,8 @@
 The device path (RAFT, flow completion, image propagation, sliding-window generator, uint8 composite) runs on the
 HIP engine (libpropainter_hip.so); with several processes (one per GPU) a long clip is sharded by sub-video
 (propainter_amd/sharding.py).  Extra flags that the reference does not have: ``--weights_dir``, ``--seeded_weights``
-(no checkpoints ship with either repository), ``--raft_fp16`` / ``--raft_fp32`` (RAFT arithmetic; the default keeps
+(no checkpoints ship with either repository), ``--save_flow`` / ``--load_flow`` (RAFT output as the reference's ``.flo``
+files; single-process runs), ``--raft_fp16`` / ``--raft_fp32`` (RAFT arithmetic; the default keeps
 RAFT at the reference's precision class under ``--fp16``, see ``raft_precision`` below).
 """
 import argparse
@@ -45,6 +46,10 @@ def build_parser():
     # ---- not in the reference
     a('--weights_dir', type=str, default='weights', help='folder holding raft-things.pth, recurrent_flow_completion.pth, ProPainter.pth')
     a('--seeded_weights', action='store_true', help='run with the deterministic seeded weights (no checkpoints available offline)')
+    a('--save_flow', type=str, default=None, help="write the RAFT flows of the clip as .flo files (the reference's PIEH / float16 "
+      'format, utils/flow_util.py) into this folder')
+    a('--load_flow', type=str, default=None, help='read the RAFT flows from this folder of .flo files instead of running RAFT '
+      '(as written by --save_flow or by the reference scripts/compute_flow.py naming: 00000_f.flo / 00000_b.flo ...)')
     a('--raft_fp16', action='store_true', help='opt in to fp16 RAFT activations/weights (fp32 accumulation, correlation, coordinates and flow): '
       'fastest, ~0.004 px mean end-point error against fp32 at 720p; only with --fp16')
     a('--raft_fp32', action='store_true', help='exact fp32 RAFT products on the fp32 matrix instructions (slowest)')
@@ -140,7 +145,16 @@ def main(argv=None):
             print(f'{L} frames are a single sub-video at --subvideo_length {cfg.subvideo_length}: running on one GPU')
             comp = run_clip(models, frames_u8, flow_masks, masks_dilated, cfg, device)
     else:
-        comp = run_clip(models, frames_u8, flow_masks, masks_dilated, cfg, device)
+        from propainter_amd import flow_io
+        gt = None
+        if args.load_flow:
+            gt = flow_io.load_clip_flows(args.load_flow)
+            print(f'RAFT skipped: {gt[0].shape[0]} flow pairs read from {args.load_flow}')
+        if args.save_flow:
+            comp, stages = run_clip(models, frames_u8, flow_masks, masks_dilated, cfg, device, return_stages=True, gt_flows=gt)
+            flow_io.save_clip_flows(stages["gt_flows"][0][0], stages["gt_flows"][1][0], args.save_flow)
+        else:
+            comp = run_clip(models, frames_u8, flow_masks, masks_dilated, cfg, device, gt_flows=gt)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if rank == 0:

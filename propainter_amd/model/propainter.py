@@ -139,7 +139,7 @@ class _GenEngine:
         return hip.nhwc_to_nchw(x, 3)
 
     # ------------------------------------------------------------------ feature propagation (:104-190, learnable)
-    def feature_propagation(self, x, flows_f, flows_b, mask2):
+    def feature_propagation(self, x, flows_f, flows_b, mask2, interpolation="bilinear"):
         """x [t,h,w,128]; flows_* [t-1,h,w,2] NHWC (1/4-res, already /4); mask2 [t,h,w,2] -> fused [t,h,w,128]."""
         t, h, w, c = x.shape
         dev, dt = x.device, self.dtype
@@ -179,7 +179,7 @@ class _GenEngine:
                     prop = cur
                 else:
                     ax = aux[i - 1:i]
-                    warped = hip.flow_warp(prop, ax, mode="bilinear")
+                    warped = hip.flow_warp(prop, ax, mode=interpolation)
                     o = L["off0"]([cur, warped, ax], act="lrelu", act_param=0.1)
                     o = L["off2"]([o], act="lrelu", act_param=0.1)
                     o = L["off4"]([o], act="lrelu", act_param=0.1)
@@ -277,9 +277,9 @@ class _GenEngine:
         dm_up = masks_updated[0, :l_t, :, ::4, ::4]
         mask2 = torch.cat([dm_in, dm_up], 1).permute(0, 2, 3, 1).contiguous()          # [l_t,h,w,2]
         token_mask = F.max_pool2d(dm_in, 7, 3, 3)[:, 0]                               # [l_t,fh,fw]
-        local = self.feature_propagation(enc[:l_t].contiguous(), dsf, dsb, mask2) if interpolation == "bilinear" else None
-        if local is None:
-            raise NotImplementedError("feature propagation uses bilinear warping (reference default)")
+        if interpolation not in ("bilinear", "nearest"):
+            raise ValueError(f"interpolation {interpolation!r}: 'bilinear' or 'nearest' (model/propainter.py:148)")
+        local = self.feature_propagation(enc[:l_t].contiguous(), dsf, dsb, mask2, interpolation)
         enc = torch.cat([local, enc[l_t:]], 0) if t > l_t else local
         tok = self.ss([enc])                                               # SoftSplit as one convolution
         tok = self.transformer(tok, (h, w), token_mask, t_dilation)
@@ -394,6 +394,17 @@ class InpaintGenerator(nn.Module):
             raise NotImplementedError("training is outside the inference hot path; call .eval()")
         assert DEPTH % t_dilation == 0, 'wrong t_dilation input.'
         dt = masked_frames.dtype
+        b, t, _, H, W = masked_frames.shape
+        if H % 8 or W % 8:
+            # the 1/4-resolution masks are taken by striding (== F.interpolate(nearest, 1/4) only for multiples of 4) and the
+            # driver always resizes to multiples of 8 (inference_propainter.py:34-47 via resize_frames)
+            raise ValueError(f"InpaintGenerator.forward needs H, W multiples of 8 (got {H}x{W})")
         eng = self._get_engine(dt, masked_frames.device)
-        return eng.forward(masked_frames, (completed_flows[0].to(dt), completed_flows[1].to(dt)), masks_in.to(dt),
-                           masks_updated.to(dt), num_local_frames, interpolation, t_dilation, enc_feat=enc_feat)
+        cf = (completed_flows[0].to(dt), completed_flows[1].to(dt))
+        mi, mu = masks_in.to(dt), masks_updated.to(dt)
+        if b == 1:
+            return eng.forward(masked_frames, cf, mi, mu, num_local_frames, interpolation, t_dilation, enc_feat=enc_feat)
+        assert enc_feat is None, "enc_feat (a per-clip engine extension) goes with b == 1"
+        outs = [eng.forward(masked_frames[i:i + 1], (cf[0][i:i + 1], cf[1][i:i + 1]), mi[i:i + 1], mu[i:i + 1], num_local_frames,
+                            interpolation, t_dilation) for i in range(b)]     # samples are independent (reference :319-372)
+        return torch.cat(outs, 0)

@@ -171,14 +171,16 @@ def _dev_index(ids, device):
 
 @torch.no_grad()
 def run_clip(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg: InferenceConfig, device, return_stages=False,
-             stage_hook=None):
+             stage_hook=None, gt_flows=None):
     """Whole path for one clip.  frames_u8 [L,H,W,3] uint8, masks [L,H,W] uint8 {0,255} (numpy or tensors).
     models = (RAFT_bi, RecurrentFlowCompleteNet, InpaintGenerator).  Returns uint8 tensor [L,H,W,3] on `device`.
-    ``stage_hook(name)`` (optional) is called at every stage boundary (bench.py records HIP events there)."""
+    ``stage_hook(name)`` (optional) is called at every stage boundary (bench.py records HIP events there).
+    ``gt_flows`` (optional): precomputed RAFT flows ``(flows_f, flows_b)`` each [L-1,2,H,W] (torch / numpy, e.g. read back
+    from the reference's ``.flo`` cache by ``flow_io.load_clip_flows``) -- stage A is skipped."""
     device = torch.device(device)
     if device.type == "cuda" and device.index is not None and device.index != torch.cuda.current_device():
         with torch.cuda.device(device):      # launches bind to the current device: make the clip's device current
-            return run_clip(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg, device, return_stages, stage_hook)
+            return run_clip(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg, device, return_stages, stage_hook, gt_flows)
     mark = stage_hook or (lambda name: None)
     fix_raft, fix_flow_complete, model = models
     to_t = lambda a: a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))
@@ -188,7 +190,13 @@ def run_clip(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg: InferenceC
     masks_dilated = to_t(masks_dilated_u8).to(device).float().div(255)[None, :, None]
     L = frames.size(1)
     mark('start')
-    gt_flows_bi = compute_flows(fix_raft, frames, cfg.raft_iter)
+    if gt_flows is None:
+        gt_flows_bi = compute_flows(fix_raft, frames, cfg.raft_iter)
+    else:
+        gt_flows_bi = tuple(to_t(f).to(device).float()[None] for f in gt_flows)
+        if any(f.shape != (1, L - 1, 2, frames.size(3), frames.size(4)) for f in gt_flows_bi):
+            raise ValueError(f"precomputed flows must be [L-1, 2, H, W] = [{L - 1}, 2, {frames.size(3)}, {frames.size(4)}]; "
+                             f"got {[tuple(f.shape[1:]) for f in gt_flows_bi]}")
     mark('raft')
     if cfg.fp16:                                                               # (:333-337)
         frames, flow_masks, masks_dilated = frames.half(), flow_masks.half(), masks_dilated.half()

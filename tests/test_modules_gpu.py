@@ -267,6 +267,51 @@ def test_logical_shards_on_one_gpu_match_the_unsharded_pass(models, fp16):
     assert torch.equal(out, ref), f"sharded pass differs in {(out != ref).float().mean().item():.3e} of bytes"
 
 
+def test_generator_nearest_interpolation_and_batch_of_two(models, sds):
+    """InpaintGenerator.forward(interpolation='nearest') (model/propainter.py:148,319) and b = 2 against the oracle."""
+    gen = models[2]
+    gq = torch.Generator().manual_seed(33)
+    H, W, t, lt = 64, 96, 4, 2
+    fr = torch.rand(2, t, 3, H, W, generator=gq) * 2 - 1
+    mk = torch.zeros(2, t, 1, H, W); mk[:, :, :, 8:40, 30:80] = 1
+    mu = torch.zeros(2, t, 1, H, W); mu[:, :, :, 16:30, 40:70] = 1
+    fl = (torch.randn(2, lt - 1, 2, H, W, generator=gq) * 2, torch.randn(2, lt - 1, 2, H, W, generator=gq) * 2)
+    ref = torch.cat([O.generator_forward(sds["gen"], (fr * (1 - mk))[i:i + 1], (fl[0][i:i + 1], fl[1][i:i + 1]), mk[i:i + 1], mu[i:i + 1], lt,
+                                         interpolation="nearest") for i in range(2)], 0)
+    out = gen((fr * (1 - mk)).cuda(), (fl[0].cuda(), fl[1].cuda()), mk.cuda(), mu.cuda(), lt, interpolation="nearest")
+    torch.cuda.synchronize()
+    assert out.shape == (2, lt, 3, H, W)
+    # nearest warps are discontinuous: a 1-ulp coordinate difference flips whole feature vectors at isolated pixels
+    d = (out.float().cpu() - ref).abs()
+    assert (d > 2e-3).float().mean().item() < 5e-3 and d.median().item() < 1e-4, (d.max().item(), (d > 2e-3).float().mean().item())
+    with pytest.raises(ValueError):
+        gen((fr * (1 - mk)).cuda()[:, :, :, :62], (fl[0].cuda()[..., :62, :], fl[1].cuda()[..., :62, :]), mk.cuda()[:, :, :, :62],
+            mu.cuda()[:, :, :, :62], lt)
+
+
+def test_cli_flow_cache_round_trip(tmp_path):
+    """--save_flow writes the RAFT flows in the reference's .flo format (PIEH, float16); --load_flow skips RAFT and, under
+    --fp16 (where the driver halves the flows anyway, inference_propainter.py:333-337), reproduces the frames bit for bit."""
+    import inference_propainter as cli
+    from PIL import Image
+    from propainter_amd.synthetic import synthetic_clip, synthetic_mask
+    L, H, W = 5, 128, 192
+    d = tmp_path / "clip"
+    d.mkdir()
+    for i, f in enumerate(synthetic_clip(L, H, W, seed=6)):
+        Image.fromarray(f).save(d / f"{i:05d}.png")
+    Image.fromarray(synthetic_mask(H, W)).save(tmp_path / "mask.png")
+    common = ["-i", str(d), "-m", str(tmp_path / "mask.png"), "--seeded_weights", "--fp16", "--save_frames", "--raft_iter", "3",
+              "--neighbor_length", "4", "--ref_stride", "3"]
+    cli.main(common + ["-o", str(tmp_path / "a"), "--save_flow", str(tmp_path / "flows")])
+    assert sorted(os.listdir(tmp_path / "flows")) == sorted([f"{i:05d}_{k}.flo" for i in range(L - 1) for k in "fb"])
+    cli.main(common + ["-o", str(tmp_path / "b"), "--load_flow", str(tmp_path / "flows")])
+    for i in range(L):
+        fa = np.asarray(Image.open(tmp_path / "a" / "clip" / "frames" / f"{i:04d}.png"))
+        fb = np.asarray(Image.open(tmp_path / "b" / "clip" / "frames" / f"{i:04d}.png"))
+        assert np.array_equal(fa, fb), i
+
+
 def test_cli_end_to_end_on_a_frame_folder(tmp_path):
     """inference_propainter.py (repo root) on a folder of PNG frames + a single mask image, seeded weights."""
     import inference_propainter as cli

@@ -22,6 +22,9 @@ FAMILIES = [   # (substring of the demangled OR mangled kernel name, family)
     ("conv_halo_kernel", "conv_gemm_f16 (LDS-DMA implicit GEMM)"),
     ("conv_ast_kernel", "conv_gemm_f16 (LDS-DMA implicit GEMM)"),
     ("conv_gemm_v2_kernel", "conv_gemm_f16 (LDS-DMA implicit GEMM)"),
+    ("conv_dcn_patch_kernel", "conv_gemm_dcn (patch-staged)"),
+    ("corr_otf_kernel", "corr_lookup_otf"),
+    ("corr_feature_pool", "corr_feature_pyramid"),
     ("conv_gemm_kernel<_Float16", "conv_gemm_f16/dcn (register-staged)"),
     ("conv_gemm_kernelIDF16_", "conv_gemm_f16/dcn (register-staged)"),
     ("conv_gemm_kernel<float", "conv_gemm_f32"),
