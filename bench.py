@@ -89,6 +89,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU-oracle sample (and with it the parity block)")
     ap.add_argument("--no-profile", action="store_true", help="skip the instrumented (per-kernel HIP events) step")
     ap.add_argument("--no-precisions", action="store_true", help="skip the extra timed steps at the other RAFT precisions")
+    ap.add_argument("--single-pass", action="store_true",
+                    help="profiling aid: run exactly ONE eager pass of the clip and exit (what the rocprofv3 passes of "
+                         "tools/gpu_profile.sh wrap, so that per-kernel counts are per pass)")
     ap.add_argument("--cpu-sample-frames", type=int, default=16, help="frames of the 432x240 CPU-oracle sample (about 10-25 s on 16 threads)")
     ap.add_argument("--cpu-baseline-worker", default=None, help=argparse.SUPPRESS)
     return ap.parse_args()
@@ -272,6 +275,11 @@ def main():
         comp = run_clip(models, frames_dev, masks_dev, masks_dev, cfg, dev, stage_hook=stage_hook)
         host_out.copy_(comp, non_blocking=True)
 
+    if args.single_pass:
+        eager_step()
+        torch.cuda.synchronize()
+        print(json.dumps({"single_pass": True, "height": H, "width": W, "frames": L, "raft_dtype": args.raft_dtype}))
+        return
     # ---- setup (untimed, like model load in the reference protocol): one eager pass builds the engines (weight
     # packing, K tables, window tables) and primes the allocator; by default the pass is then captured in a hipGraph
     eager_step()
