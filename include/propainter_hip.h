@@ -338,6 +338,13 @@ int pp_softcomp(const void* tokens, const void* emb_weight, const float* emb_bia
  * out = unfold(fold(in) / fold(ones)); in != out. */
 int pp_ffn_fold_unfold(const void* in, void* out, int BT, int C, int H, int W, int dtype, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Diagnostics (tuning tools only: tools/kbench.cpp, tools/bench_attn.py).  Read and clear the in-kernel phase counters of
+ * the PROF kernel builds (cycles summed over sampled waves); all zero unless a PP_DIAG=1 build ran a PROF variant.
+ * ---------------------------------------------------------------------------------------------- */
+int pp_debug_conv_prof(unsigned long long* out12);
+int pp_debug_attn_prof(unsigned long long* out8);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,6 +23,8 @@ LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libpropainter_hip.so")
 STAMP_PATH = os.path.join(LIB_DIR, "build_stamp.txt")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
+if os.environ.get("PP_DIAG") == "1":       # tuning builds: compiles the diagnostic / ablation kernel variants tools/kbench and
+    FLAGS.append("-DPP_DIAG")            # tools/bench_dcn.py select through pp_conv_args_t.impl (never in the shipped library)
 
 
 def sources():

@@ -107,7 +107,11 @@ __global__ __launch_bounds__(256, 2) void conv_dcn_patch_kernel(const ConvParams
     const int scs = s == 1 ? p.src[1].cstride : s == 2 ? p.src[2].cstride : s == 3 ? p.src[3].cstride : p.src[0].cstride;
     const int sco = (s == 1 ? p.src[1].choff : s == 2 ? p.src[2].choff : s == 3 ? p.src[3].choff : p.src[0].choff) + e0.w;
     __syncthreads();                                         // previous block's patch / offsets fully consumed
-    const int dbg = p.tap_w;                                 // [diagnostic] tools/bench_dcn.py ablations (impl 91..98): 0 in production
+#if defined(PP_DIAG)
+    const int dbg = p.tap_w;                                 // [diagnostic] tools/bench_dcn.py ablations (impl 91..105)
+#else
+    constexpr int dbg = 0;
+#endif
     // ---- stage (dy, dx) pairs / masks: 144 contiguous bytes per pixel (nine 16-byte loads) hold the offsets of OG channel
     //      blocks and the masks of MG channel blocks; loads of a thread are issued together (a rolled loop pays one memory
     //      latency per unit: measured 42 of the kernel's 121 us with 4- and 8-byte units)

@@ -559,7 +559,12 @@ extern "C" int pp_conv2d(const pp_conv_args_t* a, void* stream) {
     if (rc != -1000) return rc;
     PP_REQUIRE(a->impl < 10, PP_ERR_ARG, "pp_conv2d: impl %d not available for this shape", a->impl);
   }
-  if (a->dtype == PP_F16 && deform && (a->impl == 0 || (a->impl >= 90 && a->impl < 106))) {
+#if defined(PP_DIAG)
+  const bool dcn_impl = a->impl == 0 || (a->impl >= 90 && a->impl < 106);
+#else
+  const bool dcn_impl = a->impl == 0 || a->impl == 90;
+#endif
+  if (a->dtype == PP_F16 && deform && dcn_impl) {
     // patch-staged deformable kernel (16 offset groups of 8 / 16 channels, stride 1, 3x3)
     const int rc = conv_dcn_dispatch(p, st, a->impl >= 90 ? a->impl - 90 : 0);
     if (rc != -1000) return rc;

@@ -176,8 +176,11 @@ int conv_ast_dispatch(const ConvParams& p, int cfg, hipStream_t stream) {
   if ((long long)p.cout_pad * p.kchunks * 16 >= (1ll << 31) || p.M >= (1ll << 31)) return -1000;
   if (cfg == 0 && (p.cout_g < 256 || p.M < 128 * 256)) return -1000;       // needs enough couts to amortise the A load, enough rows to fill the GPU
   const unsigned nblk = (unsigned)((p.M + 127) / 128);
+#if defined(PP_DIAG)
   if (cfg == 81) hipLaunchKernelGGL((conv_ast_kernel<512, 1>), dim3(nblk), dim3(256), 0, stream, p);   // diagnostic: no epilogue
-  else hipLaunchKernelGGL((conv_ast_kernel<512>), dim3(nblk), dim3(256), 0, stream, p);
+  else
+#endif
+  hipLaunchKernelGGL((conv_ast_kernel<512>), dim3(nblk), dim3(256), 0, stream, p);
   return launch_status("pp_conv2d(ast)");
 }
 

@@ -440,6 +440,7 @@ int conv_v2_dispatch(const ConvParams& p, int cfg, hipStream_t stream) {
     case 40: return launch_v2<256, 16, 32, 4, 1, 4>(p, uni, stream);    // wave tile 64x16
     case 41: return launch_v2<256, 16, 32, 4, 1, 3>(p, uni, stream);
     case 42: return launch_v2<256, 16, 32, 4, 1, 2>(p, uni, stream);
+#if defined(PP_DIAG)      // tuning / diagnostic variants (tools/kbench, PP_DIAG=1 builds only; 60..68 are WRONG BY DESIGN: DMA-only / MFMA-only)
     // SCHED 1 variants (all fragment reads of a K step up front)
     case 50: return launch_v2<128, 128, 64, 2, 2, 2, 1>(p, uni, stream);
     case 51: return launch_v2<256, 128, 64, 4, 2, 3, 1>(p, uni, stream);
@@ -455,6 +456,7 @@ int conv_v2_dispatch(const ConvParams& p, int cfg, hipStream_t stream) {
     case 68: return launch_v2<128, 128, 32, 2, 2, 4, 3>(p, uni, stream);
     case 62: return launch_v2<256, 128, 64, 4, 2, 3, 2>(p, uni, stream);
     case 63: return launch_v2<256, 128, 64, 4, 2, 3, 3>(p, uni, stream);
+#endif
     default: return -1000;
   }
 }

@@ -317,6 +317,7 @@ int conv_v3_dispatch(const ConvParams& p, int cfg, hipStream_t stream) {
     if (kh == 5 && kw == 1) return launch_v3<16, 8, 5, 1, 16>(p, stream);
     return -1000;
   }
+#if defined(PP_DIAG)      // tuning / diagnostic variants (tools/kbench, PP_DIAG=1 builds only; measured in profiles/r2_conv_epilogue_ab.txt)
   if (cfg == 76 || cfg == 77) {   // staggered start (76) / + phase timing (77)
     if (kh == 3 && kw == 3) return cfg == 76 ? launch_v3<8, 16, 3, 3, 128, false, 1>(p, stream) : launch_v3<8, 16, 3, 3, 128, true, 2>(p, stream);
     if (kh == 1 && kw == 5) return cfg == 76 ? launch_v3<8, 16, 1, 5, 128, false, 1>(p, stream) : launch_v3<8, 16, 1, 5, 128, true, 2>(p, stream);
@@ -354,6 +355,7 @@ int conv_v3_dispatch(const ConvParams& p, int cfg, hipStream_t stream) {
     if (kh == 5 && kw == 1) return launch_v3<16, 8, 5, 1, 128, true>(p, stream);
     return -1000;
   }
+#endif
   if (kh == 3 && kw == 3) return n64 ? launch_v3<8, 16, 3, 3, 64>(p, stream) : launch_v3<8, 16, 3, 3, 128>(p, stream);
   if (kh == 1 && kw == 5) return n64 ? launch_v3<8, 16, 1, 5, 64>(p, stream) : launch_v3<8, 16, 1, 5, 128>(p, stream);
   if (kh == 5 && kw == 1) return n64 ? launch_v3<16, 8, 5, 1, 64>(p, stream) : launch_v3<16, 8, 5, 1, 128>(p, stream);
