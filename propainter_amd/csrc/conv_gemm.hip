@@ -547,7 +547,7 @@ extern "C" int pp_conv2d(const pp_conv_args_t* a, void* stream) {
     if (rc != -1000) return rc;
     PP_REQUIRE(a->impl == 0, PP_ERR_ARG, "pp_conv2d: impl 80 (A-stationary GEMM) not available for this shape");
   }
-  if (a->dtype == PP_F16 && !deform && (a->impl == 0 || (a->impl >= 70 && a->impl < 80) || a->impl == 83 || a->impl == 84)) {
+  if (a->dtype == PP_F16 && !deform && (a->impl == 0 || (a->impl >= 70 && a->impl < 80) || (a->impl >= 83 && a->impl <= 89))) {
     // halo-tile kernel family (stride-1 "same" 3x3 / 1x5 / 5x1 windows over 64-channel-multiple sources)
     const int rc = conv_v3_dispatch(p, a->impl, st);
     if (rc != -1000) return rc;

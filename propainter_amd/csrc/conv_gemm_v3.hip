@@ -38,12 +38,17 @@ static __device__ __forceinline__ void v3_dma16(__amdgpu_buffer_rsrc_t r, char* 
 // PROF: diagnostic build that accumulates s_memtime deltas per phase into pp_debug_conv_prof() (see tools/bench_conv.py)
 __device__ unsigned long long g_v3_prof[12];
 
-template <int TH, int TW, int KH, int KW, int BN, bool PROF = false, int STAGGER = 0>
-__global__ __launch_bounds__(TH * TW * 2) void conv_halo_kernel(const ConvParams p) {
+// WMT: pixel rows of a wave tile.  64 (default): 64 x 64 wave tiles, 4 waves per 128 x 128 block tile, 2 waves per SIMD.
+// 32: 32 x 64 wave tiles, 8 waves per block tile, FOUR waves per SIMD at <= 128 registers -- more LDS fragment traffic per
+// MFMA (0.75 vs 0.5 KB) for twice the latency hiding (ablations, tools/kbench impl 86..89: the phases of the 2-waves-per-SIMD
+// kernel barely overlap -- MFMA 75 + fragment reads 43 + DMA 38 + epilogue/sync 40 us of a 193 us launch).
+template <int TH, int TW, int KH, int KW, int BN, bool PROF = false, int STAGGER = 0, int WMT = 64>
+__global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : 1) void conv_halo_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef _Float16 T;
-  constexpr int BM = TH * TW;                                   // 128 px (4 waves, 2 blocks/CU) or 256 px (8 waves, 1 block/CU)
-  constexpr int NW = BM / 32, WAVES_N = BN >= 32 ? 2 : 1, WAVES_M = NW / WAVES_N;   // BN 16 (tiny cout): all waves along the pixels
+  constexpr int BM = TH * TW;                                   // 128 px (2 blocks/CU) or 256 px (8 waves, 1 block/CU)
+  constexpr int WAVES_N = BN >= 32 ? 2 : 1;                      // BN 16 (tiny cout): all waves along the pixels
+  constexpr int NW = BM / 32 * (64 / WMT), WAVES_M = NW / WAVES_N;
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 16, TN = WN / 16;
   constexpr int PH = TH + KH - 1, PW = TW + KW - 1, P = PH * PW;
@@ -208,8 +213,8 @@ __global__ __launch_bounds__(TH * TW * 2) void conv_halo_kernel(const ConvParams
       if constexpr (PROF) { pf_c = __builtin_readcyclecounter(); pf_wait += pf_c - pf_b; }
       if (t == 0 && have_next) v3_entry_ready(en);
       const bool more_b = ks + 1 < nk;
-      if constexpr (STAGGER != 3) { if (more_b) V3_ISSUE_B(ks + 1, par ^ 1); }
-      if (t < PPW && have_next) V3_ISSUE_PIECE(t, pnext, en);
+      if constexpr (STAGGER != 3 && STAGGER != 6 && STAGGER != 9) { if (more_b) V3_ISSUE_B(ks + 1, par ^ 1); }
+      if constexpr (STAGGER != 9) { if (t < PPW && have_next) V3_ISSUE_PIECE(t, pnext, en); }
       if constexpr (PROF) { pf_a = __builtin_readcyclecounter(); pf_issue += pf_a - pf_c; }
       const char* sb = bst0 + par * BSTAGE;
 #pragma unroll
@@ -219,19 +224,29 @@ __global__ __launch_bounds__(TH * TW * 2) void conv_halo_kernel(const ConvParams
         for (int f = 0; f < TM; ++f) {
           if (STAGGER == 4 && t > 0) {
             af[f] = afp[kk][f];
+          } else if constexpr (STAGGER == 8) {      // [ablation] no fragment reads
+            af[f] = f16x8{(_Float16)1, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)(float)f};
           } else {
             const int row = pp0[f] + sh;
             af[f] = *reinterpret_cast<const f16x8*>(pcur + row * 128 + (((kk * 4 + l4) ^ ((row >> 1) & 7)) << 4));
           }
         }
 #pragma unroll
-        for (int f = 0; f < TN; ++f)
-          bf[f] = *reinterpret_cast<const f16x8*>(sb + b_off + f * 16 * 128 + (((kk * 4 + l4) ^ bswz) << 4));
+        for (int f = 0; f < TN; ++f) {
+          if constexpr (STAGGER == 8) bf[f] = f16x8{(_Float16)1, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)(float)f};
+          else bf[f] = *reinterpret_cast<const f16x8*>(sb + b_off + f * 16 * 128 + (((kk * 4 + l4) ^ bswz) << 4));
+        }
+        if constexpr (STAGGER == 7) {               // [ablation] no MFMA: keep the fragments alive only
+#pragma unroll
+          for (int f = 0; f < TM; ++f) asm volatile("" ::"v"(af[f]));
+#pragma unroll
+          for (int f = 0; f < TN; ++f) asm volatile("" ::"v"(bf[f]));
+        }
 #pragma unroll
         for (int a = 0; a < TN; ++a) {
 #pragma unroll
           for (int b = 0; b < TM; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[a], af[b], acc[a][b], 0, 0, 0);
+            if constexpr (STAGGER != 7) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[a], af[b], acc[a][b], 0, 0, 0);
           if constexpr (STAGGER == 3) {
             // [variant] next step's weight DMA interleaved with the MFMA groups of kk == 0 (one instruction per group) instead
             // of a burst after the barrier: the TA queue is shared by 8 waves, a burst costs ~100 cycles per instruction
@@ -288,13 +303,13 @@ __global__ __launch_bounds__(TH * TW * 2) void conv_halo_kernel(const ConvParams
 #endif
 }
 
-template <int TH, int TW, int KH, int KW, int BN, bool PROF = false, int STAGGER = 0>
+template <int TH, int TW, int KH, int KW, int BN, bool PROF = false, int STAGGER = 0, int WMT = 64>
 static int launch_v3(ConvParams p, hipStream_t stream) {
   p.tiles_n = (p.cout_g + BN - 1) / BN;
   const long long tiles = (long long)p.N * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
   const long long nblk = tiles * p.tiles_n;
   if (nblk >= (1ll << 31)) return -1000;
-  hipLaunchKernelGGL((conv_halo_kernel<TH, TW, KH, KW, BN, PROF, STAGGER>), dim3((unsigned)nblk), dim3(TH * TW * 2), 0, stream, p);
+  hipLaunchKernelGGL((conv_halo_kernel<TH, TW, KH, KW, BN, PROF, STAGGER, WMT>), dim3((unsigned)nblk), dim3(TH * TW * 128 / WMT), 0, stream, p);
   return launch_status("pp_conv2d(v3)");
 }
 
@@ -318,6 +333,21 @@ int conv_v3_dispatch(const ConvParams& p, int cfg, hipStream_t stream) {
     return -1000;
   }
 #if defined(PP_DIAG)      // tuning / diagnostic variants (tools/kbench, PP_DIAG=1 builds only; measured in profiles/r2_conv_epilogue_ab.txt)
+  if (cfg == 85) {   // 8 waves of 32 x 64 per 128 x 128 block tile, 4 waves per SIMD
+    if (kh == 3 && kw == 3) return launch_v3<8, 16, 3, 3, 128, false, 0, 32>(p, stream);
+    if (kh == 1 && kw == 5) return launch_v3<8, 16, 1, 5, 128, false, 0, 32>(p, stream);
+    if (kh == 5 && kw == 1) return launch_v3<16, 8, 5, 1, 128, false, 0, 32>(p, stream);
+    return -1000;
+  }
+  if (cfg >= 86 && cfg <= 89) {   // ablations (WRONG RESULTS by design): 86 no weight DMA, 87 no MFMA, 88 no fragment reads, 89 no DMA
+    if (kh == 1 && kw == 5) {
+      if (cfg == 86) return launch_v3<8, 16, 1, 5, 128, false, 6>(p, stream);
+      if (cfg == 87) return launch_v3<8, 16, 1, 5, 128, false, 7>(p, stream);
+      if (cfg == 88) return launch_v3<8, 16, 1, 5, 128, false, 8>(p, stream);
+      return launch_v3<8, 16, 1, 5, 128, false, 9>(p, stream);
+    }
+    return -1000;
+  }
   if (cfg == 76 || cfg == 77) {   // staggered start (76) / + phase timing (77)
     if (kh == 3 && kw == 3) return cfg == 76 ? launch_v3<8, 16, 3, 3, 128, false, 1>(p, stream) : launch_v3<8, 16, 3, 3, 128, true, 2>(p, stream);
     if (kh == 1 && kw == 5) return cfg == 76 ? launch_v3<8, 16, 1, 5, 128, false, 1>(p, stream) : launch_v3<8, 16, 1, 5, 128, true, 2>(p, stream);
