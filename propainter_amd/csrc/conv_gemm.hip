@@ -541,8 +541,10 @@ extern "C" int pp_conv2d(const pp_conv_args_t* a, void* stream) {
                  PP_ERR_ALIGN, "pp_conv2d: PP_FUSE_GRU_H needs fuse_b (z), 16-byte aligned, cstride / choff multiples of 8");
   }
   hipStream_t st = (hipStream_t)stream;
-  if (a->dtype == PP_F16 && !deform && (a->impl == 0 || a->impl == 80 || a->impl == 81)) {
-    // A-stationary kernel for the short-K single-source linears (transformer GEMMs)
+  if (a->dtype == PP_F16 && !deform && (a->impl == 80 || a->impl == 81)) {
+    // A-stationary kernel for the short-K single-source linears (transformer GEMMs).  Selected explicitly only: with
+    // interleaved A/B rounds (tools/kbench, profiles/r2_conv_epilogue_ab.txt) the 256 x 128 LDS-DMA tile beats it by
+    // 7-25 % on the four transformer shapes (round 1 had measured +4 % for it on separate runs)
     const int rc = conv_ast_dispatch(p, a->impl, st);
     if (rc != -1000) return rc;
     PP_REQUIRE(a->impl == 0, PP_ERR_ARG, "pp_conv2d: impl 80 (A-stationary GEMM) not available for this shape");

@@ -26,7 +26,9 @@ extern "C" int pp_debug_conv_prof(unsigned long long* out);
   } while (0)
 
 static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static bool zero_fill = false;   // --zero: all-zero operands (DVFS probe: same instruction stream, less switching power)
 static float urand() {   // [-1, 1)
+  if (zero_fill) return 0.f;
   rng_state = rng_state * 6364136223846793005ull + 1442695040888963407ull;
   return (float)((rng_state >> 40) & 0xffffff) / 8388608.0f - 1.0f;
 }
@@ -72,6 +74,7 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--res")) res = true;
     else if (!strcmp(argv[i], "--prof")) prof = true;
     else if (!strcmp(argv[i], "--rounds")) rounds = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--zero")) zero_fill = true;
   }
   const int nsrc = (int)srcs.size();
   std::vector<int32_t> dy, dx, cpad(nsrc), creal(nsrc);
