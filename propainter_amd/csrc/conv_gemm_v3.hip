@@ -325,7 +325,8 @@ int conv_v3_dispatch(const ConvParams& p, int cfg, hipStream_t stream) {
   for (int i = 0; i < p.nsrc; ++i)
     if ((long long)p.N * p.H * p.W * p.src[i].cstride * 2 >= (1ll << 31)) return -1000;
   if (cfg == 0 && ((p.cout_g > 16 && p.cout_g < 48) || p.H < 8 || p.W < 8)) return -1000;      // 17..47 couts / tiny maps: v2's narrow tiles do better
-  const bool n64 = cfg == 72 || (cfg != 71 && p.cout_g <= 64);
+  // 64-cout tiles when the last 128-cout tile would be at most half full (cout 192 = 3 x 64: +5 % over 128 + 64-of-128, measured)
+  const bool n64 = cfg == 72 || (cfg != 71 && (p.cout_g <= 64 || (p.cout_g <= 192 && p.cout_g % 128 != 0 && p.cout_g % 128 <= 64)));
   if (cfg == 73 || (cfg == 0 && p.cout_g <= 16)) {   // tiny cout (flow head, RGB decoder): A-bandwidth bound, halo tiles cut the gather 6x
     if (kh == 3 && kw == 3) return launch_v3<8, 16, 3, 3, 16>(p, stream);
     if (kh == 1 && kw == 5) return launch_v3<8, 16, 1, 5, 16>(p, stream);

@@ -1,6 +1,8 @@
 cd $GRAFT_REPO_ROOT
 K=build/kbench
-$K conv 1 1 109140 1 1 1960 512 --impls 80,12,13,15,17 --reps 30 --rounds 2
-$K conv 1 1 109140 1 1 1536 512 --impls 80,12,13 --reps 30 --rounds 2
-$K conv 1 1 109140 1 1 512 512 --impls 80,12,13 --res --reps 30 --rounds 2
-$K conv 1 1 109140 1 1 6272 512 --impls 80,12,13 --reps 20 --rounds 2
+$K conv 16 90 160 3 3 192 256 --impls 70,71,72,12,13 --act 1 --reps 30 --rounds 2
+$K conv 16 90 160 3 3 126 192,64 --impls 70,71,72,12 --act 1 --reps 30 --rounds 2
+$K conv 16 90 160 1 1 256 328 --impls 0,12,13,22 --act 1 --reps 30 --rounds 2
+$K conv 1 180 320 3 3 128 128,128,8 --impls 0,12,13,22 --act 2 --reps 50 --rounds 2
+$K conv 1 180 320 3 3 432 128 --impls 70,71,72,12 --reps 50 --rounds 2
+$K conv 2 360 640 3 3 64 64 --impls 0,70,72,12,22 --act 2 --reps 30 --rounds 2
