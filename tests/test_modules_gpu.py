@@ -289,6 +289,36 @@ def test_generator_nearest_interpolation_and_batch_of_two(models, sds):
             mu.cuda()[:, :, :, :62], lt)
 
 
+# measured on MI355X (profiles/r2_parity_e2e.json): floors 3 dB under
+BMX_PSNR_FLOOR = {False: 60.0, True: 45.0}
+
+
+@pytest.mark.parametrize("fp16", [False, True], ids=["f32", "f16"])
+def test_real_frames_bmx_trees_vs_oracle_golden(models, fp16):
+    """BASELINE config 1 on real frames: 8 frames of the reference's bmx-trees sample (432x240 JPEGs, per-frame object
+    masks, dilation 4) with the reference's default settings (raft_iter 20, neighbor_length 10, ref_stride 10) against the
+    fp32 CPU oracle's composite (tests/golden/bmx_trees_432x240x8.npz, oracle/make_golden_bmx.py)."""
+    from propainter_amd.pipeline import InferenceConfig, run_clip
+    g = load_golden("bmx_trees_432x240x8.npz")
+    fr, fm, md = g["frames_u8"], g["flow_masks_u8"], g["masks_u8"]
+    ref = fr.copy()
+    ref[md > 0] = g["comp_hole"]
+    cfg = InferenceConfig(raft_iter=int(g["raft_iter"]), subvideo_length=int(g["subvideo_length"]),
+                          neighbor_length=int(g["neighbor_length"]), ref_stride=int(g["ref_stride"]), fp16=fp16)
+    raft = models[0]
+    raft.precision = "f16" if fp16 else "f32"
+    try:
+        comp = run_clip(models, fr, fm, md, cfg, torch.device("cuda")).cpu().numpy()
+    finally:
+        raft.precision = None
+    assert np.array_equal(comp[md == 0], fr[md == 0])
+    psnr = O.psnr(comp, ref)
+    hole = md > 0
+    d = np.abs(comp[hole].astype(int) - ref[hole].astype(int))
+    print(f"BMX_PARITY fp16={fp16} psnr={psnr:.2f} hole_bytes_differ={(d > 0).mean():.3e} max_abs={d.max()}")
+    assert psnr > BMX_PSNR_FLOOR[fp16], psnr
+
+
 def test_cli_flow_cache_round_trip(tmp_path):
     """--save_flow writes the RAFT flows in the reference's .flo format (PIEH, float16); --load_flow skips RAFT and, under
     --fp16 (where the driver halves the flows anyway, inference_propainter.py:333-337), reproduces the frames bit for bit."""
