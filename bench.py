@@ -89,6 +89,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU-oracle sample (and with it the parity block)")
     ap.add_argument("--no-profile", action="store_true", help="skip the instrumented (per-kernel HIP events) step")
     ap.add_argument("--no-precisions", action="store_true", help="skip the extra timed steps at the other RAFT precisions")
+    ap.add_argument("--window-streams", type=int, default=2,
+                    help="generator windows in flight on separate HIP streams (pipeline.InferenceConfig.window_streams)")
     ap.add_argument("--single-pass", action="store_true",
                     help="profiling aid: run exactly ONE eager pass of the clip and exit (what the rocprofv3 passes of "
                          "tools/gpu_profile.sh wrap, so that per-kernel counts are per pass)")
@@ -240,7 +242,8 @@ def main():
     fp16 = not args.fp32
     models = seeded_models(dev, raft_precision=args.raft_dtype)
     cfg = InferenceConfig(raft_iter=args.raft_iter, subvideo_length=args.subvideo_length,
-                          neighbor_length=args.neighbor_length, ref_stride=args.ref_stride, fp16=fp16)
+                          neighbor_length=args.neighbor_length, ref_stride=args.ref_stride, fp16=fp16,
+                          window_streams=args.window_streams)
     m = scipy.ndimage.binary_dilation(synthetic_mask(H, W), iterations=4).astype(np.uint8) * 255
     sharded = bool(args.sharded)
     exchange_stats = {}
@@ -447,7 +450,8 @@ def main():
             "dtype": "f16" if fp16 else "f32",
             "data": "synthetic (seeded clip + rectangular mask dilated x4, seeded weights of the reference architecture)",
             "config": {"workload": work, "height": H, "width": W, "frames": L, "windows": len(sched),
-                       "raft_dtype": args.raft_dtype, "stages_dtype": "f16" if fp16 else "f32", "parallelism": par},
+                       "raft_dtype": args.raft_dtype, "stages_dtype": "f16" if fp16 else "f32", "parallelism": par,
+                       "window_streams": args.window_streams},
             "roofline": roof, "cpu_baseline": cpu, "parity": parity, "raft_precisions": raft_precisions,
             "memory": {"peak_allocated_GB_eager_pass": peak_eager / 1e9, "peak_allocated_GB_process": peak_total / 1e9,
                        "note": "torch.cuda.max_memory_allocated; the eager pass is what a one-shot CLI run needs, the process "
