@@ -247,7 +247,6 @@ def test_clip_graph_replay_is_bit_identical_to_eager(models, fp16):
         assert torch.equal(out, eager), f"graph replay differs from eager in {(out != eager).float().mean().item():.3e} of bytes"
 
 
-@pytest.mark.parametrize("fp16", [False, True], ids=["f32", "f16"])
 def test_window_streams_are_bit_identical(models):
     """Generator windows on 1 / 2 / 3 concurrent HIP streams (pipeline.InferenceConfig.window_streams): same kernels on the
     same data, blended in the same order -> identical bytes, eager and as a captured hipGraph with parallel branches."""
