@@ -121,10 +121,16 @@ typedef struct {
    * fuse == PP_FUSE_GRU_ZR (cout_g = 2C, fuse_split = C): co <  C: out[pixel, out_choff + co]      = v           (z)
    *                                                       co >= C: out2[pixel, out2_choff + co - C] = v * a[co-C] (r*h)
    * fuse == PP_FUSE_GRU_H  (cout_g = C):  out[pixel, out_choff + co] = (1 - b[co]) * a[co] + b[co] * v    (new h)
-   *   with a = fuse_a (h), b = fuse_b (z), NHWC windows of dtype; `out` may alias fuse_a (element-wise in place).   */
+   *   with a = fuse_a (h), b = fuse_b (z), NHWC windows of dtype; `out` may alias fuse_a (element-wise in place).
+   * fuse == PP_FUSE_DCN_OFFMASK (act == PP_ACT_NONE; the conv_offset head of DeformableAlignment, model/propainter.py:57-65 and
+   *   model/recurrent_flow_completion.py:31-40): co <  fuse_split: out = act_param * tanh(v) + flow[pixel, (co & 1) ? x : y]
+   *                                              co >= fuse_split: out = sigmoid(v)
+   *   act_param = max_residue_magnitude; fuse_a = optional flow window (NHWC, dtype, channels fuse_a_choff = x, +1 = y,
+   *   fuse_a_choff even; NULL = no flow term); fuse_split even.  Same result as pp_dcn_offset_mask_act on the plain output
+   *   (bit-identical for fp32; for fp16 the intermediate rounding of the plain output is skipped).                      */
   const void* preadd;
   int32_t preadd_cstride, preadd_choff;
-  int32_t fuse;                  /* PP_FUSE_NONE / PP_FUSE_GRU_ZR / PP_FUSE_GRU_H                                 */
+  int32_t fuse;                  /* PP_FUSE_NONE / PP_FUSE_GRU_ZR / PP_FUSE_GRU_H / PP_FUSE_DCN_OFFMASK           */
   int32_t fuse_split;
   const void* fuse_a;
   int32_t fuse_a_cstride, fuse_a_choff;
@@ -137,6 +143,7 @@ typedef struct {
 #define PP_FUSE_NONE 0
 #define PP_FUSE_GRU_ZR 1
 #define PP_FUSE_GRU_H 2
+#define PP_FUSE_DCN_OFFMASK 3  /* offset / modulation-mask head of a deformable alignment (see pp_conv_args_t.fuse) */
 
 /* Host helper: fill `out` (kchunks_padded x 4 int32) for `ntaps` taps (dy[i], dx[i] are input
  * offsets added to out*stride - pad) over `nsrc` sources of src_channels[i] channels each (each a
@@ -210,6 +217,14 @@ int pp_corr_lookup(const float* lvl0, const float* lvl1, const float* lvl2, cons
 int pp_corr_feature_pyramid(const void* f2, void* lvl1, void* lvl2, void* lvl3, int P, int h, int w, void* stream);
 int pp_corr_lookup_otf(const void* f1, const void* f2_lvl0, const void* f2_lvl1, const void* f2_lvl2, const void* f2_lvl3,
                        const float* coords, void* out, int out_cstride, int out_cpad, int P, int h, int w, void* stream);
+
+/* Input of the motion encoder's 7x7 flow convolution (RAFT/update.py:85,92: convf1 = Conv2d(2, 128, 7, padding=3)) laid out so
+ * that the convolution needs K = 7 x 16 instead of 49 taps x 8 padded channels: rows[pixel, 2*kx + c] = flow_c(x + kx - 3, y)
+ * (zero outside the image row; channels 14, 15 zero), flow = coords1 - coords0 in fp32, rounded to `dtype`.  The layer is then
+ * a 7x1 convolution over the 16 channels with weights w'[co, 2*kx + c, ky] = w[co, c, ky, kx].  Optionally the same flow is also
+ * written to flow_out[pixel, flow_choff .. +1] (the GRU input window).  rows: NHWC [P,h,w,16] of dtype.                        */
+int pp_raft_flow_taps(const float* coords1, const float* coords0, void* rows, void* flow_out, int flow_cstride, int flow_choff,
+                      int P, int h, int w, int dtype, void* stream);
 
 /* convex 8x upsampling: flow fp32 NHWC [B,h,w,2]; mask NHWC [B,h,w,576] (channel k*64 + i*8 + j, already
  * scaled by 0.25); out fp32 planar [B,2,8h,8w]. */

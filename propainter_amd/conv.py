@@ -72,6 +72,10 @@ def pack_weight(weight, src_channels, groups=1, ktable=None):
     return packed, K, cout_g
 
 
+def pconv_act_none(act):
+    return act is None or ACTS[act] == hip.ACT_NONE
+
+
 class ConvLayer:
     """One convolution / linear layer prepared for pp_conv2d (weights packed once, on the device)."""
 
@@ -122,7 +126,8 @@ class ConvLayer:
         preadd: tensor or (tensor, choff) added to (acc + bias) * out_scale BEFORE the activation (a partial sum another
         convolution computed ahead of time).  fuse: fused SepConvGRU gating (pp_conv_args_t.fuse), one of
           dict(kind="gru_zr", h=(t, choff), out2=(t, choff), split=C)   out <- z = act(v)[:C], out2 <- act(v)[C:] * h
-          dict(kind="gru_h", h=(t, choff), z=(t, choff))                 out <- (1 - z) * h + z * act(v)"""
+          dict(kind="gru_h", h=(t, choff), z=(t, choff))                 out <- (1 - z) * h + z * act(v)
+          dict(kind="dcn_om", mag=m, flow=(t, choff) | None, split=288)  out <- m * tanh(v[:split]) + flow(y, x) | sigmoid(v[split:])"""
         srcs = [(s, 0) if torch.is_tensor(s) else s for s in srcs]
         assert len(srcs) == len(self.src_channels), (len(srcs), self.src_channels)
         x0 = srcs[0][0]
@@ -166,7 +171,15 @@ class ConvLayer:
             t, co = win(preadd)
             assert t.dtype == self.dtype and t.is_contiguous() and t.shape[:3] == (N, OH, OW)
             a.preadd, a.preadd_cstride, a.preadd_choff = t.data_ptr(), t.shape[-1], co
-        if fuse is not None:
+        if fuse is not None and fuse["kind"] == "dcn_om":
+            # offset / mask head of a deformable alignment: mag * tanh(offsets) + flow | sigmoid(masks) in the epilogue
+            assert pconv_act_none(act) and out.dtype == self.dtype and preadd is None and residual is None
+            a.fuse, a.fuse_split, a.act_param = hip.FUSE_DCN_OFFMASK, int(fuse.get("split", 288)), float(fuse["mag"])
+            if fuse.get("flow") is not None:
+                (ft, fc) = win(fuse["flow"])
+                assert ft.dtype == self.dtype and ft.is_contiguous() and ft.shape[:3] == (N, OH, OW) and fc % 2 == 0
+                a.fuse_a, a.fuse_a_cstride, a.fuse_a_choff = ft.data_ptr(), ft.shape[-1], fc
+        elif fuse is not None:
             (ht, hc) = win(fuse["h"])
             assert ht.dtype == self.dtype and ht.is_contiguous() and out.dtype == self.dtype
             a.fuse_a, a.fuse_a_cstride, a.fuse_a_choff = ht.data_ptr(), ht.shape[-1], hc

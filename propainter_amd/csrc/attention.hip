@@ -12,7 +12,8 @@
 //   S^T = K Q^T   (v_mfma_f32_16x16x32_f16: A = K rows from LDS, B = Q fragments held in registers)
 //   -> every lane owns 16 scores of ONE query, so the row max/sum need only two cross-lane shuffles;
 //   O^T += V^T P^T  with P^T taken directly from the score accumulators (keys of a 32-key step are
-//   relabelled so that no data movement is needed) and V staged transposed in LDS.
+//   relabelled so that no data movement is needed); V is staged ROW-major and its fragments come out of
+//   ds_read_b64_tr_b16 (gfx950's transposing LDS read).
 // attn_ref_kernel (any dtype): one wave per query, fp32 math; the parity path for fp32 and the
 //   on-device cross-check of the MFMA kernel.
 #include "common.h"
@@ -91,27 +92,44 @@ __global__ __launch_bounds__(256) void attn_ref_kernel(const AttnParams p) {
 }
 
 constexpr int KT = 64;          // keys per tile
-constexpr int KS_LD = HD + 8;   // K tile row stride (elements): 272 B rows, conflict-free ds_read_b128 / ds_write_b128
-constexpr int VT_LD = KT + 8;   // V^T tile row stride (elements): 144-byte rows keep the 16-byte fragment reads aligned
+constexpr int KS_LD = HD;       // K tile row stride (elements): 256-byte rows, 16-byte slots XOR-swizzled by the key row
+constexpr int VS_LD = HD + 4;   // V tile row stride (elements): 264-byte rows (8-byte skew per key row for the transposing reads)
+
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __fp16 fp16v4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef __attribute__((address_space(3))) fp16v4 lds_fp16v4;
+// ds_read_b64_tr_b16: within each group of 16 lanes, lane i supplies the address of 4 consecutive fp16 (row i / 4, column
+// chunk i % 4 of a [4][16] block) and receives column i of that block (4 values, one per row).
+static __device__ __forceinline__ f16x4 lds_read_tr16(const _Float16* p) {
+  return __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16v4*)p));
+}
+#else
+static __device__ __forceinline__ f16x4 lds_read_tr16(const _Float16*) { return f16x4{}; }   // host pass of the same source
+#endif
 
 // Flash-style MFMA kernel.  256 threads = 4 waves; every wave owns QT tiles of 16 queries (QT = 2 -> 128 queries per
 // block for masked windows, whose long key lists dominate the work; QT = 1 -> 64 >= 45 queries for the per-frame
 // self attention of unmasked windows).  The masked / unmasked decision is a device flag, so BOTH instantiations are
 // launched over all windows and each block exits at once if the window is of the other kind (no host sync).
 //
-// Per 64-key tile: K rows are staged row-major; V is staged TRANSPOSED (the PV MFMA wants 8 keys per lane for one
-// channel).  The transposing scalar writes were 16-way bank conflicted with a natural [channel][key] image, so the
-// channel rows are permuted, row(d) = (d % 8) * 16 + d / 8, with a 34-dword row stride: the 16 channel-chunk lanes of a
-// write instruction now hit 16 different banks (2-way at worst from the 2-byte key pairs) and the ds_read_b64
-// fragment reads stay conflict-free (bank = 34*i + 2*g mod 64 is injective over the 32-lane group).  A side effect of
-// the permutation: accumulator row i of tile dt is channel i*8 + dt, so every lane ends with 8 consecutive channels
-// per query -> 16-byte output stores.  Global loads of tile k+1 are issued before the MFMAs of tile k (register
-// prefetch), hiding the gather latency behind the matrix work.
+// Per 64-key tile both K and V rows are staged row-major with 16-/8-byte stores (round 1 staged V transposed with 32
+// ds_write_b16 per lane and tile: rocprofv3 SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.44 for this kernel, the
+// LDS array busier than the matrix pipe).
+//   K tile [64 keys][256 B], 16-byte slot ^ (key & 15): the QK fragments (16 key rows starting at a multiple of 16) are
+//     conflict-free under ds_read_b128's lane groups (tools/lds_swizzle_check.py), and so are the 8-lane store groups.
+//   V tile [64 keys][264 B]: the PV operand (8 keys of ONE channel per lane) is read with ds_read_b64_tr_b16: the 16 lanes
+//     of a group hand in the 8-byte pieces of a [4 keys][16 channels] block (lane i: key i / 4, channels 4 * (i % 4) ..)
+//     and lane i receives column i.  The 16 columns of tile dt are the channels m * 32 + dt * 4 + e (m = 0..3, e = 0..3),
+//     so accumulator row i of tile dt is channel (i / 4) * 32 + dt * 4 + i % 4 and every lane ends up with 32 CONSECUTIVE
+//     channels of its query -> 16-byte output stores.  The 8-byte row skew (264 = 256 + 8) spreads the 8 key rows x 4
+//     pieces of a 32-lane half over all 64 banks.
+// Global loads of tile k+1 are issued before the MFMAs of tile k (register prefetch), hiding the gather latency behind
+// the matrix work.
 __device__ unsigned long long g_attn_prof[8];
 
 template <int QT, bool MASKED, bool PROF>
 __device__ __forceinline__ void attn_block(const AttnParams& p, const int b, const int w, const int head, const int yb,
-                                           _Float16* Ks, _Float16* Vt, int* idx_lds, int* tind_lds) {
+                                           _Float16* Ks, _Float16* Vs, int* idx_lds, int* tind_lds) {
   typedef _Float16 T;
   constexpr int QB = 64 * QT;                                  // queries per block
   const int nq_total = p.T * p.wsz;
@@ -181,37 +199,42 @@ __device__ __forceinline__ void attn_block(const AttnParams& p, const int b, con
   const long long qkv_cs = p.qkv_cs, pkv_cs = p.pkv_cs;
   const long long frame_tok = (long long)p.Hp * p.Wp, frame_pool = p.P;
   const int hoff = head * HD;
-  auto load_tile = [&](int fi, int r0) {                       // keys r0 .. r0+63 of key frame #fi (no division, no global index reads)
+  // one quarter (16 keys) of the next tile: 2 x 16-byte loads per lane.  The quarters are issued between the QK MFMA groups of
+  // the current tile: issued back to back by all 8 waves of a CU right after the barrier, the 64 KB of a tile pair queue on
+  // the CU's one address unit (64 B/clk) and every wave sat in the issue for ~1.2 k cycles (in-kernel stamps, tools/bench_attn.py)
+  auto load_part = [&](int fi, int r0, int i) {                 // keys r0 .. r0+63 of key frame #fi (no division, no global index reads)
     const int f = MASKED ? tind_lds[fi] : frame_blk;
     const long long bf = (long long)b * p.T + f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = tid + 256 * i;
-      const int key = c >> 4, dch = c & 15;
-      const int r = r0 + key;
-      kr[i] = u32x4{0, 0, 0, 0};
-      vr[i] = u32x4{0, 0, 0, 0};
-      if (r < kpf) {
-        const bool grid = r < ngrid;
-        const long long row = grid ? bf * frame_tok + idx_lds[grid ? r : 0] : bf * frame_pool + (r - ngrid);
-        const long long eoff = row * (grid ? qkv_cs : pkv_cs) + hoff + dch * 8;
-        kr[i] = *reinterpret_cast<const u32x4*>((grid ? kg : pkg) + eoff);
-        vr[i] = *reinterpret_cast<const u32x4*>((grid ? vg : pvg) + eoff);
-      }
+    const int c = tid + 256 * i;
+    const int key = c >> 4, dch = c & 15;
+    const int r = r0 + key;
+    kr[i] = u32x4{0, 0, 0, 0};
+    vr[i] = u32x4{0, 0, 0, 0};
+    if (r < kpf) {
+      const bool grid = r < ngrid;
+      const long long row = grid ? bf * frame_tok + idx_lds[grid ? r : 0] : bf * frame_pool + (r - ngrid);
+      const long long eoff = row * (grid ? qkv_cs : pkv_cs) + hoff + dch * 8;
+      kr[i] = *reinterpret_cast<const u32x4*>((grid ? kg : pkg) + eoff);
+      vr[i] = *reinterpret_cast<const u32x4*>((grid ? vg : pvg) + eoff);
     }
+  };
+  auto load_tile = [&](int fi, int r0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) load_part(fi, r0, i);
   };
   auto store_tile = [&]() {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int c = tid + 256 * i;
       const int key = c >> 4, dch = c & 15;
-      *reinterpret_cast<u32x4*>(&Ks[key * KS_LD + dch * 8]) = kr[i];
-      const T* ve = reinterpret_cast<const T*>(&vr[i]);
-      // key column permuted so that the 8 keys one lane feeds to a PV MFMA (32j + g*4 + {0..3} and 32j + 16 + g*4 + {0..3})
-      // are 16 contiguous bytes: slot = 32j + g*8 + hi*4 + i for key = 32j + hi*16 + g*4 + i  -> one ds_read_b128 per fragment
-      const int kslot = (key & 32) | ((key & 12) << 1) | ((key & 16) >> 2) | (key & 3);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) Vt[(j * 16 + dch) * VT_LD + kslot] = ve[j];    // channel dch*8 + j -> row j*16 + dch
+      *reinterpret_cast<u32x4*>(&Ks[key * KS_LD + ((dch ^ (key & 15)) << 3)]) = kr[i];
+      // two 8-byte stores (the skewed rows are only 8-byte aligned); the halves are written in opposite order by the lanes
+      // of chunks 0-7 and 8-15 so that the 16 lanes of a ds_write_b64 group cover 16 different 8-byte bank pairs
+      const int sel = dch >> 3;
+      const u32x2 lo = {vr[i][0], vr[i][1]}, hi = {vr[i][2], vr[i][3]};
+      T* vrow = &Vs[key * VS_LD + dch * 8];
+      *reinterpret_cast<u32x2*>(vrow + sel * 4) = sel ? hi : lo;
+      *reinterpret_cast<u32x2*>(vrow + (sel ^ 1) * 4) = sel ? lo : hi;
     }
   };
 
@@ -227,7 +250,7 @@ __device__ __forceinline__ void attn_block(const AttnParams& p, const int b, con
     if constexpr (PROF) { tb = __builtin_readcyclecounter(); pf[0] += tb - ta; }
     __syncthreads();
     if constexpr (PROF) { ta = __builtin_readcyclecounter(); pf[1] += ta - tb; }
-    if (ti + 1 < ntiles) load_tile(fi_n, r0_n);         // in flight during the MFMAs below
+    const bool more = ti + 1 < ntiles;                  // next tile: its four quarters are requested inside the kt loop below
     if constexpr (PROF) { tb = __builtin_readcyclecounter(); pf[2] += tb - ta; }
 
     // ---- S^T tiles: sacc[qt][kt][r] = score(key = k0 + kt*16 + (lane>>4)*4 + r, query = lane&15 of tile qt)
@@ -236,10 +259,11 @@ __device__ __forceinline__ void attn_block(const AttnParams& p, const int b, con
     for (int kt = 0; kt < 4; ++kt) {
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) sacc[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const T* kp = &Ks[(kt * 16 + (lane & 15)) * KS_LD + (lane >> 4) * 8];
+      const T* kp = &Ks[(kt * 16 + (lane & 15)) * KS_LD];
+      if (more) load_part(fi_n, r0_n, kt);              // in flight during the MFMAs
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const f16x8 kf = *reinterpret_cast<const f16x8*>(kp + s * 32);
+        const f16x8 kf = *reinterpret_cast<const f16x8*>(kp + (((s * 4 + (lane >> 4)) ^ (lane & 15)) << 3));
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) sacc[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qt][s], sacc[qt][kt], 0, 0, 0);
       }
@@ -291,12 +315,15 @@ __device__ __forceinline__ void attn_block(const AttnParams& p, const int b, con
     }
     if constexpr (PROF) { tb = __builtin_readcyclecounter(); pf[4] += tb - ta; }
     // ---- O^T += V^T P^T : k-slot (lane>>4)*8 + i of step j <-> key 32j + (i>>2)*16 + (lane>>4)*4 + (i&3);
-    // accumulator row i of tile dt is channel i*8 + dt (row permutation of the V^T image)
+    // accumulator row i of tile dt is channel (i/4)*32 + dt*4 + i%4 (column order of the transposing reads)
+    const T* vbase = &Vs[((lane >> 4) * 4 + ((lane & 15) >> 2)) * VS_LD + (lane & 3) * 32];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
 #pragma unroll
       for (int dt = 0; dt < 8; ++dt) {
-        const f16x8 vf = *reinterpret_cast<const f16x8*>(&Vt[(dt * 16 + (lane & 15)) * VT_LD + 32 * j + (lane >> 4) * 8]);
+        const f16x4 v0 = lds_read_tr16(vbase + (32 * j) * VS_LD + dt * 4);
+        const f16x4 v1 = lds_read_tr16(vbase + (32 * j + 16) * VS_LD + dt * 4);
+        const f16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) oacc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pfr[qt][j], oacc[qt][dt], 0, 0, 0);
       }
@@ -318,14 +345,17 @@ __device__ __forceinline__ void attn_block(const AttnParams& p, const int b, con
     l += __shfl_xor(l, 32);
     if (qvalid[qt]) {
       const float inv = 1.f / l;
-      // lane holds rows i = (lane>>4)*4 + r of every tile dt -> channels i*8 + dt: 8 consecutive channels per r
+      // lane holds rows (lane>>4)*4 + r of every tile dt -> channels (lane>>4)*32 + dt*4 + r: 32 consecutive channels
       T* op = reinterpret_cast<T*>(p.out) + qoff[qt] * p.C + head * HD + (lane >> 4) * 32;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
+      for (int d2 = 0; d2 < 4; ++d2) {
         f16x8 o;
 #pragma unroll
-        for (int dt = 0; dt < 8; ++dt) o[dt] = (_Float16)(oacc[qt][dt][r] * inv);
-        *reinterpret_cast<f16x8*>(op + r * 8) = o;
+        for (int r = 0; r < 4; ++r) {
+          o[r] = (_Float16)(oacc[qt][2 * d2][r] * inv);
+          o[4 + r] = (_Float16)(oacc[qt][2 * d2 + 1][r] * inv);
+        }
+        *reinterpret_cast<f16x8*>(op + d2 * 8) = o;
       }
     }
   }
@@ -336,7 +366,7 @@ __device__ __forceinline__ void attn_block(const AttnParams& p, const int b, con
 template <int QT, bool MASKED, bool PROF = false>
 __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnParams p) {
   __shared__ __attribute__((aligned(16))) _Float16 Ks[KT * KS_LD];
-  __shared__ __attribute__((aligned(16))) _Float16 Vt[HD * VT_LD];
+  __shared__ __attribute__((aligned(16))) _Float16 Vs[KT * VS_LD];
   __shared__ int idx_lds[256];
   __shared__ int tind_lds[64];
   const int head = blockIdx.x % p.heads;
@@ -344,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnParams p) {
   const int b = blockIdx.x / (p.heads * p.nW);
   const bool masked = p.wmask[b * p.nW + w] > 0.f;
   if (masked != MASKED) return;                                // the other instantiation owns this window
-  attn_block<QT, MASKED, PROF>(p, b, w, head, (int)blockIdx.y, Ks, Vt, idx_lds, tind_lds);
+  attn_block<QT, MASKED, PROF>(p, b, w, head, (int)blockIdx.y, Ks, Vs, idx_lds, tind_lds);
 }
 
 // Persistent launch for the masked windows (the long key lists: ~all of the attention time).  With the grid-mapped
@@ -354,7 +384,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnParams p) {
 template <int QT, bool PROF = false>
 __global__ __launch_bounds__(256, 2) void attn_mfma_persistent_kernel(const AttnParams p, const int gy) {
   __shared__ __attribute__((aligned(16))) _Float16 Ks[KT * KS_LD];
-  __shared__ __attribute__((aligned(16))) _Float16 Vt[HD * VT_LD];
+  __shared__ __attribute__((aligned(16))) _Float16 Vs[KT * VS_LD];
   __shared__ int idx_lds[256];
   __shared__ int tind_lds[64];
   const int total = p.work[0] * p.heads * gy;
@@ -363,7 +393,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_persistent_kernel(const Attn
     const int wh = item / gy;
     const int head = wh % p.heads;
     const int bw = p.work[1 + wh / p.heads];
-    attn_block<QT, true, PROF>(p, bw / p.nW, bw % p.nW, head, yb, Ks, Vt, idx_lds, tind_lds);
+    attn_block<QT, true, PROF>(p, bw / p.nW, bw % p.nW, head, yb, Ks, Vs, idx_lds, tind_lds);
     __syncthreads();                                           // the LDS tables are rewritten by the next item
   }
 }

@@ -139,6 +139,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc_)
   const bool res_vec = has_res && !late && nval == 8 && ((p.res_cstride | res_cbase) & 7) == 0;
   const bool zr_r = p.fuse == PP_FUSE_GRU_ZR && co >= p.fuse_split;
   const bool gh = p.fuse == PP_FUSE_GRU_H;
+  const bool om_flow = p.fuse == PP_FUSE_DCN_OFFMASK && p.fuse_a != nullptr && co < p.fuse_split;   // offsets: + flow (x, y) of the pixel
   constexpr int NQ = PREFETCH ? NP : 1;
   u32x4 q0[NQ], q1[NQ], q2[NQ];                     // [preadd | residual], h, z
   if (PREFETCH && (late || has_res)) {
@@ -150,6 +151,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc_)
       if (pre_vec) q0[pass] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.preadd) + m * p.preadd_cstride + p.preadd_choff + co);
       if (res_vec) q0[pass] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.residual) + m * p.res_cstride + res_cbase + co);
       if (zr_r) q1[pass] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.fuse_a) + m * p.fuse_a_cstride + p.fuse_a_choff + co - p.fuse_split);
+      if (om_flow) q1[pass][0] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const T*>(p.fuse_a) + m * p.fuse_a_cstride + p.fuse_a_choff);
       if (gh) {
         q1[pass] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.fuse_a) + m * p.fuse_a_cstride + p.fuse_a_choff + co);
         q2[pass] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.fuse_b) + m * p.fuse_b_cstride + p.fuse_b_choff + co);
@@ -173,6 +175,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc_)
       if (pre_vec) q0[0] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.preadd) + m * p.preadd_cstride + p.preadd_choff + co);
       if (res_vec) q0[0] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.residual) + m * p.res_cstride + res_cbase + co);
       if (zr_r) q1[0] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.fuse_a) + m * p.fuse_a_cstride + p.fuse_a_choff + co - p.fuse_split);
+      if (om_flow) q1[0][0] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const T*>(p.fuse_a) + m * p.fuse_a_cstride + p.fuse_a_choff);
       if (gh) {
         q1[0] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.fuse_a) + m * p.fuse_a_cstride + p.fuse_a_choff + co);
         q2[0] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.fuse_b) + m * p.fuse_b_cstride + p.fuse_b_choff + co);
@@ -214,6 +217,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc_)
         unpack8(q2[qi], zv);
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = (1.f - zv[r]) * hv[r] + zv[r] * v[r];
+      } else if (p.fuse == PP_FUSE_DCN_OFFMASK) {       // same math as dcn_offmask_act_kernel (token_ops.hip) on the unrounded sums
+        if (co < p.fuse_split) {
+          float fx = 0.f, fy = 0.f;
+          if (om_flow) {
+            const _Float16* fl = reinterpret_cast<const _Float16*>(&q1[qi]);
+            fx = (float)fl[0]; fy = (float)fl[1];
+          }
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[r] = p.act_param * tanhf(v[r]) + ((r & 1) ? fx : fy);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[r] = 1.f / (1.f + __expf(-v[r]));
+        }
       }
       if (!has_res && relu2) {
 #pragma unroll

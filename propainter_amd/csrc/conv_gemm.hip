@@ -344,6 +344,16 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
           }
         continue;
       }
+      if (p.fuse == PP_FUSE_DCN_OFFMASK) {                          // offset / mask head (same math as dcn_offmask_act_kernel)
+        float fx = 0.f, fy = 0.f;
+        if (p.fuse_a != nullptr && co < p.fuse_split) {
+          const T* fp_ = reinterpret_cast<const T*>(p.fuse_a) + m * p.fuse_a_cstride + p.fuse_a_choff;
+          fx = to_f32(fp_[0]); fy = to_f32(fp_[1]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          v[r] = co + r < p.fuse_split ? p.act_param * tanhf(v[r]) + ((r & 1) ? fx : fy) : 1.f / (1.f + __expf(-v[r]));
+      }
       if (p.fuse == PP_FUSE_GRU_H) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -524,10 +534,15 @@ extern "C" int pp_conv2d(const pp_conv_args_t* a, void* stream) {
   if (a->preadd != nullptr || a->fuse != PP_FUSE_NONE) {
     PP_REQUIRE(a->groups == 1 && !deform && a->out_dtype == a->dtype && a->cout_g % 8 == 0, PP_ERR_ARG,
                "pp_conv2d: the fused epilogue (preadd / fuse) needs groups == 1, no deformable sampling, out_dtype == dtype, cout_g %% 8 == 0");
-    PP_REQUIRE(a->fuse >= PP_FUSE_NONE && a->fuse <= PP_FUSE_GRU_H, PP_ERR_ARG, "pp_conv2d: fuse %d", a->fuse);
+    PP_REQUIRE(a->fuse >= PP_FUSE_NONE && a->fuse <= PP_FUSE_DCN_OFFMASK, PP_ERR_ARG, "pp_conv2d: fuse %d", a->fuse);
     PP_REQUIRE(a->preadd == nullptr || (((uintptr_t)a->preadd % 16) == 0 && ((a->preadd_cstride | a->preadd_choff) & 7) == 0),
                PP_ERR_ALIGN, "pp_conv2d: preadd must be 16-byte aligned with cstride / choff multiples of 8");
-    if (a->fuse != PP_FUSE_NONE) {
+    if (a->fuse == PP_FUSE_DCN_OFFMASK) {
+      PP_REQUIRE(a->act == PP_ACT_NONE && a->preadd == nullptr && a->fuse_split > 0 && a->fuse_split % 8 == 0 && a->fuse_split <= a->cout_g,
+                 PP_ERR_ARG, "pp_conv2d: PP_FUSE_DCN_OFFMASK needs act == none, no preadd, 0 < fuse_split <= cout_g, multiple of 8");
+      PP_REQUIRE(a->fuse_a == nullptr || (((uintptr_t)a->fuse_a % 4) == 0 && ((a->fuse_a_cstride | a->fuse_a_choff) & 1) == 0),
+                 PP_ERR_ALIGN, "pp_conv2d: PP_FUSE_DCN_OFFMASK flow window must be 4-byte aligned with even cstride / choff");
+    } else if (a->fuse != PP_FUSE_NONE) {
       PP_REQUIRE(a->fuse_a != nullptr && ((uintptr_t)a->fuse_a % 16) == 0 && ((a->fuse_a_cstride | a->fuse_a_choff) & 7) == 0,
                  PP_ERR_ALIGN, "pp_conv2d: fuse_a must be set, 16-byte aligned, cstride / choff multiples of 8");
     }
@@ -549,7 +564,7 @@ extern "C" int pp_conv2d(const pp_conv_args_t* a, void* stream) {
     if (rc != -1000) return rc;
     PP_REQUIRE(a->impl == 0, PP_ERR_ARG, "pp_conv2d: impl 80 (A-stationary GEMM) not available for this shape");
   }
-  if (a->dtype == PP_F16 && !deform && (a->impl == 0 || (a->impl >= 70 && a->impl < 80) || (a->impl >= 83 && a->impl <= 89))) {
+  if (a->dtype == PP_F16 && !deform && (a->impl == 0 || (a->impl >= 70 && a->impl < 80) || (a->impl >= 82 && a->impl <= 89))) {
     // halo-tile kernel family (stride-1 "same" 3x3 / 1x5 / 5x1 windows over 64-channel-multiple sources)
     const int rc = conv_v3_dispatch(p, a->impl, st);
     if (rc != -1000) return rc;

@@ -13,8 +13,12 @@
 //
 //   LDS: 2 patch buffers [PROWS][64 ch] (double buffered across channel blocks; the next block's patch arrives in
 //        pieces, one LDS-DMA instruction per wave per tap step) + 2 weight stages [BN][64] + epilogue tile (aliased).
-//   Swizzle: 16-byte slot ^ ((row >> 1) & 7) on both the DMA source chunk and the fragment read, keyed by the PATCH row,
-//        so any 16 consecutive patch rows (one MFMA fragment: 16 pixels of a tile row) are conflict-free.
+//   Swizzle: patch: 16-byte slot ^ (row & 7) on both the DMA source chunk and the fragment read, keyed by the PATCH row.
+//        A fragment is 16 consecutive patch rows starting at ANY row (tile row + tap shift), and ds_read_b128 is serviced
+//        in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... (MI355X_MICROARCH.md, LDS): with the v2 key
+//        ((row >> 1) & 7) only starts that are multiples of 4 rows are conflict-free (24 of 32 alignments are 2-way);
+//        (row & 7) is conflict-free at every alignment (exhaustive check: tools/lds_swizzle_check.py).  The weight tile
+//        keeps ((row >> 1) & 7): its fragments start at multiples of 16 rows.
 //   4 waves (2 x 2), wave tile 64 px x BN/2 couts, v_mfma_f32_16x16x32_f16, fp32 accumulate.  Epilogue as in v2.
 #include "conv_epilogue.h"
 
@@ -98,7 +102,8 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : 1) void conv_h
   // ---- DMA roles.  Patch piece q = j*NW + wave covers patch rows q*8 .. q*8+7; lane -> (row q*8 + lane/8, slot lane%8).
   // (q*8 + rin) >> 1 & 7 == (4*q + (rin >> 1)) & 7 and q has the parity of `wave` (NW is even): one logical chunk per lane.
   const int rin = lane >> 3, slot = lane & 7;
-  const int lc = slot ^ ((4 * (wave & 1) + (rin >> 1)) & 7);
+  const int lc = slot ^ ((4 * (wave & 1) + (rin >> 1)) & 7);        // weight rows: slot ^ ((row >> 1) & 7)
+  const int lca = STAGGER == 5 ? lc : (slot ^ rin);                 // patch rows: slot ^ (row & 7); piece rows start at multiples of 8
   int ppix[PPW];                                          // global pixel index of the lane's patch row, -1 = zero fill
 #pragma unroll
   for (int j = 0; j < PPW; ++j) {
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : 1) void conv_h
     const int s_ = (e)[2] & 0xff;                                                                               \
     const __amdgpu_buffer_rsrc_t r_ = s_ == 1 ? rs1 : s_ == 2 ? rs2 : s_ == 3 ? rs3 : rs0;                      \
     const int rowbytes_ = s_ == 1 ? rb1 : s_ == 2 ? rb2 : s_ == 3 ? rb3 : rb0;                                  \
-    const int voff_ = ppix[j] >= 0 ? ppix[j] * rowbytes_ + (e)[3] * 2 + lc * 16 : (int)0x80000000;              \
+    const int voff_ = ppix[j] >= 0 ? ppix[j] * rowbytes_ + (e)[3] * 2 + lca * 16 : (int)0x80000000;             \
     v3_dma16(r_, patch0 + (pbuf) * PATCH_BYTES + ((j) * NW + wave) * 1024, voff_, 0);                           \
   } while (0)
 #define V3_ISSUE_B(ks_, par_)                                                                                   \
@@ -202,7 +207,7 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : 1) void conv_h
 #pragma unroll
             for (int f = 0; f < TM; ++f) {
               const int row = pp0[f] + sh;
-              afp[kk][f] = *reinterpret_cast<const f16x8*>(pcur + row * 128 + (((kk * 4 + l4) ^ ((row >> 1) & 7)) << 4));
+              afp[kk][f] = *reinterpret_cast<const f16x8*>(pcur + row * 128 + (((kk * 4 + l4) ^ (row & 7)) << 4));
             }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -228,7 +233,7 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : 1) void conv_h
             af[f] = f16x8{(_Float16)1, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)(float)f};
           } else {
             const int row = pp0[f] + sh;
-            af[f] = *reinterpret_cast<const f16x8*>(pcur + row * 128 + (((kk * 4 + l4) ^ ((row >> 1) & 7)) << 4));
+            af[f] = *reinterpret_cast<const f16x8*>(pcur + row * 128 + (((kk * 4 + l4) ^ (STAGGER == 5 ? (row >> 1) & 7 : row & 7)) << 4));
           }
         }
 #pragma unroll
@@ -334,6 +339,12 @@ int conv_v3_dispatch(const ConvParams& p, int cfg, hipStream_t stream) {
     return -1000;
   }
 #if defined(PP_DIAG)      // tuning / diagnostic variants (tools/kbench, PP_DIAG=1 builds only; measured in profiles/r2_conv_epilogue_ab.txt)
+  if (cfg == 82) {   // round-1 patch swizzle ((row >> 1) & 7): 2-way bank conflicts at 24 of 32 fragment alignments
+    if (kh == 3 && kw == 3) return launch_v3<8, 16, 3, 3, 128, false, 5>(p, stream);
+    if (kh == 1 && kw == 5) return launch_v3<8, 16, 1, 5, 128, false, 5>(p, stream);
+    if (kh == 5 && kw == 1) return launch_v3<16, 8, 5, 1, 128, false, 5>(p, stream);
+    return -1000;
+  }
   if (cfg == 85) {   // 8 waves of 32 x 64 per 128 x 128 block tile, 4 waves per SIMD
     if (kh == 3 && kw == 3) return launch_v3<8, 16, 3, 3, 128, false, 0, 32>(p, stream);
     if (kh == 1 && kw == 5) return launch_v3<8, 16, 1, 5, 128, false, 0, 32>(p, stream);

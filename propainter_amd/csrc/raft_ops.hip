@@ -153,3 +153,51 @@ extern "C" int pp_convex_upsample(const float* flow, const void* mask, int mask_
                        B, h, w);
   return launch_status("pp_convex_upsample");
 }
+
+namespace pp {
+// One thread per pixel: 7 horizontal taps x (x, y) of the fp32 flow coords1 - coords0 -> 16 channels (32 / 64 contiguous bytes)
+template <typename T>
+__global__ void raft_flow_taps_kernel(const float* __restrict__ c1, const float* __restrict__ c0, T* __restrict__ rows,
+                                      T* __restrict__ fout, int fcs, int fco, long long npix, int w) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < npix; i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % w);
+    float v[16];
+#pragma unroll
+    for (int kx = 0; kx < 7; ++kx) {
+      const int xx = x + kx - 3;
+      float fx = 0.f, fy = 0.f;
+      if (xx >= 0 && xx < w) {
+        const long long j = i + (kx - 3);
+        const float2 a = *reinterpret_cast<const float2*>(c1 + 2 * j), b = *reinterpret_cast<const float2*>(c0 + 2 * j);
+        fx = a.x - b.x; fy = a.y - b.y;
+      }
+      v[2 * kx] = fx; v[2 * kx + 1] = fy;
+    }
+    v[14] = v[15] = 0.f;
+    store8<T>(rows + i * 16, v);
+    store8<T>(rows + i * 16 + 8, v + 8);
+    if (fout != nullptr) {
+      fout[i * fcs + fco] = from_f32<T>(v[6]);
+      fout[i * fcs + fco + 1] = from_f32<T>(v[7]);
+    }
+  }
+}
+}  // namespace pp
+
+extern "C" int pp_raft_flow_taps(const float* coords1, const float* coords0, void* rows, void* flow_out, int flow_cstride,
+                                 int flow_choff, int P, int h, int w, int dtype, void* stream) {
+  PP_REQUIRE(coords1 && coords0 && rows && P > 0 && h > 0 && w > 0, PP_ERR_ARG, "pp_raft_flow_taps: bad arguments");
+  PP_REQUIRE(dtype == PP_F32 || dtype == PP_F16, PP_ERR_DTYPE, "pp_raft_flow_taps: dtype %d", dtype);
+  PP_REQUIRE(flow_out == nullptr || (flow_cstride >= flow_choff + 2 && flow_choff >= 0), PP_ERR_ARG, "pp_raft_flow_taps: flow window");
+  PP_REQUIRE(((uintptr_t)rows % 16) == 0 && ((uintptr_t)coords1 % 8) == 0 && ((uintptr_t)coords0 % 8) == 0, PP_ERR_ALIGN,
+             "pp_raft_flow_taps: rows must be 16-byte aligned, coords 8-byte aligned");
+  const long long npix = (long long)P * h * w;
+  const int g = grid_for(npix);
+  if (dtype == PP_F16)
+    hipLaunchKernelGGL((raft_flow_taps_kernel<_Float16>), dim3(g), dim3(256), 0, (hipStream_t)stream, coords1, coords0, (_Float16*)rows,
+                       (_Float16*)flow_out, flow_cstride, flow_choff, npix, w);
+  else
+    hipLaunchKernelGGL((raft_flow_taps_kernel<float>), dim3(g), dim3(256), 0, (hipStream_t)stream, coords1, coords0, (float*)rows,
+                       (float*)flow_out, flow_cstride, flow_choff, npix, w);
+  return launch_status("pp_raft_flow_taps");
+}

@@ -15,7 +15,7 @@ from . import build as _build
 PP_F32, PP_F16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID, ACT_TANH, ACT_GELU = 0, 1, 2, 3, 4, 5
 MAX_SRC = 4
-FUSE_NONE, FUSE_GRU_ZR, FUSE_GRU_H = 0, 1, 2
+FUSE_NONE, FUSE_GRU_ZR, FUSE_GRU_H, FUSE_DCN_OFFMASK = 0, 1, 2, 3
 
 
 class ConvSrc(C.Structure):
@@ -358,6 +358,19 @@ def corr_lookup_otf(f1, f2_levels, coords, out):
                                                   _p(coords), _p(out), _i(out.shape[-1]), _i(out.shape[-1]), _i(P), _i(h), _i(w),
                                                   _stream(f1)), "pp_corr_lookup_otf"))
     return out
+
+
+def raft_flow_taps(coords1, coords0, rows, flow_out=None, flow_choff=0):
+    """rows[P,h,w,16] <- the 7 horizontal taps of flow = coords1 - coords0 (fp32 [P,h,w,2]) per pixel, channel 2*kx + c; optionally
+    flow_out[..., flow_choff:flow_choff+2] <- flow (pp_raft_flow_taps)."""
+    P, h, w, _ = coords1.shape
+    assert coords1.dtype == coords0.dtype == torch.float32 and coords1.is_contiguous() and coords0.is_contiguous()
+    assert rows.shape == (P, h, w, 16) and rows.is_contiguous() and (flow_out is None or (flow_out.is_contiguous() and flow_out.dtype == rows.dtype))
+    timed("raft_flow_taps", 0, 2 * _nbytes(coords1) + _nbytes(rows),
+          lambda: _check(lib().pp_raft_flow_taps(_p(coords1), _p(coords0), _p(rows), _p(flow_out), _i(flow_out.shape[-1] if flow_out is not None else 0),
+                                                 _i(flow_choff), _i(P), _i(h), _i(w), _i(dtype_code(rows.dtype)), _stream(coords1)),
+                         "pp_raft_flow_taps"))
+    return rows
 
 
 def convex_upsample(flow, mask):

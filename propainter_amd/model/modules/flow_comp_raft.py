@@ -92,7 +92,14 @@ class _RaftEngine:
         g = lambda n: (sd[u + n + ".weight"], sd[u + n + ".bias"])
         self.convc1 = mk(*g("encoder.convc1"), src_channels=[324])
         self.convc2 = mk(*g("encoder.convc2"), padding=1)
-        self.convf1 = mk(*g("encoder.convf1"), padding=3, src_channels=[2])
+        # convf1 = Conv2d(2, 128, 7, padding=3) (RAFT/update.py:85,92).  As a 7x7 window over a 2-channel map the implicit GEMM
+        # pads every tap to a 16-byte chunk (K = 448 for 98 real terms); the engine instead gathers the 7 horizontal taps of
+        # each pixel into 16 channels (pp_raft_flow_taps) and runs a 7x1 convolution over them: K = 7 x 16, same terms, same order
+        wf, bf = g("encoder.convf1")
+        wrow = torch.zeros((wf.shape[0], 16, 7, 1), dtype=wf.dtype)
+        for kx in range(7):
+            wrow[:, 2 * kx:2 * kx + 2, :, 0] = wf[:, :, :, kx]
+        self.convf1 = mk(wrow, bf, padding=(3, 0), src_channels=[16])
         self.convf2 = mk(*g("encoder.convf2"), padding=1)
         self.convm = mk(*g("encoder.conv"), padding=1, src_channels=[192, 64])
         # SepConvGRU (RAFT/update.py:45-60).  Every gate convolution reads cat[h, x], x = cat[inp, motion, flow]; inp (the
@@ -167,17 +174,15 @@ class _RaftEngine:
         coords0 = torch.stack([xs, ys], -1)[None].expand(P, h, w, 2).contiguous()
         coords1 = coords0.clone()
         corr = torch.empty((P, h, w, 328), dtype=dt, device=dev)
-        flow8 = torch.zeros((P, h, w, 8), dtype=dt, device=dev)
+        frow = torch.empty((P, h, w, 16), dtype=dt, device=dev)            # 7 horizontal flow taps per pixel (convf1 input)
         zbuf = torch.empty((P, h, w, 128), dtype=dt, device=dev)
         rh = torch.empty((P, h, w, 128), dtype=dt, device=dev)
         delta = torch.zeros((P, h, w, 8), dtype=torch.float32, device=dev)
         for it in range(iters):
             lookup(coords1, corr)
-            flow = coords1 - coords0
-            flow8[..., :2] = flow
-            xbuf[..., 126:] = flow
+            hip.raft_flow_taps(coords1, coords0, frow, flow_out=xbuf, flow_choff=126)       # flow = coords1 - coords0
             cor = self.convc2([self.convc1([corr], act="relu")], act="relu")
-            flo = self.convf2([self.convf1([flow8], act="relu")], act="relu")
+            flo = self.convf2([self.convf1([frow], act="relu")], act="relu")
             self.convm([cor, flo], out=xbuf, out_choff=0, act="relu")
             for G, (pzr, pq) in zip(self.gru, pre):
                 G["zr"]([net, xbuf], out=zbuf, act="sigmoid", preadd=pzr,

@@ -183,8 +183,7 @@ class _GenEngine:
                     o = L["off0"]([cur, warped, ax], act="lrelu", act_param=0.1)
                     o = L["off2"]([o], act="lrelu", act_param=0.1)
                     o = L["off4"]([o], act="lrelu", act_param=0.1)
-                    om = L["off6"]([o])
-                    hip.dcn_offset_mask_act(om, 3.0, flow=ax)
+                    om = L["off6"]([o], fuse=dict(kind="dcn_om", mag=3.0, flow=ax))      # 3 * tanh(offsets) + flow | sigmoid(masks)
                     prop = L["dcn"]([prop], dcn_offmask=om)
                 y = L["bb0"]([cur, prop, mk8[idx:idx + 1]], act="lrelu", act_param=0.2)
                 L["bb2"]([y], out=outs[idx:idx + 1], residual=prop)

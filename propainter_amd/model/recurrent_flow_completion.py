@@ -106,8 +106,7 @@ class _FCEngine:
                     o = L["off0"]([prev, cur, n2], act="lrelu", act_param=0.1)
                     o = L["off2"]([o], act="lrelu", act_param=0.1)
                     o = L["off4"]([o], act="lrelu", act_param=0.1)
-                    om = L["off6"]([o])
-                    hip.dcn_offset_mask_act(om, 5.0)
+                    om = L["off6"]([o], fuse=dict(kind="dcn_om", mag=5.0))               # 5 * tanh(offsets) | sigmoid(masks)
                     prop = L["dcn"]([prev, n2], dcn_offmask=om)
                 srcs = [cur] + ([feats["backward_"][idx]] if name == "forward_" else []) + [prop]
                 y = L["bb0"](srcs, act="lrelu", act_param=0.1)

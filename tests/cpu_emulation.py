@@ -71,7 +71,16 @@ def _conv_call(self, srcs, out=None, out_choff=0, act=None, act_param=0.0, out_s
             pt, pc = win(preadd)
             y = y + pt.float()[..., pc:pc + self.cout_g].reshape(y.shape)
         y = _ACT[pconv.ACTS[act]](y, act_param)
-        if fuse is not None:
+        if fuse is not None and fuse["kind"] == "dcn_om":
+            Cs = int(fuse.get("split", 288))
+            off = float(fuse["mag"]) * torch.tanh(y[..., :Cs])
+            if fuse.get("flow") is not None:
+                ft, fc = win(fuse["flow"])
+                fl = ft.float()[..., fc:fc + 2].reshape(y.shape[:-1] + (2,))
+                odd = (torch.arange(Cs) % 2).bool()                 # even channels (dy) += flow_y, odd channels (dx) += flow_x
+                off = off + torch.where(odd, fl[..., 0:1], fl[..., 1:2])
+            y = torch.cat([off, torch.sigmoid(y[..., Cs:])], -1)
+        elif fuse is not None:
             ht, hc = win(fuse["h"])
             if fuse["kind"] == "gru_zr":
                 Cs = int(fuse["split"])
@@ -219,6 +228,18 @@ def _dcn_act(om, mag, flow=None, fl_choff=0):
     return om
 
 
+def _raft_flow_taps(coords1, coords0, rows, flow_out=None, flow_choff=0):
+    flow = coords1 - coords0                                               # fp32 [P,h,w,2]
+    fp = F.pad(flow, (0, 0, 3, 3))                                         # zero columns left / right
+    w = flow.shape[2]
+    rows.zero_()
+    for kx in range(7):
+        rows[..., 2 * kx:2 * kx + 2] = fp[:, :, kx:kx + w].to(rows.dtype)
+    if flow_out is not None:
+        flow_out[..., flow_choff:flow_choff + 2] = flow.to(flow_out.dtype)
+    return rows
+
+
 def _gru_gate(zr, h, h_choff, Cc, out, out_choff, q=None):
     hv = h[..., h_choff:h_choff + Cc].float()
     if q is None:
@@ -249,7 +270,7 @@ def emulated_device_ops():
     patches = {
         "flow_warp": _flow_warp, "fb_check": _fb_check, "img_prop_step": _img_prop_step, "corr_avgpool": _corr_avgpool,
         "corr_lookup": _corr_lookup, "corr_feature_pyramid": _corr_feature_pyramid, "corr_lookup_otf": _corr_lookup_otf,
-        "convex_upsample": _convex_upsample, "window_mask": _window_mask,
+        "convex_upsample": _convex_upsample, "window_mask": _window_mask, "raft_flow_taps": _raft_flow_taps,
         "sparse_window_attention": _attention, "fold_tokens": _fold_tokens, "layernorm": _layernorm,
         "depthwise_pool": _depthwise_pool, "instance_norm": _instance_norm, "upsample2x": _upsample2x,
         "dcn_offset_mask_act": _dcn_act, "gru_gate": _gru_gate, "nchw_to_nhwc": _nchw_to_nhwc, "nhwc_to_nchw": _nhwc_to_nchw,

@@ -154,6 +154,71 @@ def test_conv_fused_gru_epilogue(dev, k, pad, mode):
     check("h_new", net.permute(0, 3, 1, 2), href, t)
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.float32], ids=["f16", "f32"])
+def test_raft_flow_taps_7x1_equals_7x7(dev, dt):
+    """Motion encoder convf1 = Conv2d(2, 128, 7, padding=3) (RAFT/update.py:85,92) as pp_raft_flow_taps + a 7x1 convolution over
+    the 16 gathered channels: same terms as the 7x7 window; the flow side output feeds the GRU input window."""
+    from propainter_amd import hip
+    from propainter_amd.conv import ConvLayer
+    g = torch.Generator().manual_seed(91)
+    P, h, w = 3, 13, 22
+    wf = torch.randn(128, 2, 7, 7, generator=g) / math.sqrt(98)
+    bf = torch.randn(128, generator=g) * 0.1
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+    c0 = torch.stack([xs, ys], -1)[None].expand(P, h, w, 2).contiguous()
+    c1 = c0 + torch.randn(P, h, w, 2, generator=g) * 6
+    flow = (c1 - c0).to(dt).float()
+    ref = F.relu(F.conv2d(flow.permute(0, 3, 1, 2), wf.to(dt).float(), bf, 1, 3))
+    wrow = torch.zeros(128, 16, 7, 1)
+    for kx in range(7):
+        wrow[:, 2 * kx:2 * kx + 2, :, 0] = wf[:, :, :, kx]
+    layer = ConvLayer(wrow, bf, padding=(3, 0), src_channels=[16], dtype=dt, device=dev)
+    rows = torch.full((P, h, w, 16), 7.0, dtype=dt, device=dev)
+    xbuf = torch.full((P, h, w, 16), 5.0, dtype=dt, device=dev)
+    hip.raft_flow_taps(c1.to(dev), c0.to(dev), rows, flow_out=xbuf, flow_choff=6)
+    out = layer([rows], act="relu")
+    torch.cuda.synchronize()
+    assert torch.equal(xbuf[..., 6:8].float().cpu(), flow) and (xbuf[..., :6] == 5).all() and (xbuf[..., 8:] == 5).all()
+    assert (rows[..., 14:] == 0).all() and torch.equal(rows[..., 6:8].float().cpu(), flow)
+    check("convf1 as taps + 7x1", out.permute(0, 3, 1, 2), ref, tol(dt, 2.0))
+
+
+@pytest.mark.parametrize("mode", ["f16_halo", "f16_v2", "f16_v1", "f32"])
+@pytest.mark.parametrize("with_flow", [True, False], ids=["flow", "noflow"])
+def test_conv_fused_dcn_offset_mask_head(dev, mode, with_flow):
+    """conv_offset head of the deformable alignment (model/propainter.py:57-65, recurrent_flow_completion.py:31-40):
+    mag * tanh(offsets) (+ flow flipped to (y, x) per tap) | sigmoid(masks) fused into the convolution epilogue, against
+    torch; for fp32 also bit-identical with the plain convolution followed by pp_dcn_offset_mask_act."""
+    from propainter_amd import hip
+    from propainter_amd.conv import ConvLayer
+    dt = torch.float16 if mode.startswith("f16") else torch.float32
+    g = torch.Generator().manual_seed(77)
+    N, H, W, C, mag = 2, 21, 30, 128, 3.0
+    x = (torch.randn(N, C, H, W, generator=g) * 0.8).to(dt).float()
+    w = torch.randn(432, C, 3, 3, generator=g) / math.sqrt(C * 9) * 2
+    b = torch.randn(432, generator=g) * 0.1
+    flow = (torch.randn(N, 2, H, W, generator=g) * 4).to(dt).float()
+    y = F.conv2d(x, w.to(dt).float(), b, 1, 1)
+    off = mag * torch.tanh(y[:, :288])
+    if with_flow:
+        off = off + flow.flip(1).repeat(1, 144, 1, 1)
+    ref = torch.cat([off, torch.sigmoid(y[:, 288:])], 1)
+    layer = ConvLayer(w, b, padding=1, src_channels=[C], dtype=dt, device=dev)
+    layer.impl = {"f16_halo": 70, "f16_v2": 12, "f16_v1": 1}.get(mode, 0)
+    xd = nhwc(x, dt)
+    aux = torch.zeros((N, H, W, 8), dtype=dt, device=dev)
+    aux[..., :2] = nhwc(flow, dt)
+    fl = aux if with_flow else None
+    out = layer([xd], fuse=dict(kind="dcn_om", mag=mag, flow=fl))
+    torch.cuda.synchronize()
+    check("fused offset/mask head", out.permute(0, 3, 1, 2), ref, tol(dt, 3.0))
+    if dt == torch.float32:
+        plain = layer([xd])
+        hip.dcn_offset_mask_act(plain, mag, flow=fl)
+        torch.cuda.synchronize()
+        assert torch.equal(plain, out), "fused head must equal conv + pp_dcn_offset_mask_act bit for bit in fp32"
+
+
 @pytest.mark.parametrize("case", [c for c in CONV_CASES if c["name"] in ("3x3", "7x7s2_c3", "1x1_c324", "two_src", "1x5", "cout2_f32out", "residual_relu2")],
                          ids=lambda c: c["name"])
 def test_conv2d_split3_is_fp32_class(dev, case):

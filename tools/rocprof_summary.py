@@ -121,8 +121,28 @@ def cmd_traffic(fetch_dir, write_dir, out):
         print(f"{k:46s} n={v['launches']:6d}  HBM bytes/launch = {v['hbm_bytes_per_launch'] / 1e6:10.2f} MB")
 
 
+def cmd_counters(root, out, names):
+    """Per-family (and per-kernel for the conv / attention kernels) sums of arbitrary PMC counters of one --pmc pass."""
+    fam = collections.defaultdict(lambda: collections.defaultdict(float))
+    ker = collections.defaultdict(lambda: collections.defaultdict(float))
+    for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] in names:
+                k = r.get("Kernel_Name", "?")
+                fam[family(k)][r["Counter_Name"]] += float(r["Counter_Value"])
+                ker[short(k, 90)][r["Counter_Name"]] += float(r["Counter_Value"])
+    json.dump({"families": fam, "kernels": ker}, open(out, "w"), indent=1)
+    for title, d in (("family", fam), ("kernel", ker)):
+        print(f"-- per {title}")
+        for k, v in sorted(d.items(), key=lambda kv: -kv[1].get(names[-1], 0))[:24]:
+            ratio = v.get(names[0], 0) / max(1.0, v.get(names[-1], 0))
+            print(f"{k:92s} " + " ".join(f"{n}={v.get(n, 0):.3e}" for n in names) + f"  {names[0]}/{names[-1]}={ratio:.3f}")
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "stats":
+    if sys.argv[1] == "counters":
+        cmd_counters(sys.argv[2], sys.argv[3], sys.argv[4].split(","))
+    elif sys.argv[1] == "stats":
         cmd_stats(sys.argv[2], sys.argv[3])
     else:
         cmd_traffic(sys.argv[2], sys.argv[3], sys.argv[4])
