@@ -103,8 +103,6 @@ typedef __attribute__((address_space(3))) fp16v4 lds_fp16v4;
 static __device__ __forceinline__ f16x4 lds_read_tr16(const _Float16* p) {
   return __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16v4*)p));
 }
-#else
-static __device__ __forceinline__ f16x4 lds_read_tr16(const _Float16*) { return f16x4{}; }   // host pass of the same source
 #endif
 
 // Flash-style MFMA kernel.  256 threads = 4 waves; every wave owns QT tiles of 16 queries (QT = 2 -> 128 queries per
@@ -129,14 +127,19 @@ __device__ unsigned long long g_attn_prof[8];
 
 template <int QT, bool MASKED, bool PROF>
 __device__ __forceinline__ void attn_block(const AttnParams& p, const int b, const int w, const int head, const int yb,
-                                           _Float16* Ks, _Float16* Vs, int* idx_lds, int* tind_lds) {
+                                           _Float16* Ks, _Float16* Vs, int* idx_lds, int* tind_lds, int* koff_lds) {
+#if defined(__HIP_DEVICE_COMPILE__)      // (buffer-descriptor / LDS-transpose builtins exist in the device pass only)
   typedef _Float16 T;
   constexpr int QB = 64 * QT;                                  // queries per block
   const int nq_total = p.T * p.wsz;
   if (MASKED && yb * QB >= nq_total) return;                   // masked windows need ceil(T*45/QB) blocks only
   if (!MASKED && yb >= p.T) return;
   const int ngrid = p.wsz + p.n_rolled;
-  for (int i = threadIdx.x; i < ngrid; i += 256) idx_lds[i] = i < p.wsz ? p.own[w * p.wsz + i] : p.rolled[w * p.n_rolled + i - p.wsz];
+  for (int i = threadIdx.x; i < ngrid; i += 256) {
+    const int tok = i < p.wsz ? p.own[w * p.wsz + i] : p.rolled[w * p.n_rolled + i - p.wsz];
+    idx_lds[i] = tok;
+    koff_lds[i] = tok * p.qkv_cs * 2;                          // byte offset of the token's K / V row inside its frame
+  }
   // key frames in LDS: a global tind[] read inside the tile loop put a dependent load (and, vmcnt being in-order, a
   // drain of the whole K/V prefetch) in front of every gather -- 6.5 k of the 10.7 k cycles per tile (tools/bench_attn.py)
   if (MASKED && threadIdx.x < p.n_tind) tind_lds[threadIdx.x] = p.tind[threadIdx.x];
@@ -175,7 +178,9 @@ __device__ __forceinline__ void attn_block(const AttnParams& p, const int b, con
       else qf[qt][s] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
     }
   }
-  const int kpf = MASKED ? ngrid + p.P : p.wsz;                // keys per key frame
+  const int n_gridkeys = MASKED ? ngrid : p.wsz;               // keys [0, n_gridkeys) come from the token grid
+  const int pool0 = (n_gridkeys + 3) & ~3;                     // first pooled key (see load_part)
+  const int kpf = MASKED ? pool0 + p.P : p.wsz;                // keys per key frame (incl. the filler keys)
   const int tpf = (kpf + KT - 1) / KT;                         // 64-key tiles per frame (the last one is partial: masked out)
   const int ntiles = (MASKED ? p.n_tind : 1) * tpf;
   const float sc2 = rsqrtf((float)HD) * 1.4426950408889634f;   // softmax scale folded with log2(e)
@@ -194,28 +199,43 @@ __device__ __forceinline__ void attn_block(const AttnParams& p, const int b, con
   // ---- tile staging: 64 keys x 16 chunks of 8 channels; 16 consecutive lanes read one 256-byte key row
   // (coalesced); rows past the key list are zero.
   u32x4 kr[4], vr[4];
-  // (strides copied into registers: selecting between p.qkv_cs and p.pkv_cs per lane made hipcc fetch the kernel-argument
-  // field with a *vector* load in front of every gather -- a dependent load + vmcnt(0) drain per K/V row, 5 k cycles a tile)
-  const long long qkv_cs = p.qkv_cs, pkv_cs = p.pkv_cs;
-  const long long frame_tok = (long long)p.Hp * p.Wp, frame_pool = p.P;
+  // K/V rows are gathered with raw buffer loads: one descriptor per tensor over this batch item (built once), the key frame
+  // in the scalar offset, and per lane only a 32-bit byte offset inside the frame -- looked up in LDS for the window / rolled
+  // tokens (koff_lds, pre-multiplied by the row pitch), one 32-bit multiply for the pooled tokens.  Rows past the key list get the
+  // out-of-range offset and come back as zeros.  (Round 1 built 64-bit flat addresses per lane: ~70 VALU instructions per
+  // 16-key quarter, 1.2 k of the 5.5 k cycles a wave spends per tile -- in-kernel stamps, tools/bench_attn.py.)
   const int hoff = head * HD;
-  // one quarter (16 keys) of the next tile: 2 x 16-byte loads per lane.  The quarters are issued between the QK MFMA groups of
-  // the current tile: issued back to back by all 8 waves of a CU right after the barrier, the 64 KB of a tile pair queue on
-  // the CU's one address unit (64 B/clk) and every wave sat in the issue for ~1.2 k cycles (in-kernel stamps, tools/bench_attn.py)
-  auto load_part = [&](int fi, int r0, int i) {                 // keys r0 .. r0+63 of key frame #fi (no division, no global index reads)
-    const int f = MASKED ? tind_lds[fi] : frame_blk;
-    const long long bf = (long long)b * p.T + f;
-    const int c = tid + 256 * i;
-    const int key = c >> 4, dch = c & 15;
-    const int r = r0 + key;
-    kr[i] = u32x4{0, 0, 0, 0};
-    vr[i] = u32x4{0, 0, 0, 0};
-    if (r < kpf) {
-      const bool grid = r < ngrid;
-      const long long row = grid ? bf * frame_tok + idx_lds[grid ? r : 0] : bf * frame_pool + (r - ngrid);
-      const long long eoff = row * (grid ? qkv_cs : pkv_cs) + hoff + dch * 8;
-      kr[i] = *reinterpret_cast<const u32x4*>((grid ? kg : pkg) + eoff);
-      vr[i] = *reinterpret_cast<const u32x4*>((grid ? vg : pvg) + eoff);
+  const long long item_tok = (long long)b * p.T * p.Hp * p.Wp, item_pool = (long long)b * p.T * p.P;
+  const int frame_grid_bytes = p.Hp * p.Wp * p.qkv_cs * 2, frame_pool_bytes = p.P * p.pkv_cs * 2;
+  const long long sg64 = (long long)p.T * frame_grid_bytes, sp64 = (long long)p.T * frame_pool_bytes;    // (the host entry refuses items >= 2 GiB)
+  const int span_grid = (int)(sg64 < 0x7fffffffll ? sg64 : 0x7fffffffll), span_pool = (int)(sp64 < 0x7fffffffll ? sp64 : 0x7fffffffll);
+  const __amdgpu_buffer_rsrc_t rs_k = uniform_buffer_rsrc(kg + item_tok * p.qkv_cs + hoff, span_grid);
+  const __amdgpu_buffer_rsrc_t rs_v = uniform_buffer_rsrc(vg + item_tok * p.qkv_cs + hoff, span_grid);
+  const __amdgpu_buffer_rsrc_t rs_pk = uniform_buffer_rsrc(pkg != nullptr ? pkg + item_pool * p.pkv_cs + hoff : kg, pkg != nullptr ? span_pool : 0);
+  const __amdgpu_buffer_rsrc_t rs_pv = uniform_buffer_rsrc(pvg != nullptr ? pvg + item_pool * p.pkv_cs + hoff : vg, pvg != nullptr ? span_pool : 0);
+  const int pool_pitch = p.pkv_cs * 2;
+  const int dch16 = (tid & 15) * 16;
+  // Key list of one key frame: [0, n_gridkeys) token-grid rows, then the pooled rows.  The pooled part starts at the next
+  // multiple of 4 (pool0): every wave fetches 4 consecutive keys per quarter, so a quarter is all-grid or all-pool and needs
+  // one wave-uniform branch and one pair of loads; the (at most 3) filler keys in between load zeros and are masked to -inf.
+  // one quarter (16 keys) of a tile: 2 x 16-byte loads per lane, issued between the QK MFMA groups of the previous tile
+  auto load_part = [&](int fi, int r0, int i) {                 // keys r0 .. r0+63 of key frame #fi
+    const int f = __builtin_amdgcn_readfirstlane(MASKED ? tind_lds[fi] : frame_blk);
+    const int rq = __builtin_amdgcn_readfirstlane(r0 + 16 * i + wave * 4);   // the wave's 4 keys of this quarter: rq .. rq + 3
+    const int r = rq + (lane >> 4);
+    if (rq < n_gridkeys) {
+      const int vo = r < n_gridkeys ? koff_lds[r] + dch16 : (int)0x80000000;
+      const int so = f * frame_grid_bytes;
+      kr[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_k, vo, so, 0);
+      vr[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_v, vo, so, 0);
+    } else if (rq < kpf) {
+      const int vo = r < kpf ? (r - pool0) * pool_pitch + dch16 : (int)0x80000000;
+      const int so = f * frame_pool_bytes;
+      kr[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_pk, vo, so, 0);
+      vr[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_pv, vo, so, 0);
+    } else {
+      kr[i] = u32x4{0, 0, 0, 0};
+      vr[i] = u32x4{0, 0, 0, 0};
     }
   };
   auto load_tile = [&](int fi, int r0) {
@@ -273,15 +293,17 @@ __device__ __forceinline__ void attn_block(const AttnParams& p, const int b, con
     // (one fma + one v_exp per score; the key-validity mask only on the partial last tile of a frame; the accumulator
     // rescale only when some lane's running max actually moved)
     f16x8 pfr[QT][2];
-    const bool partial = r0 + KT > kpf;                       // wave-uniform
+    const bool partial = r0 + KT > kpf || (MASKED && pool0 != n_gridkeys && r0 <= n_gridkeys && n_gridkeys < r0 + KT);   // wave-uniform
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
       if (partial) {
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (r0 + kt * 16 + (lane >> 4) * 4 + r >= kpf) sacc[qt][kt][r] = -1e30f;
+          for (int r = 0; r < 4; ++r) {
+            const int kk_ = r0 + kt * 16 + (lane >> 4) * 4 + r;       // past the list, or a filler key between grid and pool
+            if (kk_ >= kpf || (kk_ >= n_gridkeys && kk_ < pool0)) sacc[qt][kt][r] = -1e30f;
+          }
       }
       float tmax = sacc[qt][0][0];
 #pragma unroll
@@ -359,6 +381,7 @@ __device__ __forceinline__ void attn_block(const AttnParams& p, const int b, con
       }
     }
   }
+#endif
 }
 
 // Grid-mapped launch: blockIdx.x = (b, window, head), blockIdx.y = query block / frame.  The masked / unmasked decision is
@@ -369,12 +392,13 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnParams p) {
   __shared__ __attribute__((aligned(16))) _Float16 Vs[KT * VS_LD];
   __shared__ int idx_lds[256];
   __shared__ int tind_lds[64];
+  __shared__ int koff_lds[256];
   const int head = blockIdx.x % p.heads;
   const int w = (blockIdx.x / p.heads) % p.nW;
   const int b = blockIdx.x / (p.heads * p.nW);
   const bool masked = p.wmask[b * p.nW + w] > 0.f;
   if (masked != MASKED) return;                                // the other instantiation owns this window
-  attn_block<QT, MASKED, PROF>(p, b, w, head, (int)blockIdx.y, Ks, Vs, idx_lds, tind_lds);
+  attn_block<QT, MASKED, PROF>(p, b, w, head, (int)blockIdx.y, Ks, Vs, idx_lds, tind_lds, koff_lds);
 }
 
 // Persistent launch for the masked windows (the long key lists: ~all of the attention time).  With the grid-mapped
@@ -387,13 +411,14 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_persistent_kernel(const Attn
   __shared__ __attribute__((aligned(16))) _Float16 Vs[KT * VS_LD];
   __shared__ int idx_lds[256];
   __shared__ int tind_lds[64];
+  __shared__ int koff_lds[256];
   const int total = p.work[0] * p.heads * gy;
   for (int item = blockIdx.x; item < total; item += gridDim.x) {
     const int yb = item % gy;
     const int wh = item / gy;
     const int head = wh % p.heads;
     const int bw = p.work[1 + wh / p.heads];
-    attn_block<QT, true, PROF>(p, bw / p.nW, bw % p.nW, head, yb, Ks, Vs, idx_lds, tind_lds);
+    attn_block<QT, true, PROF>(p, bw / p.nW, bw % p.nW, head, yb, Ks, Vs, idx_lds, tind_lds, koff_lds);
     __syncthreads();                                           // the LDS tables are rewritten by the next item
   }
 }
@@ -513,6 +538,9 @@ extern "C" int pp_sparse_window_attention(const pp_attn_args_t* a, void* stream)
   hipStream_t st = (hipStream_t)stream;
   const unsigned gx = (unsigned)(p.B * p.nW * p.heads);
   if (a->dtype == PP_F16 && a->impl != 1) {
+    // the MFMA kernels address K / V rows with 32-bit byte offsets inside one batch item (raw buffer loads)
+    PP_REQUIRE((long long)a->T * a->Hp * a->Wp * a->qkv_cstride * 2 < (1ll << 31) && (long long)a->T * a->P * a->pkv_cstride * 2 < (1ll << 31),
+               PP_ERR_ARG, "pp_sparse_window_attention: the K/V tensors of one batch item must stay below 2 GiB (T=%d, %dx%d tokens)", a->T, a->Hp, a->Wp);
     // masked windows: 128-query blocks over the window's T*45 queries; unmasked: one 64-query block per frame.  Both
     // grids cover every window; blocks of the wrong kind return immediately (device-side flag, no host sync).
     const unsigned gy_m = (unsigned)((p.T * p.wsz + 127) / 128);

@@ -217,7 +217,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc_)
         unpack8(q2[qi], zv);
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = (1.f - zv[r]) * hv[r] + zv[r] * v[r];
-      } else if (p.fuse == PP_FUSE_DCN_OFFMASK) {       // same math as dcn_offmask_act_kernel (token_ops.hip) on the unrounded sums
+      } else if (p.fuse == PP_FUSE_DCN_OFFMASK) {       // dcn_offmask_act_kernel's formulas (token_ops.hip) on the unrounded sums
         if (co < p.fuse_split) {
           float fx = 0.f, fy = 0.f;
           if (om_flow) {
@@ -225,10 +225,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc_)
             fx = (float)fl[0]; fy = (float)fl[1];
           }
 #pragma unroll
-          for (int r = 0; r < 8; ++r) v[r] = p.act_param * tanhf(v[r]) + ((r & 1) ? fx : fy);
+          for (int r = 0; r < 8; ++r)       // tanh as 1 - 2 / (e^2v + 1) (v_exp + v_rcp, as PP_ACT_TANH above; the result is rounded to fp16)
+            v[r] = p.act_param * (1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * v[r]) + 1.f)) + ((r & 1) ? fx : fy);
         } else {
 #pragma unroll
-          for (int r = 0; r < 8; ++r) v[r] = 1.f / (1.f + __expf(-v[r]));
+          for (int r = 0; r < 8; ++r) v[r] = __builtin_amdgcn_rcpf(1.f + __expf(-v[r]));
         }
       }
       if (!has_res && relu2) {
