@@ -564,7 +564,13 @@ extern "C" int pp_conv2d(const pp_conv_args_t* a, void* stream) {
     if (rc != -1000) return rc;
     PP_REQUIRE(a->impl == 0, PP_ERR_ARG, "pp_conv2d: impl 80 (A-stationary GEMM) not available for this shape");
   }
-  if (a->dtype == PP_F16 && !deform && (a->impl == 0 || (a->impl >= 70 && a->impl < 80) || (a->impl >= 82 && a->impl <= 89))) {
+  if (a->dtype == PP_F16 && !deform && (a->impl == 0 || a->impl == 107)) {
+    // wide halo tiles (256 px x 128 couts per block, 128 x 64 wave tiles): large maps with full 128-cout tiles
+    const int rc = conv_v4_dispatch(p, a->impl, st);
+    if (rc != -1000) return rc;
+    PP_REQUIRE(a->impl == 0, PP_ERR_ARG, "pp_conv2d: impl %d (wide halo tiles) not available for this shape", a->impl);
+  }
+  if (a->dtype == PP_F16 && !deform && (a->impl == 0 || (a->impl >= 70 && a->impl < 80) || (a->impl >= 82 && a->impl <= 89) || a->impl == 106)) {
     // halo-tile kernel family (stride-1 "same" 3x3 / 1x5 / 5x1 windows over 64-channel-multiple sources)
     const int rc = conv_v3_dispatch(p, a->impl, st);
     if (rc != -1000) return rc;

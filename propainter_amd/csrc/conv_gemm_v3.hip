@@ -52,7 +52,7 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : 1) void conv_h
   typedef _Float16 T;
   constexpr int BM = TH * TW;                                   // 128 px (2 blocks/CU) or 256 px (8 waves, 1 block/CU)
   constexpr int WAVES_N = BN >= 32 ? 2 : 1;                      // BN 16 (tiny cout): all waves along the pixels
-  constexpr int NW = BM / 32 * (64 / WMT), WAVES_M = NW / WAVES_N;
+  constexpr int NW = WMT == 128 ? BM / 64 : BM / 32 * (64 / WMT), WAVES_M = NW / WAVES_N;
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 16, TN = WN / 16;
   constexpr int PH = TH + KH - 1, PW = TW + KW - 1, P = PH * PW;
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : 1) void conv_h
   constexpr int EPI_LD = EPI_WN + 4;
   constexpr int EPI_BYTES = NW * WM * EPI_LD * 4;
   constexpr int LDS_BYTES = PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES;
-  static_assert((BM == 128 || BM == 256) && (TW == 16 || TW == 8) && PPW <= NTAPS && (BN % 32 == 0 || BN == 16) &&
+  static_assert((BM == 128 || BM == 256) && (TW == 16 || TW == 8) && PPW <= 3 * NTAPS && (BN % 32 == 0 || BN == 16) &&
                     LDS_BYTES <= (BM == 128 ? 80 : 160) * 1024, "tile");
 
   __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
@@ -219,7 +219,12 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : 1) void conv_h
       if (t == 0 && have_next) v3_entry_ready(en);
       const bool more_b = ks + 1 < nk;
       if constexpr (STAGGER != 3 && STAGGER != 6 && STAGGER != 9) { if (more_b) V3_ISSUE_B(ks + 1, par ^ 1); }
-      if constexpr (STAGGER != 9) { if (t < PPW && have_next) V3_ISSUE_PIECE(t, pnext, en); }
+      if constexpr (STAGGER != 9) {
+        if (have_next) {
+#pragma unroll
+          for (int jj = t; jj < PPW; jj += NTAPS) V3_ISSUE_PIECE(jj, pnext, en);     // (one piece per step for the shipped tiles: PPW <= NTAPS)
+        }
+      }
       if constexpr (PROF) { pf_a = __builtin_readcyclecounter(); pf_issue += pf_a - pf_c; }
       const char* sb = bst0 + par * BSTAGE;
 #pragma unroll
@@ -285,7 +290,7 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : 1) void conv_h
   };
   const RowMap rowmap{wm * WM, ty0, tx0, p.H, p.W, (long long)n * p.H};
   if constexpr (WN <= 64) {
-    conv_epilogue<WM, WN>(p, acc, lds + wave * (EPI_BYTES / NW), lane, n0 + wn * WN, 0, p.out, rowmap, nullptr, PROF ? &pf_e2 : nullptr);
+    conv_epilogue<WM, WN, WN / 16, 0, (WM <= 64)>(p, acc, lds + wave * (EPI_BYTES / NW), lane, n0 + wn * WN, 0, p.out, rowmap, nullptr, PROF ? &pf_e2 : nullptr);
   } else {
     // 128-cout wave tiles (BN 256, experimental): two passes of 64 couts through the same wave-private staging tile
     // (LDS operations of one wave execute in order, so the second pass cannot overtake the first pass's reads)
@@ -343,6 +348,12 @@ int conv_v3_dispatch(const ConvParams& p, int cfg, hipStream_t stream) {
     if (kh == 3 && kw == 3) return launch_v3<8, 16, 3, 3, 128, false, 5>(p, stream);
     if (kh == 1 && kw == 5) return launch_v3<8, 16, 1, 5, 128, false, 5>(p, stream);
     if (kh == 5 && kw == 1) return launch_v3<16, 8, 5, 1, 128, false, 5>(p, stream);
+    return -1000;
+  }
+  if (cfg == 106) {   // probe: 256 px x 128 couts per block, FOUR waves of 128 px x 64 couts (0.375 KB of fragment reads per MFMA
+                      // instead of 0.5, half the weight DMA per MFMA) -- one block per CU (120 KB LDS), one wave per SIMD
+    if (kh == 3 && kw == 3) return launch_v3<16, 16, 3, 3, 128, false, 0, 128>(p, stream);
+    if (kh == 1 && kw == 5) return launch_v3<16, 16, 1, 5, 128, false, 0, 128>(p, stream);
     return -1000;
   }
   if (cfg == 85) {   // 8 waves of 32 x 64 per 128 x 128 block tile, 4 waves per SIMD

@@ -55,6 +55,8 @@ __device__ __forceinline__ float act_late(float v, int act, float slope) {
 int conv_v2_dispatch(const ConvParams& p, int cfg, hipStream_t stream);
 // conv_gemm_v3.hip (halo tiles); returns -1000 when the shape is outside that family (caller falls back to v2)
 int conv_v3_dispatch(const ConvParams& p, int cfg, hipStream_t stream);
+// conv_gemm_v4.hip (wide halo tiles: 256 px x 128 couts, 32-channel steps); returns -1000 outside that family (caller falls back to v3)
+int conv_v4_dispatch(const ConvParams& p, int cfg, hipStream_t stream);
 // conv_dcn.hip (patch-staged modulated deformable 3x3 convolution, fp16); returns -1000 when the layer is outside that family
 int conv_dcn_dispatch(const ConvParams& p, hipStream_t stream, int dbg = 0);
 // conv_gemm_ast.hip (A-stationary short-K GEMM); returns -1000 when the layer is outside that family
