@@ -90,6 +90,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU-oracle sample (and with it the parity block)")
     ap.add_argument("--no-profile", action="store_true", help="skip the instrumented (per-kernel HIP events) step")
     ap.add_argument("--no-precisions", action="store_true", help="skip the extra timed steps at the other RAFT precisions")
+    ap.add_argument("--raft-streams", type=int, default=2,
+                    help="RAFT encoders / pair-direction groups on this many HIP streams (InferenceConfig.raft_streams; identical flows)")
     ap.add_argument("--window-streams", type=int, default=2,
                     help="generator windows in flight on separate HIP streams (pipeline.InferenceConfig.window_streams)")
     ap.add_argument("--single-pass", action="store_true",
@@ -244,7 +246,7 @@ def main():
     models = seeded_models(dev, raft_precision=args.raft_dtype)
     cfg = InferenceConfig(raft_iter=args.raft_iter, subvideo_length=args.subvideo_length,
                           neighbor_length=args.neighbor_length, ref_stride=args.ref_stride, fp16=fp16,
-                          window_streams=args.window_streams)
+                          window_streams=args.window_streams, raft_streams=args.raft_streams)
     m = scipy.ndimage.binary_dilation(synthetic_mask(H, W), iterations=4).astype(np.uint8) * 255
     sharded = bool(args.sharded)
     exchange_stats = {}
@@ -362,7 +364,7 @@ def main():
             t1 = time.perf_counter()
             # windows serialised on one stream here: a launch's event pair then brackets that launch alone (with
             # concurrent windows the durations of overlapping launches would be counted twice)
-            eager_step(hook, dataclasses.replace(cfg, window_streams=1))
+            eager_step(hook, dataclasses.replace(cfg, window_streams=1, raft_streams=1))
             torch.cuda.synchronize()
             prof_wall = time.perf_counter() - t1
         stages = {marks[i][0]: marks[i - 1][1].elapsed_time(marks[i][1]) for i in range(1, len(marks))}
@@ -475,7 +477,7 @@ def main():
             "data": "synthetic (seeded clip + rectangular mask dilated x4, seeded weights of the reference architecture)",
             "config": {"workload": work, "height": H, "width": W, "frames": L, "windows": len(sched),
                        "raft_dtype": args.raft_dtype, "stages_dtype": "f16" if fp16 else "f32", "parallelism": par,
-                       "window_streams": args.window_streams},
+                       "window_streams": args.window_streams, "raft_streams": args.raft_streams},
             "roofline": roof, "cpu_baseline": cpu, "parity": parity, "raft_precisions": raft_precisions,
             "memory": {"peak_allocated_GB_eager_pass": peak_eager / 1e9, "peak_allocated_GB_process": peak_total / 1e9,
                        "note": "torch.cuda.max_memory_allocated; the eager pass is what a one-shot CLI run needs, the process "

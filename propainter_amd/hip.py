@@ -157,6 +157,48 @@ def _stream(t):
     return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
+_side_streams = {}
+
+
+def side_streams(device, n):
+    """n side streams of `device` (created once, outside any graph capture)."""
+    if n < 2:
+        return []
+    key = (str(device), n)
+    if key not in _side_streams:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("side streams must be created by an eager pass before graph capture")
+        _side_streams[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
+    return _side_streams[key]
+
+
+def fork_join(device, thunks, n_streams):
+    """Runs independent pieces of GPU work (`thunks`: callables returning a tensor or a tuple / list of tensors) on up to
+    n_streams side streams forked from and joined to the current stream -- under hipGraph capture this records parallel
+    branches.  Same kernels on the same data: results are identical to running the thunks one after another.  The inputs a
+    thunk reads must stay referenced by the caller until this function returns (they belong to the current stream's pool)."""
+    device = torch.device(device)
+    lanes = side_streams(device, min(n_streams, len(thunks))) if device.type == "cuda" else []
+    if len(lanes) < 2:
+        return [th() for th in thunks]
+    cur = torch.cuda.current_stream(device)
+    results = [None] * len(thunks)
+    for i0 in range(0, len(thunks), len(lanes)):
+        group = []
+        for s_, k in zip(lanes, range(i0, min(len(thunks), i0 + len(lanes)))):
+            s_.wait_stream(cur)
+            with torch.cuda.stream(s_):
+                results[k] = thunks[k]()
+            group.append((k, s_))
+        for k, s_ in group:
+            cur.wait_stream(s_)
+            r = results[k]
+            for t in (r if isinstance(r, (tuple, list)) else (r,)):
+                if torch.is_tensor(t):
+                    t.record_stream(cur)
+    return results
+
+
 def on_device_of(t):
     """Context manager: makes the device of `t` current for the launches inside (no-op when it already is)."""
     return torch.cuda.device(t.device)

@@ -229,6 +229,7 @@ class RAFT_bi(nn.Module):
         # clip driver may hand over all frames at once instead of the reference's 12/8/4/2-frame clips
         # (inference_propainter.py:302-330): identical flows, each frame encoded once, larger GEMMs.
         self.batch_invariant = True
+        self.supports_streams = True          # forward(..., streams=n): encoders / pair groups on n HIP streams
         self.max_pairs = max_pairs
         self._engines = {}
         self.to(device)
@@ -246,7 +247,7 @@ class RAFT_bi(nn.Module):
 
     @hip.on_input_device
     @torch.no_grad()
-    def forward(self, gt_local_frames, iters=20):
+    def forward(self, gt_local_frames, iters=20, streams=1):
         b, l_t, c, h, w = gt_local_frames.size()
         hip.require_gpu(gt_local_frames, "RAFT_bi")
         if h % 8 or w % 8 or h < 128 or w < 128:
@@ -258,11 +259,16 @@ class RAFT_bi(nn.Module):
         # encoders once per frame, in frame chunks that keep every activation below 2 GiB (32-bit buffer offsets of the
         # LDS-DMA gather; InstanceNorm statistics are per frame, so chunking does not change results)
         fchunk = max(1, (1 << 30) // (h * w * 16 * 4))     # largest activation: [H/2, W/2, 64] per frame, <= 1 GiB in fp32
+        # (streams > 1, engine extension: the two encoders of a chunk, and below the pair-direction groups, run on separate HIP
+        # streams -- forked from / joined to the current one, parallel branches under hipGraph capture.  Every frame / pair is
+        # computed independently of its batch neighbours, so the flows are identical.)
+        dev = gt_local_frames.device
         fm, cx_ = [], []
         for s in range(0, b * l_t, fchunk):
             x = hip.nchw_to_nhwc(fr[s:s + fchunk].contiguous(), out_dtype=dt, cpad=8)
-            fm.append(eng.encode(eng.fnet, x, True))
-            cx_.append(eng.encode(eng.cnet, x, False))
+            f_, c_ = hip.fork_join(dev, [lambda: eng.encode(eng.fnet, x, True), lambda: eng.encode(eng.cnet, x, False)], streams)
+            fm.append(f_)
+            cx_.append(c_)
         fmap = (fm[0] if len(fm) == 1 else torch.cat(fm, 0)).view(b, l_t, h // 8, w // 8, 256)
         ctx = (cx_[0] if len(cx_) == 1 else torch.cat(cx_, 0)).view(b, l_t, h // 8, w // 8, 256)
         a_f, a_b = fmap[:, :-1].reshape(-1, h // 8, w // 8, 256), fmap[:, 1:].reshape(-1, h // 8, w // 8, 256)
@@ -276,8 +282,10 @@ class RAFT_bi(nn.Module):
             chunk = self.max_pairs or max(1, ((1 << 31) - 1) // (n8 * 328 * 2))
         else:                 # fp32 all-pairs pyramid: 1.34 x n8^2 x 4 bytes per pair-direction, 40 GB per chunk
             chunk = self.max_pairs or max(1, int(40e9 // (n8 * n8 * 4 * 1.34)))
-        ups = [eng.refine(f1[i:i + chunk].contiguous(), f2[i:i + chunk].contiguous(), cx[i:i + chunk].contiguous(), iters)
-               for i in range(0, P, chunk)]
+        if streams > 1 and P >= 2 * streams:
+            chunk = min(chunk, -(-P // streams))
+        parts = [(f1[i:i + chunk].contiguous(), f2[i:i + chunk].contiguous(), cx[i:i + chunk].contiguous()) for i in range(0, P, chunk)]
+        ups = hip.fork_join(dev, [(lambda a=a, b_=b_, c_=c_: eng.refine(a, b_, c_, iters)) for a, b_, c_ in parts], streams)
         up = torch.cat(ups, 0).to(gt_local_frames.dtype)
         half = P // 2
         return up[:half].view(b, l_t - 1, 2, h, w), up[half:].view(b, l_t - 1, 2, h, w)

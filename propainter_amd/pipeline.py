@@ -11,6 +11,8 @@ from dataclasses import dataclass
 import numpy as np
 import torch
 
+from . import hip
+
 
 @dataclass
 class InferenceConfig:
@@ -22,6 +24,8 @@ class InferenceConfig:
     fp16: bool = False
     window_streams: int = 2      # engine extension: generator windows in flight on separate HIP streams (bit-identical results;
                                  # measured 1167.7 -> 1102.9 ms per 720p clip with 2, 1114.6 with 3: profiles/r2_window_streams.txt)
+    raft_streams: int = 2        # engine extension: RAFT's two encoders, and its pair-directions in this many groups, on separate
+                                 # HIP streams (every pair is computed independently: identical flows)
 
 
 def get_ref_index(mid_neighbor_id, neighbor_ids, length, ref_stride=10, ref_num=-1):
@@ -73,17 +77,19 @@ def window_schedule(video_length, neighbor_length, ref_stride, subvideo_length):
     return sched
 
 
-def compute_flows(fix_raft, frames, raft_iter):
+def compute_flows(fix_raft, frames, raft_iter, streams=1):
     """Stage A (:302-330): RAFT (fp32 input like the reference) in clips of raft_clip_length with 1 frame overlap."""
     L = frames.size(1)
     sl = raft_clip_length(frames.size(-1))
+    # (engine extension; other RAFT callables keep the reference signature)
+    kw = {"streams": streams} if streams > 1 and getattr(fix_raft, "supports_streams", False) else {}
     if L <= sl or getattr(fix_raft, "batch_invariant", False):
         # the reference clips only to bound memory; an engine whose pairs are batch-independent takes the whole clip
-        return fix_raft(frames, iters=raft_iter)
+        return fix_raft(frames, iters=raft_iter, **kw)
     ff, fb = [], []
     for f in range(0, L, sl):
         e = min(L, f + sl)
-        a, b = fix_raft(frames[:, (f if f == 0 else f - 1):e], iters=raft_iter)
+        a, b = fix_raft(frames[:, (f if f == 0 else f - 1):e], iters=raft_iter, **kw)
         ff.append(a)
         fb.append(b)
     return torch.cat(ff, 1), torch.cat(fb, 1)
@@ -153,19 +159,11 @@ class Compositor:
 
 
 _index_cache = {}
-_stream_cache = {}
 
 
 def _window_streams(device, n):
     """n side streams of `device` (created once, outside any graph capture)."""
-    if n < 2:
-        return []
-    key = (str(device), n)
-    if key not in _stream_cache:
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("side streams must be created by an eager pass before graph capture")
-        _stream_cache[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
-    return _stream_cache[key]
+    return hip.side_streams(device, n)
 
 
 def _dev_index(ids, device):
@@ -206,7 +204,7 @@ def run_clip(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg: InferenceC
     L = frames.size(1)
     mark('start')
     if gt_flows is None:
-        gt_flows_bi = compute_flows(fix_raft, frames, cfg.raft_iter)
+        gt_flows_bi = compute_flows(fix_raft, frames, cfg.raft_iter, streams=cfg.raft_streams)
     else:
         gt_flows_bi = tuple(to_t(f).to(device).float()[None] for f in gt_flows)
         if any(f.shape != (1, L - 1, 2, frames.size(3), frames.size(4)) for f in gt_flows_bi):

@@ -200,7 +200,7 @@ def sharded_clip_steps(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg: 
     # ---- stage A: RAFT on the own pairs (needs frame `hi` of the right neighbour: raw input)
     fo = [plan.flows_own(q) for q in ranks]
     if fo[rank][1] > fo[rank][0]:
-        ff, fb = compute_flows(fix_raft, frames.sl(fo[rank][0], fo[rank][1] + 1), cfg.raft_iter)
+        ff, fb = compute_flows(fix_raft, frames.sl(fo[rank][0], fo[rank][1] + 1), cfg.raft_iter, streams=cfg.raft_streams)
         gt = torch.stack([ff, fb], 0)                                                        # [2,1,n,2,H,W]
     else:
         gt = torch.zeros((2, 1, 0, 2, H, W), dtype=torch.float32, device=device)

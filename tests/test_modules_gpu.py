@@ -247,6 +247,26 @@ def test_clip_graph_replay_is_bit_identical_to_eager(models, fp16):
         assert torch.equal(out, eager), f"graph replay differs from eager in {(out != eager).float().mean().item():.3e} of bytes"
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["f16", "f32"])
+def test_raft_streams_give_identical_flows(models, precision):
+    """RAFT_bi(streams=2): the two encoders and the two halves of the pair-directions on separate HIP streams -- every frame and
+    pair is computed independently of its batch neighbours, so the flows must be bit-identical to the single-stream order."""
+    raft = models[0]
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(12)
+    frames = (torch.rand(1, 5, 3, 128, 160, generator=g) * 2 - 1).to(dev)
+    old = raft.precision
+    try:
+        raft.precision = precision
+        f1, b1 = raft(frames, iters=4)
+        f2, b2 = raft(frames, iters=4, streams=2)
+        torch.cuda.synchronize()
+    finally:
+        raft.precision = old
+    assert torch.equal(f1, f2) and torch.equal(b1, b2)
+
+
 def test_window_streams_are_bit_identical(models):
     """Generator windows on 1 / 2 / 3 concurrent HIP streams (pipeline.InferenceConfig.window_streams): same kernels on the
     same data, blended in the same order -> identical bytes, eager and as a captured hipGraph with parallel branches."""

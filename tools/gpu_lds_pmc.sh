@@ -5,7 +5,7 @@ TAG=${1:-r2}
 R=$(pwd)
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --single-pass --window-streams 1 --no-cpu-baseline $BENCH_ARGS"
+CMD="python $R/bench.py --single-pass --window-streams 1 --raft-streams 1 --no-cpu-baseline $BENCH_ARGS"
 timeout 900 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $R/gpurun_out/pmc_lds --output-format csv -- $CMD > $R/gpurun_out/pmc_lds.log 2>&1
 echo "pmc lds exit $?"
 cd $R

@@ -5,7 +5,7 @@ TAG=${1:-r2}
 R=$(pwd)
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --single-pass --window-streams 1 --no-cpu-baseline $BENCH_ARGS"   # windows serialised: per-launch durations are not overlapped
+CMD="python $R/bench.py --single-pass --window-streams 1 --raft-streams 1 --no-cpu-baseline $BENCH_ARGS"   # windows serialised: per-launch durations are not overlapped
 timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_trace --output-format csv -- $CMD > $R/gpurun_out/prof_trace.log 2>&1
 echo "trace exit $?"
 if [ -z "$SKIP_PMC" ]; then
