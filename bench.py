@@ -413,6 +413,7 @@ def main():
                 if had_graph:
                     try:
                         from propainter_amd.pipeline import ClipGraph
+                        torch.cuda.empty_cache()          # the eager pass's cached blocks back to the driver: the capture builds its own pool
                         g = ClipGraph(models, L, H, W, cfg, dev, example=(frames_dev, masks_dev, masks_dev))
                         how = "mean of 2 hipGraph replays"
                     except Exception as e:
