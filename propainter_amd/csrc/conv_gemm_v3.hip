@@ -336,7 +336,11 @@ int conv_v3_dispatch(const ConvParams& p, int cfg, hipStream_t stream) {
     if ((long long)p.N * p.H * p.W * p.src[i].cstride * 2 >= (1ll << 31)) return -1000;
   if (cfg == 0 && ((p.cout_g > 16 && p.cout_g < 48) || p.H < 8 || p.W < 8)) return -1000;      // 17..47 couts / tiny maps: v2's narrow tiles do better
   // 64-cout tiles when the last 128-cout tile would be at most half full (cout 192 = 3 x 64: +5 % over 128 + 64-of-128, measured)
-  const bool n64 = cfg == 72 || (cfg != 71 && (p.cout_g <= 64 || (p.cout_g <= 192 && p.cout_g % 128 != 0 && p.cout_g % 128 <= 64)));
+  // ... and when the 128-cout tiles would not even give every CU one block (flow-completion chains: 2 x 90 x 160 px = 225 tiles):
+  // twice the blocks of half the size run 8-12 % faster there, 12 % slower at 450 tiles (tools/kbench 71 vs 72)
+  const long long blk128 = (long long)p.N * ((p.H + 7) / 8) * ((p.W + 15) / 16) * ((p.cout_g + 127) / 128);
+  const bool n64 = cfg == 72 || (cfg != 71 && (p.cout_g <= 64 || (p.cout_g <= 192 && p.cout_g % 128 != 0 && p.cout_g % 128 <= 64) ||
+                                               (blk128 <= 256 && p.cout_g % 64 == 0)));
   if (cfg == 73 || (cfg == 0 && p.cout_g <= 16)) {   // tiny cout (flow head, RGB decoder): A-bandwidth bound, halo tiles cut the gather 6x
     if (kh == 3 && kw == 3) return launch_v3<8, 16, 3, 3, 16>(p, stream);
     if (kh == 1 && kw == 5) return launch_v3<8, 16, 1, 5, 16>(p, stream);
