@@ -248,6 +248,42 @@ def test_clip_graph_replay_is_bit_identical_to_eager(models, fp16):
 
 
 @pytest.mark.gpu
+def test_clip_graph_capture_and_replay_under_rccl_process_group():
+    """hipGraph capture of the whole pass (pipeline.ClipGraph, incl. the side-stream branches) inside a process that has an
+    initialised `nccl` (RCCL) process group, as every rank of `bench.py --gpus N` has: capture, replay, compare with the eager
+    pass, then a barrier on the group.  Child process with a hard timeout."""
+    import subprocess
+    import sys
+    code = """
+import os, numpy as np, torch, torch.distributed as dist
+os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29579')
+torch.cuda.set_device(0)
+dev = torch.device('cuda', 0)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+x = torch.ones(8, device=dev); dist.all_reduce(x); torch.cuda.synchronize()           # the communicator exists before the capture
+from propainter_amd.pipeline import ClipGraph, InferenceConfig, run_clip
+from propainter_amd.synthetic import seeded_models, synthetic_clip, synthetic_mask
+models = seeded_models(dev, raft_precision='f16')
+L, H, W = 8, 128, 192
+cfg = InferenceConfig(raft_iter=4, subvideo_length=80, neighbor_length=4, ref_stride=3, fp16=True)
+clip = synthetic_clip(L, H, W, seed=5)
+m = np.repeat(synthetic_mask(H, W)[None], L, 0)
+eager = run_clip(models, clip, m, m, cfg, dev).clone()
+cg = ClipGraph(models, L, H, W, cfg, dev)
+out = cg(clip, m, m)
+torch.cuda.synchronize()
+assert torch.equal(out, eager), 'graph replay differs from the eager pass'
+dist.barrier(); torch.cuda.synchronize()
+dist.destroy_process_group()
+print('GRAPH_UNDER_PG_OK')
+"""
+    env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=400)
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 0 and "GRAPH_UNDER_PG_OK" in out, out[-3000:]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("precision", ["f16", "f32"])
 def test_raft_streams_give_identical_flows(models, precision):
     """RAFT_bi(streams=2): the two encoders and the two halves of the pair-directions on separate HIP streams -- every frame and
