@@ -223,3 +223,29 @@ def test_c_weight_packer_equals_the_python_packer(cfg):
     rc = L.pp_conv_pack_weight(wn.ctypes.data, cfg["cout"], kh, kw, len(cin), sc, groups, ktn.ctypes.data, kchunks, hip.PP_F16,
                                out16.ctypes.data, out16.size)
     assert rc == cout_pad and np.array_equal(out16, ref.numpy().astype(np.float16))
+
+
+def test_shipped_lds_swizzles_are_conflict_free_under_the_lane_group_model():
+    """tools/lds_swizzle_check.py: the fragment layouts the kernels ship must be conflict-free under ds_read_b128's lane groups
+    (MI355X_MICROARCH.md, LDS) -- the halo patch at EVERY start row, the weight tile at 16-aligned starts; the round-1 patch key
+    is kept in the table as the counter-example (2-way conflicts at 24 of 32 alignments)."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "lds_swizzle_check.py")
+    spec = importlib.util.spec_from_file_location("lds_swizzle_check", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = {name: mod.worst_and_bad(fn, starts, kks) for name, fn, starts, kks in mod.CASES}
+    shipped = [k for k in res if "[shipped]" in k or "16-aligned" in k or "32-channel" in k]
+    assert len(shipped) == 3
+    for k in shipped:
+        assert res[k][0] == 1 and res[k][1] == 0, (k, res[k])
+    old = [k for k in res if "[round 1]" in k][0]
+    assert res[old][0] == 2 and res[old][1] * 4 == res[old][2] * 3      # 24 of 32 alignments
+
+
+def test_fork_join_is_sequential_without_a_gpu():
+    from propainter_amd import hip
+    import torch
+    out = hip.fork_join("cpu", [lambda: torch.ones(2), lambda: (torch.zeros(1), torch.ones(1))], 2)
+    assert torch.equal(out[0], torch.ones(2)) and isinstance(out[1], tuple)
