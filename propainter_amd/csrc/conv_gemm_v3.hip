@@ -69,6 +69,7 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : 1) void conv_h
   constexpr int EPI_LD = EPI_WN + 4;
   constexpr int EPI_BYTES = NW * WM * EPI_LD * 4;
   constexpr int LDS_BYTES = PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES;
+  constexpr bool PRE_MFMA = STAGGER == 0 && BM == 128 && (BN == 128 || BN == 64) && WMT == 64 && PATCH_BYTES >= 16 * 1024;   // (STAGGER 11, impl 109: off, for A/B)
   static_assert((BM == 128 || BM == 256) && (TW == 16 || TW == 8) && PPW <= 3 * NTAPS && (BN % 32 == 0 || BN == 16) &&
                     LDS_BYTES <= (BM == 128 ? 80 : 160) * 1024, "tile");
 
@@ -274,6 +275,50 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : 1) void conv_h
     }
   }
   if constexpr (PROF) pf_b = __builtin_readcyclecounter();
+  // ---- pre-activation addend through the matrix cores (PRE_MFMA): out = act(conv + preadd) as one more K block with IDENTITY
+  // weights -- the preadd tile (128 px x 64 couts per wave column, fp16) is LDS-DMA'd into the free patch buffers and multiplied
+  // by 1.0 into the fp32 accumulators (exact), so the epilogue keeps its fast register path instead of reading the addend per
+  // output row (measured +63 us on a 193 us launch, profiles/r2_conv_epilogue_ab.txt).  Each wave needs only the 64 addend
+  // channels of its own cout half: 2 x 16 KB, 16 MFMAs per wave, identity fragments built in registers (no weight traffic).
+  bool preadd_in_acc = false;
+  if constexpr (PRE_MFMA) {
+    if (p.preadd != nullptr && p.out_scale == 1.f && p.cout_g % BN == 0 &&        // (the addend is not scaled; full cout tiles only;
+        (long long)nrec * p.preadd_cstride * 2 < (1ll << 31)) {                       //  32-bit buffer offsets)
+      __syncthreads();                                // every wave's fragment reads of the last K step are complete
+      const __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.preadd + p.preadd_choff * 2), 0,
+                                                                             nrec * p.preadd_cstride * 2, 0x00020000);
+      const int lcp = slot ^ rin;
+#pragma unroll
+      for (int q = 0; q < 16 / NW; ++q) {
+        const int piece = q * NW + wave;
+        const int m = piece * 8 + rin;                 // tile pixel (row-major in the TH x TW tile)
+        const int iy = ty0 + m / TW, ix = tx0 + m % TW;
+        const bool ok = (iy < p.H) & (ix < p.W);
+        const int base = ok ? ((n * p.H + iy) * p.W + ix) * (p.preadd_cstride * 2) + n0 * 2 + lcp * 16 : (int)0x80000000;
+        v3_dma16(rsp, patch0 + piece * 1024, base, 0);
+        if constexpr (BN == 128) v3_dma16(rsp, patch0 + PATCH_BYTES + piece * 1024, base, 128);     // the second 64 couts of the tile
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      // the wave's couts are channels c0 .. c0 + WN - 1 of addend patch pj; cout fragment f sits in k chunk (c0 + 16 f) / 32
+      const int pj = BN == 128 ? wn : 0, c0 = BN == 128 ? 0 : wn * WN;
+      const char* pp = patch0 + pj * PATCH_BYTES;
+#pragma unroll
+      for (int f = 0; f < TN; ++f) {
+        const int kk = (c0 + f * 16) >> 5, kpos = (c0 + f * 16) & 31;       // (kk is compile-time for BN 128, wave-uniform for BN 64)
+        f16x8 idf;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) idf[i] = (l4 * 8 + i == kpos + l15) ? (_Float16)1 : (_Float16)0;
+#pragma unroll
+        for (int b = 0; b < TM; ++b) {
+          const int row = wm * WM + b * 16 + l15;
+          const f16x8 af = *reinterpret_cast<const f16x8*>(pp + row * 128 + (((kk * 4 + l4) ^ (row & 7)) << 4));
+          acc[f][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(idf, af, acc[f][b], 0, 0, 0);
+        }
+      }
+      preadd_in_acc = true;
+    }
+  }
   __syncthreads();                                    // LDS becomes the epilogue tile
   unsigned long long pf_e1 = 0, pf_e2 = 0;
   if constexpr (PROF) pf_e1 = __builtin_readcyclecounter();
@@ -290,7 +335,8 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : 1) void conv_h
   };
   const RowMap rowmap{wm * WM, ty0, tx0, p.H, p.W, (long long)n * p.H};
   if constexpr (WN <= 64) {
-    conv_epilogue<WM, WN, WN / 16, 0, (WM <= 64)>(p, acc, lds + wave * (EPI_BYTES / NW), lane, n0 + wn * WN, 0, p.out, rowmap, nullptr, PROF ? &pf_e2 : nullptr);
+    conv_epilogue<WM, WN, WN / 16, 0, (WM <= 64)>(p, acc, lds + wave * (EPI_BYTES / NW), lane, n0 + wn * WN, 0, p.out, rowmap, nullptr, PROF ? &pf_e2 : nullptr,
+                                                  preadd_in_acc);
   } else {
     // 128-cout wave tiles (BN 256, experimental): two passes of 64 couts through the same wave-private staging tile
     // (LDS operations of one wave execute in order, so the second pass cannot overtake the first pass's reads)
@@ -360,6 +406,12 @@ int conv_v3_dispatch(const ConvParams& p, int cfg, hipStream_t stream) {
     if (kh == 1 && kw == 5) return launch_v3<16, 16, 1, 5, 128, false, 0, 128>(p, stream);
     return -1000;
   }
+  if (cfg == 109) {   // the pre-activation addend / residual read by the epilogue instead of going through the matrix cores (A/B)
+    if (kh == 3 && kw == 3) return launch_v3<8, 16, 3, 3, 128, false, 11>(p, stream);
+    if (kh == 1 && kw == 5) return launch_v3<8, 16, 1, 5, 128, false, 11>(p, stream);
+    if (kh == 5 && kw == 1) return launch_v3<16, 8, 5, 1, 128, false, 11>(p, stream);
+    return -1000;
+  }
   if (cfg == 85) {   // 8 waves of 32 x 64 per 128 x 128 block tile, 4 waves per SIMD
     if (kh == 3 && kw == 3) return launch_v3<8, 16, 3, 3, 128, false, 0, 32>(p, stream);
     if (kh == 1 && kw == 5) return launch_v3<8, 16, 1, 5, 128, false, 0, 32>(p, stream);
@@ -413,6 +465,17 @@ int conv_v3_dispatch(const ConvParams& p, int cfg, hipStream_t stream) {
     return -1000;
   }
 #endif
+  if (cfg != 109 && p.cout_g >= 32 && p.residual != nullptr && p.preadd == nullptr && p.fuse == PP_FUSE_NONE && p.act == PP_ACT_NONE && p.out_f16 &&
+      p.out_scale == 1.f && p.cout_g % (n64 ? 64 : 128) == 0 && ((p.res_cstride | p.res_choff) & 7) == 0 && ((uintptr_t)p.residual % 16) == 0) {
+    // a residual added to a LINEAR convolution (out = act2(conv + bias + residual)) is a pre-activation addend: same value, and the
+    // addend path goes through the matrix cores instead of being read row by row in the epilogue (see PRE_MFMA in the kernel)
+    ConvParams q = p;
+    q.preadd = p.residual; q.preadd_cstride = p.res_cstride; q.preadd_choff = p.res_choff;
+    q.residual = nullptr; q.act = p.act2; q.act_param = 0.f; q.act2 = PP_ACT_NONE;
+    if (kh == 3 && kw == 3) return n64 ? launch_v3<8, 16, 3, 3, 64>(q, stream) : launch_v3<8, 16, 3, 3, 128>(q, stream);
+    if (kh == 1 && kw == 5) return n64 ? launch_v3<8, 16, 1, 5, 64>(q, stream) : launch_v3<8, 16, 1, 5, 128>(q, stream);
+    if (kh == 5 && kw == 1) return n64 ? launch_v3<16, 8, 5, 1, 64>(q, stream) : launch_v3<16, 8, 5, 1, 128>(q, stream);
+  }
   if (kh == 3 && kw == 3) return n64 ? launch_v3<8, 16, 3, 3, 64>(p, stream) : launch_v3<8, 16, 3, 3, 128>(p, stream);
   if (kh == 1 && kw == 5) return n64 ? launch_v3<8, 16, 1, 5, 64>(p, stream) : launch_v3<8, 16, 1, 5, 128>(p, stream);
   if (kh == 5 && kw == 1) return n64 ? launch_v3<16, 8, 5, 1, 64>(p, stream) : launch_v3<16, 8, 5, 1, 128>(p, stream);

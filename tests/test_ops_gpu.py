@@ -154,6 +154,44 @@ def test_conv_fused_gru_epilogue(dev, k, pad, mode):
     check("h_new", net.permute(0, 3, 1, 2), href, t)
 
 
+@pytest.mark.parametrize("impl", [0, 109, 12], ids=["auto", "halo_epilogue_reads", "v2"])
+@pytest.mark.parametrize("cout,hw,k,pad", [(128, (40, 72), (3, 3), 1), (64, (40, 72), (3, 3), 1), (128, (19, 27), (3, 3), 1), (256, (33, 50), (1, 5), (0, 2))],
+                         ids=["c128", "c64", "c128_small_grid", "c256_1x5"])
+@pytest.mark.parametrize("act2", [None, "relu"])
+def test_conv_linear_residual_and_preadd_through_the_matrix_cores(dev, cout, hw, k, pad, act2, impl):
+    """A residual added to a LINEAR convolution (out = act2(conv + bias + residual): the backbone convolutions of both propagation
+    modules) and a pre-activation addend (the SepConvGRU partial sums) enter the halo kernel as one more K block with identity
+    weights (exact: fp16 x 1.0 into the fp32 accumulators) -- against torch, and against the epilogue-read form of the same kernel
+    (impl 109 exists in diagnostic builds only; skipped otherwise) and the v2 kernel."""
+    from propainter_amd import hip
+    from propainter_amd.conv import ConvLayer
+    dt = torch.float16
+    g = torch.Generator().manual_seed(123)
+    N, (H, W), C = 2, hw, 128
+    x = (torch.randn(N, C, H, W, generator=g) * 0.8).to(dt).float()
+    w = torch.randn(cout, C, *k, generator=g) / math.sqrt(C * k[0] * k[1])
+    b = torch.randn(cout, generator=g) * 0.1
+    res = (torch.randn(N, cout, H, W, generator=g) * 2).to(dt).float()
+    y = F.conv2d(x, w.to(dt).float(), b, 1, pad)
+    ref_res = y + res
+    if act2 == "relu":
+        ref_res = F.relu(ref_res)
+    ref_pre = torch.tanh(y + res)
+    layer = ConvLayer(w, b, padding=pad, src_channels=[C], dtype=dt, device=dev)
+    layer.impl = impl
+    xd, rd = nhwc(x, dt), nhwc(res, dt)
+    try:
+        out = layer([xd], residual=rd, act2=act2)
+        out_pre = layer([xd], preadd=rd, act="tanh")
+        torch.cuda.synchronize()
+    except RuntimeError as e:
+        if impl == 109 and "not available" in str(e):
+            pytest.skip("impl 109 is compiled in PP_DIAG builds only")
+        raise
+    check("conv + residual", out[..., :cout].permute(0, 3, 1, 2), ref_res, tol(dt, 2.0))
+    check("tanh(conv + preadd)", out_pre[..., :cout].permute(0, 3, 1, 2), ref_pre, tol(dt, 2.0))
+
+
 @pytest.mark.parametrize("dt", [torch.float16, torch.float32], ids=["f16", "f32"])
 def test_raft_flow_taps_7x1_equals_7x7(dev, dt):
     """Motion encoder convf1 = Conv2d(2, 128, 7, padding=3) (RAFT/update.py:85,92) as pp_raft_flow_taps + a 7x1 convolution over
