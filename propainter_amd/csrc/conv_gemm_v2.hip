@@ -45,7 +45,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 }
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int S, bool UNI, int SCHED = 0>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_v2_kernel(const ConvParams p) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N <= 4 && BM * BN <= 128 * 128) ? 2 : 1) void conv_gemm_v2_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the body uses device-only types (__amdgpu_buffer_rsrc_t): the host pass only needs the stub
   typedef _Float16 T;
   constexpr int NW = WAVES_M * WAVES_N;
@@ -376,6 +376,53 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_v2_kernel(co
   }
   __syncthreads();                                    // every wave is done with the stages: LDS becomes the epilogue tile
 
+  // ---- pre-activation addend / residual of a LINEAR layer through the matrix cores (as in conv_gemm_v3.hip: an operand the
+  // epilogue reads per output row costs like an un-overlapped stream): the BM x 128 fp16 tile is LDS-DMA'd into the free stages and
+  // multiplied by an identity fragment into the fp32 accumulators (exact); the epilogue then sees a plain layer.  64 x 64 wave tiles.
+  bool addend_in_acc = false;
+  int act_after = p.act;
+  if constexpr (WM == 64 && WN == 64 && BN == 128 && BK == 64 && 2 * BM * 128 <= PIPE_BYTES) {
+    const bool lin_res = p.residual != nullptr && p.preadd == nullptr && p.act == PP_ACT_NONE;      // out = act2(conv + bias + residual)
+    const char* ad = p.preadd != nullptr ? p.preadd : p.residual;
+    const int ad_cs = p.preadd != nullptr ? p.preadd_cstride : p.res_cstride;
+    const int ad_co = p.preadd != nullptr ? p.preadd_choff : p.res_choff;
+    if ((p.preadd != nullptr || lin_res) && p.groups == 1 && p.fuse == PP_FUSE_NONE && p.out_f16 && p.out_scale == 1.f &&
+        p.cout_g % 128 == 0 && (ad_cs & 7) == 0 && (ad_co & 7) == 0 && ((unsigned long long)ad & 15) == 0 &&
+        p.M * (long long)ad_cs * 2 < (1ll << 31)) {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ad + ad_co * 2), 0, (int)(p.M * ad_cs * 2), 0x00020000);
+      const int s8 = lane & 7, r8 = lane >> 3;         // one instruction = 8 rows x 128 B; logical chunk = slot ^ (row & 7)
+      const int lcp = s8 ^ r8;
+#pragma unroll
+      for (int q = 0; q < BM / 8 / NW; ++q) {
+        const int piece = q * NW + wave;
+        const long long m = m0 + piece * 8 + r8;
+        const int off = m < p.M ? (int)(m * ad_cs * 2) + n0 * 2 + lcp * 16 : (int)0x80000000;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(lds + piece * 1024), 16, off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(lds + BM * 128 + piece * 1024), 16, off, 128, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const int l15 = lane & 15, l4 = lane >> 4;
+      const char* pp = lds + wn * (BM * 128);          // the wave's 64 couts are the 64 channels of half wn
+#pragma unroll
+      for (int f = 0; f < TN; ++f) {
+        const int kk = f >> 1, kpos = (f & 1) * 16;
+        f16x8 idf;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) idf[i] = (l4 * 8 + i == kpos + l15) ? (_Float16)1 : (_Float16)0;
+#pragma unroll
+        for (int b = 0; b < TM; ++b) {
+          const int row = wm * WM + b * 16 + l15;
+          const f16x8 afr = *reinterpret_cast<const f16x8*>(pp + row * 128 + (((kk * 4 + l4) ^ (row & 7)) << 4));
+          acc[f][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(idf, afr, acc[f][b], 0, 0, 0);
+        }
+      }
+      addend_in_acc = true;
+      if (lin_res) act_after = p.act2;
+      __syncthreads();                                // the operand tile has been consumed: LDS becomes the epilogue tile
+    }
+  }
+
   // ---- epilogue (conv_epilogue.h): wave-private staging tile; 8 consecutive couts (16 B fp16 / 32 B fp32) per lane
   struct RowMap {
     long long m_base, M;
@@ -385,9 +432,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_v2_kernel(co
     }
   };
   const RowMap rowmap{m0 + wm * WM, p.M};
-  if constexpr (WN >= 16 && WN % 8 == 0)
-    conv_epilogue<WM, WN>(p, acc, lds + wave * (WM * EPI_LD * 4), lane, n0 + wn * WN, g,
-                          p.out + (long long)g * p.out_gstride * (p.out_f16 ? 2 : 4), rowmap);
+  if constexpr (WN >= 16 && WN % 8 == 0) {
+    if (addend_in_acc) {
+      ConvParams pe = p;
+      pe.preadd = nullptr; pe.residual = nullptr; pe.act = act_after; pe.act2 = PP_ACT_NONE;
+      if (act_after != p.act) pe.act_param = 0.f;
+      conv_epilogue<WM, WN>(pe, acc, lds + wave * (WM * EPI_LD * 4), lane, n0 + wn * WN, g,
+                            p.out + (long long)g * p.out_gstride * (p.out_f16 ? 2 : 4), rowmap);
+    } else {
+      conv_epilogue<WM, WN>(p, acc, lds + wave * (WM * EPI_LD * 4), lane, n0 + wn * WN, g,
+                            p.out + (long long)g * p.out_gstride * (p.out_f16 ? 2 : 4), rowmap);
+    }
+  }
 #endif
 }
 
