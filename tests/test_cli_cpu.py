@@ -114,3 +114,23 @@ def test_flow_files_use_the_reference_format(tmp_path):
         ref.flowwrite(flow, q)
         assert open(q, "rb").read() == raw
         assert np.array_equal(ref.flowread(q), back) and np.array_equal(flow_io.flowread(q), back)
+
+
+def test_bench_refuses_to_run_without_a_gpu_and_keeps_the_driver_contract():
+    """bench.py: `--gpus N --steps K --warmup W` are the driver's flags; with no flags it defaults to one GPU and a short run;
+    and it must fail loudly on a box without a GPU (the product path has no CPU fallback) instead of timing the oracle."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    text = h.stdout.decode()
+    assert h.returncode == 0
+    for flag in ("--gpus", "--steps", "--warmup", "--sharded", "--raft-dtype", "--window-streams", "--raft-streams"):
+        assert flag in text, flag
+    import torch
+    if torch.cuda.is_available():
+        return
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=300)
+    out = r.stdout.decode()
+    assert r.returncode != 0 and "needs a GPU" in out, out[-1500:]
