@@ -14,7 +14,8 @@
  *   - activation layout inside the engine is NHWC ("pixel-major"): element (n,y,x,c) of a tensor lives
  *     at ((n*H + y)*W + x)*cstride + choff + c, so concatenations are expressed as channel windows of
  *     a wider buffer instead of copies;
- *   - dtype codes: PP_F32 = 0, PP_F16 = 1.  Accumulation is always fp32.
+ *   - dtype codes: PP_F32 = 0, PP_F16 = 1; PP_F16S = 2 where an entry point says so: split-plane fp16 (value = hi + lo, the lo
+ *     plane `lo_off` elements after the hi plane in the pixel row; see pp_conv_args_t.split).  Accumulation is always fp32.
  */
 #ifndef PROPAINTER_HIP_H
 #define PROPAINTER_HIP_H
@@ -28,6 +29,7 @@ extern "C" {
 
 #define PP_F32 0
 #define PP_F16 1
+#define PP_F16S 2   /* split-plane fp16 pair (hi, lo): only where an entry point documents it */
 
 #define PP_ERR_ARG (-1)        /* bad shape / null pointer / unsupported size        */
 #define PP_ERR_DTYPE (-2)      /* unsupported dtype code                              */
@@ -138,6 +140,19 @@ typedef struct {
   int32_t fuse_b_cstride, fuse_b_choff;
   void* out2;
   int32_t out2_cstride, out2_choff;
+  /* ---- split-plane fp16 tensors ("f16x3": reference-class fp32 arithmetic on the fp16 matrix cores; dtype must be PP_F16) ----
+   * A split-plane tensor stores the fp32 value v of logical channel c as hi = fp16(v) at channel c and lo = fp16(v - hi) at
+   * channel c + <lo offset> of the same pixel row (22 significand bits).  With split = 1
+   *   - the SOURCES need no kernel support: the K table (pp_conv_build_ktable + the host-side expansion of
+   *     propainter_amd/conv.py) walks every 64-channel block of a source three times -- hi plane x W_hi, lo plane x W_hi, hi plane x
+   *     W_lo with W_hi = fp16(W), W_lo = fp16(W - W_hi) packed in that K order -- so every product is hi*hi + lo*hi + hi*lo with
+   *     fp32 accumulation (the dropped lo*lo term is < 2^-22 relative);
+   *   - every fp16 operand of the EPILOGUE (out when out_dtype == PP_F16, out2, preadd, residual, fuse_a, fuse_b) is split-plane with
+   *     the lo offsets below (multiples of 8 elements); out_dtype == PP_F32 writes plain fp32;
+   *   - PP_FUSE_DCN_OFFMASK, groups > 1 and the deformable mode are not available.                                                */
+  int32_t split;
+  int32_t out_lo, out2_lo, preadd_lo, res_lo, fuse_a_lo, fuse_b_lo;
+  int32_t pad2_;
 } pp_conv_args_t;
 
 #define PP_FUSE_NONE 0
@@ -202,7 +217,8 @@ int pp_corr_avgpool(const float* in, float* out, int64_t M, int H, int W, void* 
 
 /* 4-level 9x9 bilinear lookup.  lvl[l] = [B*h*w, Hl, Wl] fp32 map of every source pixel; coords fp32
  * NHWC [B,h,w,2] (x, y); out NHWC [B,h,w,out_cstride] channel l*81 + a*9 + b samples
- * (x/2^l + a - 4, y/2^l + b - 4) (first index moves x; RAFT/corr.py:36-43); channels 324..C_out_pad-1 = 0. */
+ * (x/2^l + a - 4, y/2^l + b - 4) (first index moves x; RAFT/corr.py:36-43); channels 324..C_out_pad-1 = 0.
+ * out_dtype PP_F16S: split-plane output, lo plane at out_cstride / 2 (>= out_cpad). */
 int pp_corr_lookup(const float* lvl0, const float* lvl1, const float* lvl2, const float* lvl3, const float* coords,
                    void* out, int out_cstride, int out_cpad, int B, int h, int w, int out_dtype, void* stream);
 
@@ -222,7 +238,8 @@ int pp_corr_lookup_otf(const void* f1, const void* f2_lvl0, const void* f2_lvl1,
  * that the convolution needs K = 7 x 16 instead of 49 taps x 8 padded channels: rows[pixel, 2*kx + c] = flow_c(x + kx - 3, y)
  * (zero outside the image row; channels 14, 15 zero), flow = coords1 - coords0 in fp32, rounded to `dtype`.  The layer is then
  * a 7x1 convolution over the 16 channels with weights w'[co, 2*kx + c, ky] = w[co, c, ky, kx].  Optionally the same flow is also
- * written to flow_out[pixel, flow_choff .. +1] (the GRU input window).  rows: NHWC [P,h,w,16] of dtype.                        */
+ * written to flow_out[pixel, flow_choff .. +1] (the GRU input window).  rows: NHWC [P,h,w,16] of dtype.  dtype PP_F16S: rows are
+ * [P,h,w,16 hi | 16 lo] and flow_out's lo plane sits flow_cstride / 2 after its hi plane.                                        */
 int pp_raft_flow_taps(const float* coords1, const float* coords0, void* rows, void* flow_out, int flow_cstride, int flow_choff,
                       int P, int h, int w, int dtype, void* stream);
 
@@ -295,6 +312,11 @@ int pp_depthwise_pool(const void* in, const float* weight, const float* bias, vo
 int64_t pp_instance_norm_workspace_floats(int N, int H, int W, int C);
 int pp_instance_norm(const void* in, void* out, float* stats_ws, int N, int H, int W, int C, float eps, int relu,
                      int dtype, void* stream);
+/* The same for the split-plane ("f16x3") RAFT feature encoder, with the tail of a ResidualBlock fused (RAFT/extractor.py:44-57):
+ * in = fp32 NHWC [N,H,W,C] (a pp_conv2d output with out_dtype PP_F32), out = split-plane fp16 NHWC [N,H,W,2C] (PP_F16S, lo plane at C),
+ * out = relu2(relu(IN(in)) + residual); residual = split-plane window (lo plane at res_cstride / 2) or NULL. */
+int pp_instance_norm_split(const float* in, void* out, float* stats_ws, int N, int H, int W, int C, float eps, int relu,
+                           const void* residual, int res_cstride, int res_choff, int relu2, void* stream);
 
 /* bilinear x2 upsampling, align_corners=True, NHWC [N,H,W,C] -> [N,2H,2W,C] (deconv blocks). */
 int pp_upsample2x(const void* in, void* out, int N, int H, int W, int C, int dtype, void* stream);
@@ -311,7 +333,8 @@ int pp_gru_gate(const void* zr, int zr_cstride, const void* h, int h_cstride, in
                 int q_cstride, void* out, int out_cstride, int out_choff, int64_t npix, int C, int mode, int dtype,
                 void* stream);
 
-/* layout packers: planar NCHW [N,C,H,W] (src dtype) <-> NHWC channel window (dst dtype). */
+/* layout packers: planar NCHW [N,C,H,W] (src dtype) <-> NHWC channel window (dst dtype).  pp_nchw_to_nhwc also takes
+ * out_dtype PP_F16S (fp32 input): split-plane output, lo plane at out_cstride / 2. */
 int pp_nchw_to_nhwc(const void* in, int in_dtype, void* out, int out_dtype, int out_cstride, int out_choff, int N,
                     int C, int H, int W, float scale, void* stream);
 int pp_nhwc_to_nchw(const void* in, int in_dtype, int in_cstride, int in_choff, void* out, int out_dtype, int N,

@@ -32,7 +32,41 @@ def fold_batchnorm(weight, bias, bn_weight, bn_bias, mean, var, eps=1e-5):
     return w.float(), b.float()
 
 
-def pack_weight(weight, src_channels, groups=1, ktable=None):
+KT_PLANE_LO = 1 << 24      # K-table code bits of a split-plane expansion: the chunk reads the lo plane of its source ...
+KT_WEIGHT_LO = 1 << 25     # ... / multiplies with W_lo = fp16(W - fp16(W)) instead of W_hi = fp16(W)
+
+
+def split_ktable(ktable, src_lo):
+    """Split-plane ("f16x3") expansion of a K table built by hip.build_ktable (channel-block-major order).
+
+    A split-plane source stores the fp32 value of channel c as hi = fp16(v) at c and lo = fp16(v - hi) at c + src_lo[s].  Every
+    block of the table (all taps of up to 64 channels of one source) is walked three times: hi plane x W_hi, lo plane x W_hi,
+    hi plane x W_lo (smallest terms last does not matter for the fp32 accumulators) -- so the fp16 kernels compute
+    hi*W_hi + lo*W_hi + hi*W_lo without knowing it.  The plane / weight choice of a chunk is recorded in bits 24 / 25 of its
+    code word (the kernels read bits 0..23 only); pack_weight() follows them.  Returns int32 [3 * chunks (padded to 8) + 1, 4]."""
+    kt = np.asarray(ktable)
+    if kt.shape[0] % 8 == 1:
+        kt = kt[:-1]
+    live = kt[(kt[:, 2] & 0xff) != 255]
+    key = (live[:, 2] & 0xff).astype(np.int64) * (1 << 20) + live[:, 3] // 64          # (source, 64-channel block)
+    starts = [0] + [i for i in range(1, len(live)) if key[i] != key[i - 1]] + [len(live)]
+    rows = []
+    for a, b in zip(starts[:-1], starts[1:]):
+        blk = live[a:b]
+        lo = blk.copy()
+        lo[:, 3] += np.asarray(src_lo, dtype=np.int64)[blk[:, 2] & 0xff].astype(np.int32)
+        lo[:, 2] |= KT_PLANE_LO
+        wl = blk.copy()
+        wl[:, 2] |= KT_WEIGHT_LO
+        rows += [blk, lo, wl]
+    out = np.concatenate(rows, 0)
+    pad = (-out.shape[0]) % 8
+    tail = np.zeros((pad + 1, 4), dtype=np.int32)
+    tail[:pad, 2] = 255
+    return np.ascontiguousarray(np.concatenate([out, tail], 0).astype(np.int32))
+
+
+def pack_weight(weight, src_channels, groups=1, ktable=None, src_lo=None):
     """weight [Cout, Cin_g, kh, kw] (any float dtype, CPU or GPU) -> (packed fp32 [groups, cout_pad, K], K, cout_g).
 
     The K order is whatever ``ktable`` (int32 [kchunks(+1), 4] from pp_conv_build_ktable: {dy, dx, src | grp<<8 | tap<<16,
@@ -62,9 +96,15 @@ def pack_weight(weight, src_channels, groups=1, ktable=None):
     code = kt[:, 2].astype(np.int64)
     src, tap, choff = code & 0xff, (code >> 16) & 0xff, kt[:, 3].astype(np.int64)
     live = src != 255
+    if src_lo is not None:       # split-plane table: a lo-plane chunk multiplies with the weights of the channel it shadows
+        choff = choff - np.where(live & ((code & KT_PLANE_LO) != 0), np.asarray(list(src_lo) + [0] * 256, dtype=np.int64)[np.minimum(src, len(src_lo))], 0)
     col0 = np.where(live, tap * ctot + np.asarray(bases + [0] * 256, dtype=np.int64)[np.minimum(src, len(bases))] + choff, 0)
     cols = torch.from_numpy((col0[:, None] + np.arange(8)[None, :]).reshape(-1))
     wk = wt[:, cols] * torch.from_numpy(np.repeat(live, 8)).float()[None, :]              # [Cout, K]
+    if (code & (KT_PLANE_LO | KT_WEIGHT_LO)).any():      # split-plane table: W_hi = fp16(W) / W_lo = fp16(W - W_hi) per chunk
+        w_hi = wk.half().float()
+        w_lo = (wk - w_hi).half().float()
+        wk = torch.where(torch.from_numpy(np.repeat((code & KT_WEIGHT_LO) != 0, 8))[None, :], w_lo, w_hi)
     cout_g = cout // groups
     cout_pad = (cout_g + 15) // 16 * 16
     packed = wk.new_zeros(groups, cout_pad, K)
@@ -80,7 +120,7 @@ class ConvLayer:
     """One convolution / linear layer prepared for pp_conv2d (weights packed once, on the device)."""
 
     def __init__(self, weight, bias, *, stride=1, padding=0, dilation=1, groups=1, src_channels=None,
-                 pad_mode="zeros", dtype=torch.float16, device="cuda", taps=None, dcn_groups=0, split3=False):
+                 pad_mode="zeros", dtype=torch.float16, device="cuda", taps=None, dcn_groups=0, split3=False, split=False, src_lo=None):
         if weight.dim() == 2:                       # nn.Linear
             weight = weight[:, :, None, None]
         cout, cin_g, kh, kw = weight.shape
@@ -96,7 +136,17 @@ class ConvLayer:
         if taps is None:
             taps = [(ky * self.dilation[0], kx * self.dilation[1]) for ky in range(kh) for kx in range(kw)]
         kt = hip.build_ktable(taps, self.src_cpad, dcn_groups)
-        packed, K, cout_g = pack_weight(weight, self.src_channels, groups, ktable=kt)   # K order = the table's order
+        # split=True: split-plane ("f16x3") layer -- fp16 kernels, every source / epilogue operand a pair of fp16 planes
+        # (hi, lo) of one buffer, lo plane src_lo[i] channels after the hi plane (default: a dedicated buffer [.., 2 * cpad])
+        self.split = bool(split)
+        if self.split:
+            if dtype != torch.float16 or dcn_groups or groups != 1:
+                raise ValueError("split-plane layers are plain fp16 convolutions (groups == 1)")
+            self.src_lo = [int(v) for v in (src_lo if src_lo is not None else self.src_cpad)]
+            assert len(self.src_lo) == len(self.src_cpad) and all(l >= c and l % 8 == 0 for l, c in zip(self.src_lo, self.src_cpad))
+            kt = split_ktable(kt, self.src_lo)
+        packed, K, cout_g = pack_weight(weight, self.src_channels, groups, ktable=kt,     # K order = the table's order
+                                        src_lo=self.src_lo if self.split else None)
         self.cout_g, self.cout = cout_g, cout
         self.cout_pad = packed.shape[1]
         self.K = K
@@ -136,7 +186,9 @@ class ConvLayer:
         odt = out_dtype or self.dtype
         if out is None:
             cp = pad8(self.cout)
-            out = (torch.zeros if cp != self.cout else torch.empty)((N, OH, OW, cp), dtype=odt, device=x0.device)
+            out = (torch.zeros if cp != self.cout else torch.empty)((N, OH, OW, 2 * cp if (self.split and odt == torch.float16) else cp),
+                                                                    dtype=odt, device=x0.device)
+        split_out = self.split and out.dtype == torch.float16
         a = hip.ConvArgs()
         a.dtype = hip.dtype_code(self.dtype)
         a.N, a.H, a.W, a.OH, a.OW = N, H, W, OH, OW
@@ -147,6 +199,9 @@ class ConvLayer:
         for i, (t, choff) in enumerate(srcs):
             if t.dtype != self.dtype or not t.is_contiguous() or t.shape[:3] != x0.shape[:3]:
                 raise ValueError(f"conv source {i}: dtype {t.dtype} / shape {tuple(t.shape)} incompatible")
+            if self.split and (t.shape[-1] != 2 * self.src_lo[i] or choff + self.src_cpad[i] > self.src_lo[i]):
+                raise ValueError(f"conv source {i}: split-plane buffer of {t.shape[-1]} channels, window {choff}+{self.src_cpad[i]}, "
+                                 f"layer built for lo offset {self.src_lo[i]}")
             a.src[i].ptr = t.data_ptr()
             a.src[i].cstride = t.shape[-1]
             a.src[i].choff = choff
@@ -167,10 +222,16 @@ class ConvLayer:
             assert self.dcn and dcn_offmask.dtype == self.dtype and dcn_offmask.is_contiguous()
             a.dcn_offmask, a.dcn_cstride, a.dcn_mask_off = dcn_offmask.data_ptr(), dcn_offmask.shape[-1], 288
         win = lambda x: (x, 0) if torch.is_tensor(x) else x
+        if self.split:      # every fp16 operand of the epilogue is split-plane: lo plane half a pixel row after the hi plane
+            a.split = 1
+            a.out_lo = out.shape[-1] // 2 if split_out else 0
+            a.res_lo = residual.shape[-1] // 2 if residual is not None else 0
+            assert fuse is None or fuse["kind"] != "dcn_om"
         if preadd is not None:
             t, co = win(preadd)
             assert t.dtype == self.dtype and t.is_contiguous() and t.shape[:3] == (N, OH, OW)
             a.preadd, a.preadd_cstride, a.preadd_choff = t.data_ptr(), t.shape[-1], co
+            a.preadd_lo = t.shape[-1] // 2 if self.split else 0
         if fuse is not None and fuse["kind"] == "dcn_om":
             # offset / mask head of a deformable alignment: mag * tanh(offsets) + flow | sigmoid(masks) in the epilogue
             assert pconv_act_none(act) and out.dtype == self.dtype and preadd is None and residual is None
@@ -183,27 +244,71 @@ class ConvLayer:
             (ht, hc) = win(fuse["h"])
             assert ht.dtype == self.dtype and ht.is_contiguous() and out.dtype == self.dtype
             a.fuse_a, a.fuse_a_cstride, a.fuse_a_choff = ht.data_ptr(), ht.shape[-1], hc
+            a.fuse_a_lo = ht.shape[-1] // 2 if self.split else 0
             if fuse["kind"] == "gru_zr":
                 (ot, oc) = win(fuse["out2"])
                 assert ot.dtype == self.dtype and ot.is_contiguous()
                 a.fuse, a.fuse_split = hip.FUSE_GRU_ZR, int(fuse["split"])
                 a.out2, a.out2_cstride, a.out2_choff = ot.data_ptr(), ot.shape[-1], oc
+                a.out2_lo = ot.shape[-1] // 2 if self.split else 0
             elif fuse["kind"] == "gru_h":
                 (zt, zc) = win(fuse["z"])
                 assert zt.dtype == self.dtype and zt.is_contiguous()
                 a.fuse = hip.FUSE_GRU_H
                 a.fuse_b, a.fuse_b_cstride, a.fuse_b_choff = zt.data_ptr(), zt.shape[-1], zc
+                a.fuse_b_lo = zt.shape[-1] // 2 if self.split else 0
             else:
                 raise ValueError(fuse["kind"])
         a.impl = 3 if self.split3 else self.impl
         a.ktable_uniform = self.ktable_uniform
         a.tap_h, a.tap_w = self.tap_hw
         self._keep = (srcs, out, residual, dcn_offmask, preadd, fuse)
-        hip.conv2d_raw(a, cin_read=sum(self.src_cpad) * self.groups, on=x0)
+        hip.conv2d_raw(a, cin_read=sum(self.src_cpad) * self.groups, on=x0, split_k=self.split)
         return out
 
 
 _gemm_tables = {}
+
+
+_split_gemm_tables = {}
+
+
+def batched_gemm_nt_split(a, b, out_scale=1.0):
+    """Split-plane ("f16x3") batched GEMM: a, b fp16 [B, M | N, 2K] = hi | lo planes of fp32 operands;
+    out[b, m, n] = out_scale * sum_k a[b, m, k] * b[b, n, k] as hi*hi + lo*hi + hi*lo on the fp16 matrix cores, fp32 output.
+    The A side needs no copy (its K table walks hi, lo, hi of every 64-channel block); the B side is the kernel's dense
+    "weight" operand, so its rows are gathered once into that K order (hi, hi, lo per block).
+    RAFT all-pairs correlation volume at reference precision (RAFT/corr.py:52-60)."""
+    B, M, K2 = a.shape
+    Bb, Nn, K2b = b.shape
+    K = K2 // 2
+    assert B == Bb and K2 == K2b and K % 64 == 0 and a.dtype == b.dtype == torch.float16 and a.is_contiguous() and b.is_contiguous()
+    key = (K, str(a.device))
+    if key not in _split_gemm_tables:
+        kt = split_ktable(hip.build_ktable([(0, 0)], [K]), [K])
+        code = kt[:-1, 2].astype(np.int64)
+        plane = np.where(code & KT_WEIGHT_LO, 1, 0)                                  # B-side plane of every chunk
+        cols = (plane * K + kt[:-1, 3] % K)[:, None] + np.arange(8)[None, :]         # [chunks, 8] columns of b's rows (lo-plane A chunks: c + K -> c)
+        cols[(code & 0xff) == 255] = 0
+        _split_gemm_tables[key] = (torch.from_numpy(kt).to(a.device), torch.from_numpy(cols.reshape(-1)).to(a.device), kt.shape[0] - 1)
+    kt, cols, kchunks = _split_gemm_tables[key]
+    bt = b.index_select(2, cols)                                                        # [B, N, 3K] in K-table order
+    out = torch.empty((B, M, Nn), dtype=torch.float32, device=a.device)
+    g = hip.ConvArgs()
+    g.dtype = hip.PP_F16
+    g.N, g.H, g.W, g.OH, g.OW = 1, 1, M, 1, M
+    g.stride_h = g.stride_w = 1
+    g.groups, g.cout_g, g.cout_pad, g.kchunks, g.nsrc = B, Nn, Nn, kchunks, 1
+    g.src[0].ptr, g.src[0].cstride, g.src[0].choff, g.src[0].cgroup = a.data_ptr(), K2, 0, 0
+    g.ktable, g.weight, g.weight_gstride = kt.data_ptr(), bt.data_ptr(), Nn * kchunks * 8
+    g.act, g.out_scale, g.act2 = hip.ACT_NONE, float(out_scale), hip.ACT_NONE
+    g.out_dtype = hip.PP_F32
+    g.ktable_uniform = 12
+    g.out, g.out_cstride, g.out_choff, g.out_cgroup = out.data_ptr(), Nn, 0, 0
+    g.src_gstride, g.out_gstride = M * K2, M * Nn
+    hip.conv2d_raw(g, cin_read=K * B, on=a, split_k=True)
+    del bt
+    return out
 
 
 def batched_gemm_nt(a, bt, out_scale=1.0, split3=False):

@@ -95,6 +95,28 @@ template <typename T> __device__ __forceinline__ void store8(T* p, const float* 
   }
 }
 
+// Split-plane ("f16x3") store: hi = fp16(v), lo = fp16(v - hi); hi + lo carries 22 significand bits of v (|v| < 65504).
+__device__ __forceinline__ void store8_split(_Float16* hi_p, _Float16* lo_p, const float* v) {
+  u32x4 rh, rl;
+  _Float16* h = reinterpret_cast<_Float16*>(&rh);
+  _Float16* l = reinterpret_cast<_Float16*>(&rl);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    h[i] = (_Float16)v[i];
+    l[i] = (_Float16)(v[i] - (float)h[i]);
+  }
+  *reinterpret_cast<u32x4*>(hi_p) = rh;
+  *reinterpret_cast<u32x4*>(lo_p) = rl;
+}
+// ... and the matching 8-element load: hi + lo as fp32
+__device__ __forceinline__ void load8_split(const _Float16* hi_p, const _Float16* lo_p, float* v) {
+  const u32x4 rh = *reinterpret_cast<const u32x4*>(hi_p), rl = *reinterpret_cast<const u32x4*>(lo_p);
+  const _Float16* h = reinterpret_cast<const _Float16*>(&rh);
+  const _Float16* l = reinterpret_cast<const _Float16*>(&rl);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (float)h[i] + (float)l[i];
+}
+
 // grid_sample(align_corners=True) coordinate round trip exactly as torch computes it in fp32:
 // g = 2*c/(size-1) - 1 ; c' = ((g + 1) / 2) * (size - 1).   Keeps 'nearest' ties identical.
 __device__ __forceinline__ float grid_roundtrip(float c, int size) {

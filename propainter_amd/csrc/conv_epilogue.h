@@ -18,7 +18,11 @@ namespace pp {
 // two calls of 64): tiles A0 .. A0 + WN/16 - 1 of acc[TNT][TM] are used.
 // PREFETCH: issue the global reads of phase 2 for all passes at once (needs 3 x 4 x NP free VGPRs after the staging; the
 // A-stationary kernel, which sits at the register cap, turns it off and loads inside the passes).
-template <int WM, int WN, int TNT = WN / 16, int A0 = 0, bool PREFETCH = true, bool ALLOW_LATE = true, typename RowMap>
+// SPLIT: split-plane ("f16x3", pp_conv_args_t.split) operands: every fp16 operand read or written here is a hi plane plus a lo
+// plane `*_lo` elements further along the pixel row; value = (float)hi + (float)lo, stores write hi = fp16(v), lo = fp16(v - hi)
+// (22 significand bits).  fp32 outputs (out_f16 == 0) stay plain.  The phase-2 reads are prefetched in two halves (the
+// register budget of the six planes of h / z / addend is the plain path's).
+template <int WM, int WN, int TNT = WN / 16, int A0 = 0, bool PREFETCH = true, bool ALLOW_LATE = true, bool SPLIT = false, typename RowMap>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc_)[TNT][WM / 16], char* wave_lds, int lane,
                                               int co_wave /* first cout of the wave tile within the group */, int g,
                                               char* outp, const RowMap rowmap, const f32x4* bias_pre = nullptr,
@@ -32,7 +36,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc_)
   // arithmetic run in phase 2 on 8 consecutive couts per lane, where preadd / h / z are read with 16-byte loads
   const bool pre_late = ALLOW_LATE && p.preadd != nullptr && !preadd_done;     // the addend still has to be read (before the activation)
   const bool late = ALLOW_LATE && (pre_late || p.fuse != PP_FUSE_NONE);       // (ALLOW_LATE false: the caller's dispatch excludes such layers)
-  const bool stage16 = p.out_f16 && !has_res && !late;
+  const bool stage16 = !SPLIT && p.out_f16 && !has_res && !late;
   constexpr int LPR = WN / 8;                       // lanes per pixel row (8 couts each)
   constexpr int RPP = 64 / LPR;                     // pixel rows per pass
   constexpr int NP = WM / RPP;                      // passes of phase 2
@@ -135,141 +139,162 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc_)
   // back to back, right after the accumulators have been staged (their registers are free now): one exposed memory
   // latency per wave tile instead of one per pass (measured: the per-pass dependent loads made the fused GRU
   // convolutions ~2x slower than their K loop alone)
-  const bool pre_vec = pre_late && nval == 8 && ((p.preadd_cstride | p.preadd_choff) & 7) == 0;
-  const bool res_vec = has_res && !late && nval == 8 && ((p.res_cstride | res_cbase) & 7) == 0;
+  const bool pre_vec = pre_late && nval == 8 && ((p.preadd_cstride | p.preadd_choff | (SPLIT ? p.preadd_lo : 0)) & 7) == 0;
+  const bool res_vec = has_res && !late && nval == 8 && ((p.res_cstride | res_cbase | (SPLIT ? p.res_lo : 0)) & 7) == 0;
   const bool zr_r = p.fuse == PP_FUSE_GRU_ZR && co >= p.fuse_split;
   const bool gh = p.fuse == PP_FUSE_GRU_H;
   const bool om_flow = p.fuse == PP_FUSE_DCN_OFFMASK && p.fuse_a != nullptr && co < p.fuse_split;   // offsets: + flow (x, y) of the pixel
-  constexpr int NQ = PREFETCH ? NP : 1;
-  u32x4 q0[NQ], q1[NQ], q2[NQ];                     // [preadd | residual], h, z
-  if (PREFETCH && (late || has_res)) {
-#pragma unroll
-    for (int pass = 0; pass < NP; ++pass) {
-      const long long m = rowmap(pass * RPP + lane / LPR);
-      q0[pass] = q1[pass] = q2[pass] = u32x4{0, 0, 0, 0};
-      if (m < 0 || nval <= 0) continue;
-      if (pre_vec) q0[pass] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.preadd) + m * p.preadd_cstride + p.preadd_choff + co);
-      if (res_vec) q0[pass] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.residual) + m * p.res_cstride + res_cbase + co);
-      if (zr_r) q1[pass] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.fuse_a) + m * p.fuse_a_cstride + p.fuse_a_choff + co - p.fuse_split);
-      if (om_flow) q1[pass][0] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const T*>(p.fuse_a) + m * p.fuse_a_cstride + p.fuse_a_choff);
-      if (gh) {
-        q1[pass] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.fuse_a) + m * p.fuse_a_cstride + p.fuse_a_choff + co);
-        q2[pass] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.fuse_b) + m * p.fuse_b_cstride + p.fuse_b_choff + co);
-      }
-    }
-  }
+  constexpr int NPL = SPLIT ? 2 : 1;                // planes per fp16 operand
+  constexpr int NQ = PREFETCH ? (SPLIT && NP >= 2 ? NP / 2 : NP) : 1;     // passes whose global reads are in flight together
+  static_assert(NP % NQ == 0 && NQ >= 1, "prefetch rounds");
+  u32x4 q0[NQ][NPL], q1[NQ][NPL], q2[NQ][NPL];     // [preadd | residual], h, z
+  const int pre_lo = SPLIT ? p.preadd_lo : 0, res_lo = SPLIT ? p.res_lo : 0, fa_lo = SPLIT ? p.fuse_a_lo : 0, fb_lo = SPLIT ? p.fuse_b_lo : 0;
   const bool relu2 = p.act2 == PP_ACT_RELU;
-  auto unpack8 = [](const u32x4& raw, float* f) {
-    const _Float16* hh = reinterpret_cast<const _Float16*>(&raw);
+  auto unpack8 = [](const u32x4 (&raw)[NPL], float* f) {
+    const _Float16* hh = reinterpret_cast<const _Float16*>(&raw[0]);
 #pragma unroll
     for (int r = 0; r < 8; ++r) f[r] = (float)hh[r];
+    if constexpr (SPLIT) {
+      const _Float16* ll = reinterpret_cast<const _Float16*>(&raw[NPL - 1]);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) f[r] += (float)ll[r];
+    }
+  };
+  auto fetch = [&](int qi, long long m) {            // every global READ of phase 2 for the pixel row m (16-byte loads)
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) {
+      if (pre_vec) q0[qi][pl] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.preadd) + m * p.preadd_cstride + p.preadd_choff + co + pl * pre_lo);
+      if (res_vec) q0[qi][pl] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.residual) + m * p.res_cstride + res_cbase + co + pl * res_lo);
+      if (zr_r) q1[qi][pl] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.fuse_a) + m * p.fuse_a_cstride + p.fuse_a_choff + co - p.fuse_split + pl * fa_lo);
+      if (gh) {
+        q1[qi][pl] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.fuse_a) + m * p.fuse_a_cstride + p.fuse_a_choff + co + pl * fa_lo);
+        q2[qi][pl] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.fuse_b) + m * p.fuse_b_cstride + p.fuse_b_choff + co + pl * fb_lo);
+      }
+    }
+    if (om_flow) q1[qi][0][0] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const T*>(p.fuse_a) + m * p.fuse_a_cstride + p.fuse_a_choff);
   };
 #pragma unroll
-  for (int pass = 0; pass < NP; ++pass) {
-    const int prow = pass * RPP + lane / LPR;
-    const long long m = rowmap(prow);
-    if (m < 0 || nval <= 0) continue;
-    constexpr bool PF = PREFETCH;
-    const int qi = PF ? pass : 0;
-    if constexpr (!PF) {
-      if (pre_vec) q0[0] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.preadd) + m * p.preadd_cstride + p.preadd_choff + co);
-      if (res_vec) q0[0] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.residual) + m * p.res_cstride + res_cbase + co);
-      if (zr_r) q1[0] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.fuse_a) + m * p.fuse_a_cstride + p.fuse_a_choff + co - p.fuse_split);
-      if (om_flow) q1[0][0] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const T*>(p.fuse_a) + m * p.fuse_a_cstride + p.fuse_a_choff);
-      if (gh) {
-        q1[0] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.fuse_a) + m * p.fuse_a_cstride + p.fuse_a_choff + co);
-        q2[0] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.fuse_b) + m * p.fuse_b_cstride + p.fuse_b_choff + co);
+  for (int rnd = 0; rnd < NP / NQ; ++rnd) {
+    if (PREFETCH && (late || has_res)) {
+#pragma unroll
+      for (int qi = 0; qi < NQ; ++qi) {
+        const long long m = rowmap((rnd * NQ + qi) * RPP + lane / LPR);
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) q0[qi][pl] = q1[qi][pl] = q2[qi][pl] = u32x4{0, 0, 0, 0};
+        if (m < 0 || nval <= 0) continue;
+        fetch(qi, m);
       }
     }
-    float v[8];
-    const f32x4 lo = *reinterpret_cast<const f32x4*>(et + prow * LDF + cl);
-    const f32x4 hi = *reinterpret_cast<const f32x4*>(et + prow * LDF + cl + 4);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { v[r] = lo[r]; v[4 + r] = hi[r]; }
-    if (late) {
-      if (pre_late) {
-        float pv[8];
-        const T* pp_ = reinterpret_cast<const T*>(p.preadd) + m * p.preadd_cstride + p.preadd_choff + co;
-        if (pre_vec) unpack8(q0[qi], pv);
-        else {
+    for (int qi = 0; qi < NQ; ++qi) {
+      const int pass = rnd * NQ + qi;
+      const int prow = pass * RPP + lane / LPR;
+      const long long m = rowmap(prow);
+      if (m < 0 || nval <= 0) continue;
+      if constexpr (!PREFETCH) fetch(0, m);
+      float v[8];
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(et + prow * LDF + cl);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(et + prow * LDF + cl + 4);
 #pragma unroll
-          for (int r = 0; r < 8; ++r) pv[r] = r < nval ? to_f32(pp_[r]) : 0.f;
-        }
+      for (int r = 0; r < 4; ++r) { v[r] = lo[r]; v[4 + r] = hi[r]; }
+      if (late) {
+        if (pre_late) {
+          float pv[8];
+          const T* pp_ = reinterpret_cast<const T*>(p.preadd) + m * p.preadd_cstride + p.preadd_choff + co;
+          if (pre_vec) unpack8(q0[qi], pv);
+          else {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] += pv[r];
-        const float slope2 = p.act == PP_ACT_NONE ? 1.f : (p.act == PP_ACT_LRELU ? p.act_param : 0.f);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = act_late(v[r], p.act, slope2);
-      }
-      if (p.fuse == PP_FUSE_GRU_ZR) {
-        if (co >= p.fuse_split) {                       // r half: r * h -> out2 (8-cout chunks never straddle the split)
-          const int cr = co - p.fuse_split;
-          float hv[8];
-          unpack8(q1[qi], hv);
-#pragma unroll
-          for (int r = 0; r < 8; ++r) v[r] *= hv[r];
-          store8<T>(reinterpret_cast<T*>(p.out2) + m * p.out2_cstride + p.out2_choff + cr, v);
-          continue;
-        }
-      } else if (p.fuse == PP_FUSE_GRU_H) {
-        float hv[8], zv[8];
-        unpack8(q1[qi], hv);
-        unpack8(q2[qi], zv);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = (1.f - zv[r]) * hv[r] + zv[r] * v[r];
-      } else if (p.fuse == PP_FUSE_DCN_OFFMASK) {       // dcn_offmask_act_kernel's formulas (token_ops.hip) on the unrounded sums
-        if (co < p.fuse_split) {
-          float fx = 0.f, fy = 0.f;
-          if (om_flow) {
-            const _Float16* fl = reinterpret_cast<const _Float16*>(&q1[qi]);
-            fx = (float)fl[0]; fy = (float)fl[1];
+            for (int r = 0; r < 8; ++r) pv[r] = r < nval ? to_f32(pp_[r]) + (SPLIT ? to_f32(pp_[r + pre_lo]) : 0.f) : 0.f;
           }
 #pragma unroll
-          for (int r = 0; r < 8; ++r)       // tanh as 1 - 2 / (e^2v + 1) (v_exp + v_rcp, as PP_ACT_TANH above; the result is rounded to fp16)
-            v[r] = p.act_param * (1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * v[r]) + 1.f)) + ((r & 1) ? fx : fy);
-        } else {
+          for (int r = 0; r < 8; ++r) v[r] += pv[r];
+          const float slope2 = p.act == PP_ACT_NONE ? 1.f : (p.act == PP_ACT_LRELU ? p.act_param : 0.f);
 #pragma unroll
-          for (int r = 0; r < 8; ++r) v[r] = __builtin_amdgcn_rcpf(1.f + __expf(-v[r]));
+          for (int r = 0; r < 8; ++r) v[r] = act_late(v[r], p.act, slope2);
+        }
+        if (p.fuse == PP_FUSE_GRU_ZR) {
+          if (co >= p.fuse_split) {                       // r half: r * h -> out2 (8-cout chunks never straddle the split)
+            const int cr = co - p.fuse_split;
+            float hv[8];
+            unpack8(q1[qi], hv);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] *= hv[r];
+            T* o2 = reinterpret_cast<T*>(p.out2) + m * p.out2_cstride + p.out2_choff + cr;
+            if constexpr (SPLIT) store8_split(o2, o2 + p.out2_lo, v);
+            else store8<T>(o2, v);
+            continue;
+          }
+        } else if (p.fuse == PP_FUSE_GRU_H) {
+          float hv[8], zv[8];
+          unpack8(q1[qi], hv);
+          unpack8(q2[qi], zv);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[r] = (1.f - zv[r]) * hv[r] + zv[r] * v[r];
+        } else if (p.fuse == PP_FUSE_DCN_OFFMASK) {       // dcn_offmask_act_kernel's formulas (token_ops.hip) on the unrounded sums
+          if (co < p.fuse_split) {
+            float fx = 0.f, fy = 0.f;
+            if (om_flow) {
+              const _Float16* fl = reinterpret_cast<const _Float16*>(&q1[qi][0]);
+              fx = (float)fl[0]; fy = (float)fl[1];
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r)       // tanh as 1 - 2 / (e^2v + 1) (v_exp + v_rcp, as PP_ACT_TANH above; the result is rounded to fp16)
+              v[r] = p.act_param * (1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * v[r]) + 1.f)) + ((r & 1) ? fx : fy);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = __builtin_amdgcn_rcpf(1.f + __expf(-v[r]));
+          }
+        }
+        if (!has_res && relu2) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
         }
       }
-      if (!has_res && relu2) {
+      if (has_res) {
+        const T* rp = reinterpret_cast<const T*>(p.residual) + m * p.res_cstride + res_cbase + co;
+        if (res_vec) {
+          float rv[8];
+          unpack8(q0[qi], rv);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
+          for (int r = 0; r < 8; ++r) v[r] += rv[r];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 8; ++r)
+            if (r < nval) v[r] += to_f32(rp[r]) + (SPLIT ? to_f32(rp[r + res_lo]) : 0.f);
+        }
+        if (relu2) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
       }
-    }
-    if (has_res) {
-      const T* rp = reinterpret_cast<const T*>(p.residual) + m * p.res_cstride + res_cbase + co;
-      if (res_vec) {
-        float rv[8];
-        unpack8(q0[qi], rv);
+      const long long oidx = m * p.out_cstride + out_cbase + co;
+      if (p.out_f16) {
+        _Float16* op = reinterpret_cast<_Float16*>(outp) + oidx;
+        if constexpr (SPLIT) {
+          if (nval == 8 && ((p.out_cstride | out_cbase | p.out_lo) & 7) == 0) store8_split(op, op + p.out_lo, v);
+          else {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] += rv[r];
+            for (int r = 0; r < 8; ++r)
+              if (r < nval) {
+                const _Float16 h = (_Float16)v[r];
+                op[r] = h;
+                op[r + p.out_lo] = (_Float16)(v[r] - (float)h);
+              }
+          }
+        } else if (nval == 8 && ((p.out_cstride | out_cbase) & 7) == 0) store8<_Float16>(op, v);
+        else {
+#pragma unroll
+          for (int r = 0; r < 8; ++r)
+            if (r < nval) op[r] = (_Float16)v[r];
+        }
       } else {
+        float* op = reinterpret_cast<float*>(outp) + oidx;
+        if (nval == 8 && ((p.out_cstride | out_cbase) & 3) == 0) store8<float>(op, v);
+        else {
 #pragma unroll
-        for (int r = 0; r < 8; ++r)
-          if (r < nval) v[r] += to_f32(rp[r]);
-      }
-      if (relu2) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
-      }
-    }
-    const long long oidx = m * p.out_cstride + out_cbase + co;
-    if (p.out_f16) {
-      _Float16* op = reinterpret_cast<_Float16*>(outp) + oidx;
-      if (nval == 8 && ((p.out_cstride | out_cbase) & 7) == 0) store8<_Float16>(op, v);
-      else {
-#pragma unroll
-        for (int r = 0; r < 8; ++r)
-          if (r < nval) op[r] = (_Float16)v[r];
-      }
-    } else {
-      float* op = reinterpret_cast<float*>(outp) + oidx;
-      if (nval == 8 && ((p.out_cstride | out_cbase) & 3) == 0) store8<float>(op, v);
-      else {
-#pragma unroll
-        for (int r = 0; r < 8; ++r)
-          if (r < nval) op[r] = v[r];
+          for (int r = 0; r < 8; ++r)
+            if (r < nval) op[r] = v[r];
+        }
       }
     }
   }

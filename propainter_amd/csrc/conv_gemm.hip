@@ -531,6 +531,8 @@ extern "C" int pp_conv2d(const pp_conv_args_t* a, void* stream) {
   p.fuse_a = (const char*)a->fuse_a; p.fuse_a_cstride = a->fuse_a_cstride; p.fuse_a_choff = a->fuse_a_choff;
   p.fuse_b = (const char*)a->fuse_b; p.fuse_b_cstride = a->fuse_b_cstride; p.fuse_b_choff = a->fuse_b_choff;
   p.out2 = (char*)a->out2; p.out2_cstride = a->out2_cstride; p.out2_choff = a->out2_choff;
+  p.split = a->split; p.out_lo = a->out_lo; p.out2_lo = a->out2_lo; p.preadd_lo = a->preadd_lo; p.res_lo = a->res_lo;
+  p.fuse_a_lo = a->fuse_a_lo; p.fuse_b_lo = a->fuse_b_lo;
   if (a->preadd != nullptr || a->fuse != PP_FUSE_NONE) {
     PP_REQUIRE(a->groups == 1 && !deform && a->out_dtype == a->dtype && a->cout_g % 8 == 0, PP_ERR_ARG,
                "pp_conv2d: the fused epilogue (preadd / fuse) needs groups == 1, no deformable sampling, out_dtype == dtype, cout_g %% 8 == 0");
@@ -556,6 +558,25 @@ extern "C" int pp_conv2d(const pp_conv_args_t* a, void* stream) {
                  PP_ERR_ALIGN, "pp_conv2d: PP_FUSE_GRU_H needs fuse_b (z), 16-byte aligned, cstride / choff multiples of 8");
   }
   hipStream_t st = (hipStream_t)stream;
+  if (a->split) {
+    // split-plane ("f16x3") layer: the LDS-DMA kernels with the split epilogue only -- there is no register-staged fallback
+    PP_REQUIRE(a->split == 1 && a->dtype == PP_F16 && !deform && a->groups == 1 && a->fuse != PP_FUSE_DCN_OFFMASK, PP_ERR_ARG,
+               "pp_conv2d: split-plane layers need dtype PP_F16, groups == 1, no deformable sampling, no PP_FUSE_DCN_OFFMASK");
+    PP_REQUIRE(((a->out_lo | a->out2_lo | a->preadd_lo | a->res_lo | a->fuse_a_lo | a->fuse_b_lo) & 7) == 0 && a->out_lo >= 0 &&
+                   a->out2_lo >= 0 && a->preadd_lo >= 0 && a->res_lo >= 0 && a->fuse_a_lo >= 0 && a->fuse_b_lo >= 0,
+               PP_ERR_ALIGN, "pp_conv2d: split-plane lo offsets must be non-negative multiples of 8 elements");
+    PP_REQUIRE(a->out_dtype == PP_F32 || (a->out_lo > 0 && ((uintptr_t)a->out % 16) == 0 && ((a->out_cstride | a->out_choff) & 7) == 0),
+               PP_ERR_ALIGN, "pp_conv2d: a split-plane fp16 output needs out_lo > 0, a 16-byte aligned base, cstride / choff multiples of 8");
+    PP_REQUIRE(a->residual == nullptr || (((uintptr_t)a->residual % 16) == 0 && ((a->res_cstride | a->res_choff) & 7) == 0 && a->res_lo > 0),
+               PP_ERR_ALIGN, "pp_conv2d: a split-plane residual needs res_lo > 0, 16-byte alignment, cstride / choff multiples of 8");
+    PP_REQUIRE((a->preadd == nullptr || a->preadd_lo > 0) && (a->fuse == PP_FUSE_NONE || a->fuse_a_lo > 0) &&
+                   (a->fuse != PP_FUSE_GRU_ZR || a->out2_lo > 0) && (a->fuse != PP_FUSE_GRU_H || a->fuse_b_lo > 0),
+               PP_ERR_ARG, "pp_conv2d: split-plane epilogue operands need their lo offsets");
+    int rc = conv_v3s_dispatch(p, a->impl == 71 || a->impl == 72 ? a->impl : 0, st);
+    if (rc == -1000) rc = conv_v2s_dispatch(p, (a->impl >= 10 && a->impl < 70) || a->impl >= 110 ? a->impl : 0, st);
+    PP_REQUIRE(rc != -1000, PP_ERR_ARG, "pp_conv2d: no split-plane kernel for this layer (kchunks %d, impl %d)", a->kchunks, a->impl);
+    return rc;
+  }
   if (a->dtype == PP_F16 && !deform && (a->impl == 80 || a->impl == 81)) {
     // A-stationary kernel for the short-K single-source linears (transformer GEMMs).  Selected explicitly only: with
     // interleaved A/B rounds (tools/kbench, profiles/r2_conv_epilogue_ab.txt) the 256 x 128 LDS-DMA tile beats it by

@@ -1,0 +1,29 @@
+// LDS-DMA implicit-GEMM kernel (conv_v2_kernel.h), split-plane "f16x3" instantiations: the layers of RAFT the halo-tile kernel does
+// not serve (strided / 7x7 / 1x1 convolutions, sources that are not multiples of 64 channels).  See conv_gemm_v3s.hip.
+#include "conv_v2_kernel.h"
+
+namespace pp {
+
+int conv_v2s_dispatch(const ConvParams& p, int cfg, hipStream_t stream) {
+  if (p.kchunks % 8 != 0 || p.M >= (1ll << 31) || (long long)p.N * p.H * p.W >= (1ll << 31) || p.groups != 1) return -1000;
+  bool uni = p.ktable_uniform != 0 && p.pad_mode == 0 && (long long)p.cout_pad * p.kchunks * 16 < (1ll << 31);
+  for (int i = 0; i < p.nsrc; ++i) uni = uni && (long long)p.N * p.H * p.W * p.src[i].cstride * 2 < (1ll << 31);
+  if (cfg >= 100) { uni = false; cfg -= 100; }
+  if (cfg == 0) {   // the fp16 dispatch's choices (conv_v2_dispatch)
+    if (p.cout_g >= 512) cfg = 13;
+    else if (p.cout_g > 64) cfg = 12;
+    else if (p.cout_g > 32) cfg = 22;
+    else if (p.cout_g > 16) cfg = 32;
+    else cfg = 42;
+  }
+  switch (cfg) {
+    case 12: return launch_v2<128, 128, 64, 2, 2, 2, 0, true>(p, uni, stream);
+    case 13: return launch_v2<256, 128, 64, 4, 2, 3, 0, true>(p, uni, stream);
+    case 22: return launch_v2<256, 64, 64, 4, 1, 2, 0, true>(p, uni, stream);
+    case 32: return launch_v2<256, 32, 32, 4, 1, 2, 0, true>(p, uni, stream);
+    case 42: return launch_v2<256, 16, 32, 4, 1, 2, 0, true>(p, uni, stream);
+    default: return -1000;
+  }
+}
+
+}  // namespace pp

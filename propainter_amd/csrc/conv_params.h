@@ -41,6 +41,9 @@ struct ConvParams {
   int fuse_b_cstride, fuse_b_choff;
   char* out2;
   int out2_cstride, out2_choff;
+  // split-plane ("f16x3") operands (pp_conv_args_t.split): element offset of the lo plane of each fp16 operand the epilogue touches
+  int split;
+  int out_lo, out2_lo, preadd_lo, res_lo, fuse_a_lo, fuse_b_lo;
 };
 
 // activation of the late (post-staging) epilogue path: same fast forms as the register path of conv_epilogue.h
@@ -55,6 +58,9 @@ __device__ __forceinline__ float act_late(float v, int act, float slope) {
 int conv_v2_dispatch(const ConvParams& p, int cfg, hipStream_t stream);
 // conv_gemm_v3.hip (halo tiles); returns -1000 when the shape is outside that family (caller falls back to v2)
 int conv_v3_dispatch(const ConvParams& p, int cfg, hipStream_t stream);
+// conv_gemm_v3s.hip / conv_gemm_v2s.hip: the same kernels with split-plane epilogues (p.split); -1000 outside the family
+int conv_v3s_dispatch(const ConvParams& p, int cfg, hipStream_t stream);
+int conv_v2s_dispatch(const ConvParams& p, int cfg, hipStream_t stream);
 // conv_gemm_v4.hip (wide halo tiles: 256 px x 128 couts, 32-channel steps); returns -1000 outside that family (caller falls back to v3)
 int conv_v4_dispatch(const ConvParams& p, int cfg, hipStream_t stream);
 // conv_dcn.hip (patch-staged modulated deformable 3x3 convolution, fp16); returns -1000 when the layer is outside that family

@@ -20,7 +20,8 @@ __global__ void corr_avgpool_kernel(const float* __restrict__ in, float* __restr
 // One 256-thread block per source pixel, one wave per pyramid level.  The wave stages the 10x10 patch
 // around (x/2^l, y/2^l) in LDS (zeros outside the map), then 81 lanes-outputs blend 4 neighbours with the
 // common fractional weights.  Output channel l*81 + a*9 + b <- sample (x + a - 4, y + b - 4).
-template <typename TO>
+// SPLIT (TO = _Float16): split-plane output -- hi = fp16(v) at channel i, lo = fp16(v - hi) at channel i + ocs / 2 (PP_F16S)
+template <typename TO, bool SPLIT = false>
 __global__ __launch_bounds__(256) void corr_lookup_kernel(const float* __restrict__ l0, const float* __restrict__ l1,
                                                           const float* __restrict__ l2, const float* __restrict__ l3,
                                                           const float* __restrict__ coords, TO* __restrict__ out,
@@ -67,9 +68,13 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(const float* __restric
       v += wgt * s;
     }
     op[i] = from_f32<TO>(v);
+    if constexpr (SPLIT) op[i + ocs / 2] = from_f32<TO>(v - to_f32(from_f32<TO>(v)));
   }
   if (lvl == 3)
-    for (int i = 324 + lane; i < ocpad; i += 64) out[pix * ocs + i] = from_f32<TO>(0.f);
+    for (int i = 324 + lane; i < ocpad; i += 64) {
+      out[pix * ocs + i] = from_f32<TO>(0.f);
+      if constexpr (SPLIT) out[pix * ocs + ocs / 2 + i] = from_f32<TO>(0.f);
+    }
 }
 
 // One thread per fine output pixel pair (both flow channels): softmax over the 9 mask logits of its
@@ -127,10 +132,15 @@ extern "C" int pp_corr_lookup(const float* lvl0, const float* lvl1, const float*
   PP_REQUIRE(B > 0 && (h >> 3) >= 2 && (w >> 3) >= 2, PP_ERR_ARG,
              "pp_corr_lookup: level-3 map would be %dx%d (RAFT needs >= 2x2: inputs of at least 128x128)", h >> 3, w >> 3);
   PP_REQUIRE(out_cpad >= 324 && out_cstride >= out_cpad, PP_ERR_ARG, "pp_corr_lookup: out_cpad %d / cstride %d", out_cpad, out_cstride);
-  PP_REQUIRE(out_dtype == PP_F32 || out_dtype == PP_F16, PP_ERR_DTYPE, "pp_corr_lookup: dtype %d", out_dtype);
+  PP_REQUIRE(out_dtype == PP_F32 || out_dtype == PP_F16 || out_dtype == PP_F16S, PP_ERR_DTYPE, "pp_corr_lookup: dtype %d", out_dtype);
+  PP_REQUIRE(out_dtype != PP_F16S || (out_cstride % 2 == 0 && out_cstride / 2 >= out_cpad), PP_ERR_ARG,
+             "pp_corr_lookup: split-plane output needs an even cstride with cstride / 2 >= out_cpad");
   const long long npix = (long long)B * h * w;
   hipStream_t st = (hipStream_t)stream;
-  if (out_dtype == PP_F16)
+  if (out_dtype == PP_F16S)
+    hipLaunchKernelGGL((corr_lookup_kernel<_Float16, true>), dim3((unsigned)npix), dim3(256), 0, st, lvl0, lvl1, lvl2, lvl3, coords,
+                       (_Float16*)out, out_cstride, out_cpad, h, w);
+  else if (out_dtype == PP_F16)
     hipLaunchKernelGGL((corr_lookup_kernel<_Float16>), dim3((unsigned)npix), dim3(256), 0, st, lvl0, lvl1, lvl2, lvl3, coords,
                        (_Float16*)out, out_cstride, out_cpad, h, w);
   else
@@ -156,7 +166,8 @@ extern "C" int pp_convex_upsample(const float* flow, const void* mask, int mask_
 
 namespace pp {
 // One thread per pixel: 7 horizontal taps x (x, y) of the fp32 flow coords1 - coords0 -> 16 channels (32 / 64 contiguous bytes)
-template <typename T>
+// SPLIT (T = _Float16, PP_F16S): rows are [16 hi | 16 lo] (32 elements per pixel), flow_out's lo plane sits fcs / 2 further
+template <typename T, bool SPLIT = false>
 __global__ void raft_flow_taps_kernel(const float* __restrict__ c1, const float* __restrict__ c0, T* __restrict__ rows,
                                       T* __restrict__ fout, int fcs, int fco, long long npix, int w) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < npix; i += (long long)gridDim.x * blockDim.x) {
@@ -174,6 +185,19 @@ __global__ void raft_flow_taps_kernel(const float* __restrict__ c1, const float*
       v[2 * kx] = fx; v[2 * kx + 1] = fy;
     }
     v[14] = v[15] = 0.f;
+    if constexpr (SPLIT) {
+      store8_split(rows + i * 32, rows + i * 32 + 16, v);
+      store8_split(rows + i * 32 + 8, rows + i * 32 + 24, v + 8);
+      if (fout != nullptr) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const T hi = from_f32<T>(v[6 + c]);
+          fout[i * fcs + fco + c] = hi;
+          fout[i * fcs + fcs / 2 + fco + c] = from_f32<T>(v[6 + c] - to_f32(hi));
+        }
+      }
+      continue;
+    }
     store8<T>(rows + i * 16, v);
     store8<T>(rows + i * 16 + 8, v + 8);
     if (fout != nullptr) {
@@ -187,13 +211,18 @@ __global__ void raft_flow_taps_kernel(const float* __restrict__ c1, const float*
 extern "C" int pp_raft_flow_taps(const float* coords1, const float* coords0, void* rows, void* flow_out, int flow_cstride,
                                  int flow_choff, int P, int h, int w, int dtype, void* stream) {
   PP_REQUIRE(coords1 && coords0 && rows && P > 0 && h > 0 && w > 0, PP_ERR_ARG, "pp_raft_flow_taps: bad arguments");
-  PP_REQUIRE(dtype == PP_F32 || dtype == PP_F16, PP_ERR_DTYPE, "pp_raft_flow_taps: dtype %d", dtype);
+  PP_REQUIRE(dtype == PP_F32 || dtype == PP_F16 || dtype == PP_F16S, PP_ERR_DTYPE, "pp_raft_flow_taps: dtype %d", dtype);
   PP_REQUIRE(flow_out == nullptr || (flow_cstride >= flow_choff + 2 && flow_choff >= 0), PP_ERR_ARG, "pp_raft_flow_taps: flow window");
+  PP_REQUIRE(dtype != PP_F16S || flow_out == nullptr || (flow_cstride % 2 == 0 && flow_cstride / 2 >= flow_choff + 2), PP_ERR_ARG,
+             "pp_raft_flow_taps: split-plane flow window (lo plane at cstride / 2)");
   PP_REQUIRE(((uintptr_t)rows % 16) == 0 && ((uintptr_t)coords1 % 8) == 0 && ((uintptr_t)coords0 % 8) == 0, PP_ERR_ALIGN,
              "pp_raft_flow_taps: rows must be 16-byte aligned, coords 8-byte aligned");
   const long long npix = (long long)P * h * w;
   const int g = grid_for(npix);
-  if (dtype == PP_F16)
+  if (dtype == PP_F16S)
+    hipLaunchKernelGGL((raft_flow_taps_kernel<_Float16, true>), dim3(g), dim3(256), 0, (hipStream_t)stream, coords1, coords0, (_Float16*)rows,
+                       (_Float16*)flow_out, flow_cstride, flow_choff, npix, w);
+  else if (dtype == PP_F16)
     hipLaunchKernelGGL((raft_flow_taps_kernel<_Float16>), dim3(g), dim3(256), 0, (hipStream_t)stream, coords1, coords0, (_Float16*)rows,
                        (_Float16*)flow_out, flow_cstride, flow_choff, npix, w);
   else

@@ -213,6 +213,42 @@ __global__ void inorm_apply_kernel(const T* __restrict__ in, const float* __rest
   }
 }
 
+// InstanceNorm apply of the split-plane ("f16x3") RAFT feature encoder: fp32 convolution output in, split-plane fp16 out, with the
+// residual tail of a ResidualBlock fused (RAFT/extractor.py:44-57): out = relu2(relu(IN(in)) + res), res split-plane or none.
+__global__ void inorm_apply_split_kernel(const float* __restrict__ in, const float* __restrict__ ws, _Float16* __restrict__ out,
+                                         const _Float16* __restrict__ res, int res_cs, int res_co, long long N, int HW, int C, int relu,
+                                         int relu2) {
+  const long long total = N * HW * (C / 8);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % (C / 8));
+    const long long pix = i / (C / 8);
+    const long long n = pix / HW;
+    float v[8];
+    load8<float>(in + pix * C + cc * 8, v);
+    const float4* st = reinterpret_cast<const float4*>(ws + (n * C + cc * 8) * 2);   // (mean, rstd) x 8, 16-byte aligned
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 m = st[j];
+      const float r0 = (v[2 * j] - m.x) * m.y, r1 = (v[2 * j + 1] - m.z) * m.w;
+      v[2 * j] = relu ? fmaxf(r0, 0.f) : r0;
+      v[2 * j + 1] = relu ? fmaxf(r1, 0.f) : r1;
+    }
+    if (res != nullptr) {
+      float r[8];
+      const _Float16* rp = res + pix * res_cs + res_co + cc * 8;
+      load8_split(rp, rp + res_cs / 2, r);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += r[j];
+    }
+    if (relu2) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+    }
+    _Float16* op = out + pix * (2 * C) + cc * 8;
+    store8_split(op, op + C, v);
+  }
+}
+
 // bilinear x2, align_corners=True: src = dst * (in-1)/(out-1)
 template <typename T>
 __global__ void upsample2x_kernel(const T* __restrict__ in, T* __restrict__ out, int N, int H, int W, int C) {
@@ -303,6 +339,20 @@ __global__ void nchw_to_nhwc_kernel(const TI* __restrict__ in, TO* __restrict__ 
     const int c = (int)((i / HW) % C);
     const long long n = i / ((long long)HW * C);
     out[(n * HW + p) * ocs + oco + c] = from_f32<TO>(to_f32(in[i]) * scale);
+  }
+}
+// fp32 planar -> split-plane NHWC (PP_F16S): hi at channel c, lo at c + ocs / 2
+__global__ void nchw_to_nhwc_split_kernel(const float* __restrict__ in, _Float16* __restrict__ out, int ocs, int oco, int N, int C, int HW,
+                                          float scale) {
+  const long long total = (long long)N * C * HW;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int p = (int)(i % HW);
+    const int c = (int)((i / HW) % C);
+    const long long n = i / ((long long)HW * C);
+    const float v = in[i] * scale;
+    const _Float16 hi = (_Float16)v;
+    out[(n * HW + p) * ocs + oco + c] = hi;
+    out[(n * HW + p) * ocs + ocs / 2 + oco + c] = (_Float16)(v - (float)hi);
   }
 }
 template <typename TI, typename TO>
@@ -396,6 +446,26 @@ extern "C" int pp_instance_norm(const void* in, void* out, float* stats_ws, int 
   return launch_status("pp_instance_norm");
 }
 
+extern "C" int pp_instance_norm_split(const float* in, void* out, float* stats_ws, int N, int H, int W, int C, float eps, int relu,
+                                      const void* residual, int res_cstride, int res_choff, int relu2, void* stream) {
+  PP_REQUIRE(in && out && stats_ws && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && C <= 256, PP_ERR_ARG,
+             "pp_instance_norm_split: bad arguments (C=%d must be a multiple of 8, <= 256)", C);
+  PP_REQUIRE((uintptr_t)stats_ws % 16 == 0 && (uintptr_t)in % 16 == 0 && (uintptr_t)out % 16 == 0, PP_ERR_ALIGN,
+             "pp_instance_norm_split: buffers must be 16-byte aligned");
+  PP_REQUIRE(residual == nullptr || ((uintptr_t)residual % 16 == 0 && res_cstride % 16 == 0 && res_choff % 8 == 0 && res_choff >= 0 &&
+                                     res_cstride / 2 >= res_choff + C),
+             PP_ERR_ALIGN, "pp_instance_norm_split: split-plane residual window (cstride %d, choff %d)", res_cstride, res_choff);
+  hipStream_t st = (hipStream_t)stream;
+  const int HW = H * W;
+  const int slices = inorm_slices(HW);
+  float* part = stats_ws + (size_t)N * C * 2;
+  hipLaunchKernelGGL((inorm_stats_kernel<float>), dim3(slices, N), dim3(256), 0, st, in, part, HW, C, slices);
+  hipLaunchKernelGGL(inorm_finalize_kernel, dim3((N * C + 255) / 256), dim3(256), 0, st, (const float*)part, stats_ws, N, C, slices, HW, eps);
+  hipLaunchKernelGGL(inorm_apply_split_kernel, dim3(grid_for((long long)N * HW * (C / 8))), dim3(256), 0, st, in, (const float*)stats_ws,
+                     (_Float16*)out, (const _Float16*)residual, res_cstride, res_choff, (long long)N, HW, C, relu, relu2);
+  return launch_status("pp_instance_norm_split");
+}
+
 extern "C" int pp_upsample2x(const void* in, void* out, int N, int H, int W, int C, int dtype, void* stream) {
   PP_REQUIRE(in && out && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, PP_ERR_ARG, "pp_upsample2x: bad arguments (C=%d)", C);
   PP_REQUIRE(dtype == PP_F32 || dtype == PP_F16, PP_ERR_DTYPE, "pp_upsample2x: dtype %d", dtype);
@@ -437,8 +507,15 @@ extern "C" int pp_gru_gate(const void* zr, int zr_cstride, const void* h, int h_
 extern "C" int pp_nchw_to_nhwc(const void* in, int in_dtype, void* out, int out_dtype, int out_cstride, int out_choff, int N,
                                int C, int H, int W, float scale, void* stream) {
   PP_REQUIRE(in && out && N > 0 && C > 0 && H > 0 && W > 0 && out_cstride >= C, PP_ERR_ARG, "pp_nchw_to_nhwc: bad arguments");
-  PP_REQUIRE((in_dtype | out_dtype) <= 1 && in_dtype >= 0 && out_dtype >= 0, PP_ERR_DTYPE, "pp_nchw_to_nhwc: dtype");
   const int g = grid_for((long long)N * C * H * W);
+  if (out_dtype == PP_F16S) {      // split-plane output (lo plane at out_cstride / 2), fp32 input
+    PP_REQUIRE(in_dtype == PP_F32 && out_cstride % 2 == 0 && out_cstride / 2 >= out_choff + C, PP_ERR_ARG,
+               "pp_nchw_to_nhwc: split-plane output needs fp32 input and an even cstride with cstride / 2 >= choff + C");
+    hipLaunchKernelGGL(nchw_to_nhwc_split_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)in, (_Float16*)out, out_cstride,
+                       out_choff, N, C, H * W, scale);
+    return launch_status("pp_nchw_to_nhwc");
+  }
+  PP_REQUIRE((in_dtype | out_dtype) <= 1 && in_dtype >= 0 && out_dtype >= 0, PP_ERR_DTYPE, "pp_nchw_to_nhwc: dtype");
   PP_DISPATCH_2(in_dtype, out_dtype,
                 hipLaunchKernelGGL((nchw_to_nhwc_kernel<TI, TO>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const TI*)in, (TO*)out,
                                    out_cstride, out_choff, N, C, H * W, scale);)

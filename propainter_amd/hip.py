@@ -12,7 +12,7 @@ import torch
 
 from . import build as _build
 
-PP_F32, PP_F16 = 0, 1
+PP_F32, PP_F16, PP_F16S = 0, 1, 2      # PP_F16S: split-plane fp16 pair (value = hi + lo, lo plane at cstride / 2 in the aux ops)
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID, ACT_TANH, ACT_GELU = 0, 1, 2, 3, 4, 5
 MAX_SRC = 4
 FUSE_NONE, FUSE_GRU_ZR, FUSE_GRU_H, FUSE_DCN_OFFMASK = 0, 1, 2, 3
@@ -41,6 +41,8 @@ class ConvArgs(C.Structure):
         ("fuse_a", C.c_void_p), ("fuse_a_cstride", C.c_int32), ("fuse_a_choff", C.c_int32),
         ("fuse_b", C.c_void_p), ("fuse_b_cstride", C.c_int32), ("fuse_b_choff", C.c_int32),
         ("out2", C.c_void_p), ("out2_cstride", C.c_int32), ("out2_choff", C.c_int32),
+        ("split", C.c_int32), ("out_lo", C.c_int32), ("out2_lo", C.c_int32), ("preadd_lo", C.c_int32), ("res_lo", C.c_int32),
+        ("fuse_a_lo", C.c_int32), ("fuse_b_lo", C.c_int32), ("pad2_", C.c_int32),
     ]
 
 
@@ -288,9 +290,9 @@ def window_tables(Hp, Wp, wh=5, ww=9):
 # ----------------------------------------------------------------------------------------------
 # device ops
 # ----------------------------------------------------------------------------------------------
-def conv2d_raw(args: ConvArgs, cin_read=None, on=None):
+def conv2d_raw(args: ConvArgs, cin_read=None, on=None, split_k=False):
     """cin_read: channels read per input pixel (for the profiler's byte model; defaults to K per group x groups);
-    on: a tensor of the launch (names the device / stream)."""
+    on: a tensor of the launch (names the device / stream); split_k: the K table is a split-plane expansion (profiler accounting)."""
     if _profiler is None:
         _check(lib().pp_conv2d(C.byref(args), _stream(on)), "pp_conv2d")
         return
@@ -299,12 +301,18 @@ def conv2d_raw(args: ConvArgs, cin_read=None, on=None):
     K = args.kchunks * 8
     esz = 2 if args.dtype == PP_F16 else 4
     osz = 2 if args.out_dtype == PP_F16 else 4
+    # executed_k_mult = 3 for a split-plane ("f16x3") layer: its K table walks every block three times (hi*W_hi, lo*W_hi, hi*W_lo);
+    # the ALGORITHMIC work is that of the fp32 layer it stands for: K / 3 products of 4-byte values
+    if split_k:
+        K //= 3
+        esz = 4
+        osz = 4
     flops = 2.0 * M * args.cout_g * K * args.groups
     cin = cin_read if cin_read is not None else K * args.groups
     nbytes = args.N * args.H * args.W * cin * esz + args.groups * args.cout_pad * K * esz + M * args.cout_g * args.groups * osz
     if args.dcn_offmask:
         nbytes += M * 432 * esz
-    name = "conv_gemm_dcn" if args.dcn_offmask else ("conv_gemm_f16" if args.dtype == PP_F16 else "conv_gemm_f32")
+    name = "conv_gemm_dcn" if args.dcn_offmask else ("conv_gemm_f16x3" if split_k else "conv_gemm_f16" if args.dtype == PP_F16 else "conv_gemm_f32")
     if _profiler is not None and getattr(_profiler, "detail", False):      # per-layer-shape classes (bench.py --detail)
         name += f" | taps{args.tap_h}x{args.tap_w} s{args.stride_h} K{K} cout{args.cout_g}x{args.groups} M{M} {args.H}x{args.W}"
     timed(name, flops, nbytes, lambda: _check(lib().pp_conv2d(C.byref(args), _stream(on)), "pp_conv2d"))
@@ -365,12 +373,13 @@ def corr_avgpool(x, M, H, W):
     return out
 
 
-def corr_lookup(levels, coords, out):
-    """levels: 4 fp32 tensors [B*h*w, Hl, Wl]; coords fp32 [B,h,w,2]; out NHWC [B,h,w,Cpad>=324]."""
+def corr_lookup(levels, coords, out, split=False):
+    """levels: 4 fp32 tensors [B*h*w, Hl, Wl]; coords fp32 [B,h,w,2]; out NHWC [B,h,w,Cpad>=324] (split: fp16 [B,h,w,2*Cpad], hi | lo planes)."""
     B, h, w, _ = coords.shape
     assert coords.dtype == torch.float32 and coords.is_contiguous() and out.is_contiguous()
+    cs = out.shape[-1]
     timed("corr_lookup", 0, B * h * w * 4 * 100 * 4 + _nbytes(out), lambda: _check(lib().pp_corr_lookup(_p(levels[0]), _p(levels[1]), _p(levels[2]), _p(levels[3]), _p(coords), _p(out),
-                                _i(out.shape[-1]), _i(out.shape[-1]), _i(B), _i(h), _i(w), _i(dtype_code(out.dtype)),
+                                _i(cs), _i(cs // 2 if split else cs), _i(B), _i(h), _i(w), _i(PP_F16S if split else dtype_code(out.dtype)),
                                 _stream(coords)),
            "pp_corr_lookup"))
     return out
@@ -402,15 +411,16 @@ def corr_lookup_otf(f1, f2_levels, coords, out):
     return out
 
 
-def raft_flow_taps(coords1, coords0, rows, flow_out=None, flow_choff=0):
+def raft_flow_taps(coords1, coords0, rows, flow_out=None, flow_choff=0, split=False):
     """rows[P,h,w,16] <- the 7 horizontal taps of flow = coords1 - coords0 (fp32 [P,h,w,2]) per pixel, channel 2*kx + c; optionally
-    flow_out[..., flow_choff:flow_choff+2] <- flow (pp_raft_flow_taps)."""
+    flow_out[..., flow_choff:flow_choff+2] <- flow (pp_raft_flow_taps).  split: rows fp16 [P,h,w,32] = 16 hi | 16 lo, flow_out split-plane."""
     P, h, w, _ = coords1.shape
     assert coords1.dtype == coords0.dtype == torch.float32 and coords1.is_contiguous() and coords0.is_contiguous()
-    assert rows.shape == (P, h, w, 16) and rows.is_contiguous() and (flow_out is None or (flow_out.is_contiguous() and flow_out.dtype == rows.dtype))
+    assert rows.shape == (P, h, w, 32 if split else 16) and rows.is_contiguous() and (flow_out is None or (flow_out.is_contiguous() and flow_out.dtype == rows.dtype))
+    assert not split or rows.dtype == torch.float16
     timed("raft_flow_taps", 0, 2 * _nbytes(coords1) + _nbytes(rows),
           lambda: _check(lib().pp_raft_flow_taps(_p(coords1), _p(coords0), _p(rows), _p(flow_out), _i(flow_out.shape[-1] if flow_out is not None else 0),
-                                                 _i(flow_choff), _i(P), _i(h), _i(w), _i(dtype_code(rows.dtype)), _stream(coords1)),
+                                                 _i(flow_choff), _i(P), _i(h), _i(w), _i(PP_F16S if split else dtype_code(rows.dtype)), _stream(coords1)),
                          "pp_raft_flow_taps"))
     return rows
 
@@ -525,6 +535,24 @@ def instance_norm(x, relu=False, eps=1e-5, out=None):
     return out
 
 
+def instance_norm_split(x, relu=False, eps=1e-5, residual=None, res_choff=0, relu2=False):
+    """x fp32 NHWC [N,H,W,C] -> split-plane fp16 [N,H,W,2C]: relu2(relu(IN(x)) + residual) (pp_instance_norm_split; the tail of RAFT's
+    ResidualBlock, RAFT/extractor.py:44-57).  residual: split-plane fp16 [N,H,W,2*Cr] window starting at res_choff, or None."""
+    N, H, W, Cc = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    out = torch.empty((N, H, W, 2 * Cc), dtype=torch.float16, device=x.device)
+    L = lib()
+    L.pp_instance_norm_workspace_floats.restype = C.c_int64
+    ws = torch.empty((int(L.pp_instance_norm_workspace_floats(N, H, W, Cc)),), dtype=torch.float32, device=x.device)
+    if residual is not None:
+        assert residual.dtype == torch.float16 and residual.is_contiguous() and residual.shape[:3] == (N, H, W)
+    timed("instance_norm", 0, _nbytes(x) * 2 + _nbytes(out) * (2 if residual is not None else 1),
+          lambda: _check(lib().pp_instance_norm_split(_p(x), _p(out), _p(ws), _i(N), _i(H), _i(W), _i(Cc), C.c_float(eps), _i(1 if relu else 0),
+                                                      _p(residual), _i(residual.shape[-1] if residual is not None else 0), _i(res_choff),
+                                                      _i(1 if relu2 else 0), _stream(x)), "pp_instance_norm_split"))
+    return out
+
+
 def upsample2x(x):
     N, H, W, Cc = x.shape
     out = torch.empty((N, 2 * H, 2 * W, Cc), dtype=x.dtype, device=x.device)
@@ -555,15 +583,16 @@ def gru_gate(zr, h, h_choff, Cc, out, out_choff, q=None):
     return out
 
 
-def nchw_to_nhwc(x, out=None, out_choff=0, out_dtype=None, cpad=None, scale=1.0):
-    """x planar [N,C,H,W] -> NHWC window of `out` (allocated zero-filled [N,H,W,cpad] if None)."""
+def nchw_to_nhwc(x, out=None, out_choff=0, out_dtype=None, cpad=None, scale=1.0, split=False):
+    """x planar [N,C,H,W] -> NHWC window of `out` (allocated zero-filled [N,H,W,cpad] if None).  split: fp32 input -> split-plane fp16
+    [N,H,W,2*cpad] (hi | lo planes)."""
     N, Cc, H, W = x.shape
     if out is None:
         cpad = cpad or ((Cc + 7) // 8 * 8)
-        dt = out_dtype or x.dtype
-        out = (torch.zeros if cpad != Cc else torch.empty)((N, H, W, cpad), dtype=dt, device=x.device)
-    assert x.is_contiguous() and out.is_contiguous()
-    timed("nchw_to_nhwc", 0, _nbytes(x) * 2, lambda: _check(lib().pp_nchw_to_nhwc(_p(x), _i(dtype_code(x.dtype)), _p(out), _i(dtype_code(out.dtype)),
+        dt = torch.float16 if split else (out_dtype or x.dtype)
+        out = (torch.zeros if cpad != Cc else torch.empty)((N, H, W, 2 * cpad if split else cpad), dtype=dt, device=x.device)
+    assert x.is_contiguous() and out.is_contiguous() and (not split or (x.dtype == torch.float32 and out.dtype == torch.float16))
+    timed("nchw_to_nhwc", 0, _nbytes(x) * 2, lambda: _check(lib().pp_nchw_to_nhwc(_p(x), _i(dtype_code(x.dtype)), _p(out), _i(PP_F16S if split else dtype_code(out.dtype)),
                                  _i(out.shape[-1]), _i(out_choff), _i(N), _i(Cc), _i(H), _i(W), C.c_float(scale),
                                  _stream(x)),
            "pp_nchw_to_nhwc"))

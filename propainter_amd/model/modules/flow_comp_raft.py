@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from ... import hip
-from ...conv import ConvLayer, batched_gemm_nt, fold_batchnorm
+from ...conv import ConvLayer, batched_gemm_nt, batched_gemm_nt_split, fold_batchnorm
 from ...param_tree import ParamTree, conv_entries, norm_entries, populate
 
 
@@ -61,10 +61,14 @@ def raft_schema(prefix=""):
 class _RaftEngine:
     """Packed layers for one (dtype, device)."""
 
+    split = False                 # split-plane activations (_RaftEngineSplit)
+
     def __init__(self, sd, dtype, device, split3=False):
         self.dtype, self.device, self.split3 = dtype, device, split3
         self.corr_otf = dtype == torch.float16       # on-the-fly correlation (fp16 MFMA); fp32 modes keep the exact volume
-        mk = lambda w, b, **kw: ConvLayer(w, b, dtype=dtype, device=device, split3=split3, **kw)
+        self._build(sd, lambda w, b, **kw: ConvLayer(w, b, dtype=dtype, device=device, split3=split3, **kw))
+
+    def _build(self, sd, mk):
 
         def enc(prefix, bn):
             def cv(name, norm=None, **kw):
@@ -195,6 +199,94 @@ class _RaftEngine:
         return hip.convex_upsample((coords1 - coords0).contiguous(), mask)
 
 
+class _RaftEngineSplit(_RaftEngine):
+    """Precision "f16x3": RAFT at the reference's precision class (it keeps RAFT fp32 even under --fp16,
+    inference_propainter.py:311) on the fp16 matrix cores and the LDS-DMA kernels.
+
+    Every activation is a SPLIT-PLANE tensor: fp16 [..., 2C] whose first C channels hold hi = fp16(v) and whose last C
+    channels hold lo = fp16(v - hi) of the fp32 value v (22 significand bits); weights are split the same way when they
+    are packed.  A convolution computes hi*W_hi + lo*W_hi + hi*W_lo with fp32 accumulation (the dropped lo*W_lo term is
+    < 2^-22 relative): its K table walks every 64-channel block three times (conv.split_ktable), so the halo-tile /
+    LDS-DMA kernels of the fp16 engine run unchanged; only their epilogues read operands as hi + lo and write two planes
+    (csrc/conv_epilogue.h, SPLIT).  Coordinates, flow, correlation values and the up-sampling mask stay fp32.  The
+    all-pairs correlation volume is kept (fp32, RAFT/corr.py:13-27): its GEMM runs on the same kernels
+    (conv.batched_gemm_nt_split)."""
+
+    def __init__(self, sd, device):
+        self.dtype, self.device, self.split3, self.split = torch.float16, device, False, True
+        self.corr_otf = False
+        mk = lambda w, b, **kw: ConvLayer(w, b, dtype=torch.float16, device=device, split=True, **kw)
+        self._build(sd, mk)
+        # the context encoder's output convolution feeds tanh (GRU state) and relu (context input) halves
+        # (RAFT/raft.py:113-116): two convolutions with the activation in the epilogue instead of a split + two passes
+        w2, b2 = sd["cnet.conv2.weight"], sd["cnet.conv2.bias"]
+        self.cnet["conv2_net"] = mk(w2[:128], b2[:128])
+        self.cnet["conv2_inp"] = mk(w2[128:], b2[128:])
+
+    def encode(self, L, x, instance_norm):
+        """x split-plane NHWC [n,H,W,16] -> split-plane [n,H/8,W/8,512]; for the context encoder (instance_norm False) the
+        pair (tanh half, relu half), each split-plane [n,H/8,W/8,256]."""
+        f32 = torch.float32
+        if instance_norm:
+            def block(x, p, down):
+                y = hip.instance_norm_split(L[p + ".conv1"]([x], out_dtype=f32), relu=True)
+                if down:
+                    x = hip.instance_norm_split(L[p + ".down"]([x], out_dtype=f32), relu=False)
+                return hip.instance_norm_split(L[p + ".conv2"]([y], out_dtype=f32), relu=True, residual=x, relu2=True)
+            x = hip.instance_norm_split(L["conv1"]([x], out_dtype=f32), relu=True)
+        else:
+            def block(x, p, down):
+                y = L[p + ".conv1"]([x], act="relu")
+                if down:
+                    x = L[p + ".down"]([x])
+                return L[p + ".conv2"]([y], act="relu", residual=x, act2="relu")
+            x = L["conv1"]([x], act="relu")
+        for li in (1, 2, 3):
+            x = block(x, f"layer{li}.0", li > 1)
+            x = block(x, f"layer{li}.1", False)
+        if instance_norm:
+            return L["conv2"]([x])
+        return L["conv2_net"]([x], act="tanh"), L["conv2_inp"]([x], act="relu")
+
+    def refine(self, f1, f2, ctx, iters):
+        """f1, f2 split-plane [P,h,w,512]; ctx = (net0, inp) split-plane [P,h,w,256] each.  Returns fp32 flow_up [P,2,8h,8w]."""
+        net0, inp = ctx
+        P, h, w, _ = f1.shape
+        dev, dt = f1.device, torch.float16
+        n8 = h * w
+        vol = batched_gemm_nt_split(f1.view(P, n8, 512), f2.view(P, n8, 512), out_scale=1.0 / 16.0)
+        levels = [vol.view(P * n8, h, w)]
+        hh, ww = h, w
+        for _ in range(3):
+            levels.append(hip.corr_avgpool(levels[-1], P * n8, hh, ww))
+            hh, ww = hh // 2, ww // 2
+        net = net0.clone()
+        pre = [(G["zr_pre"]([inp]), G["q_pre"]([inp])) for G in self.gru]     # iteration-invariant partial sums
+        xbuf = torch.empty((P, h, w, 256), dtype=dt, device=dev)            # [motion(126) | flow(2)] x (hi, lo)
+        ys, xs = torch.meshgrid(torch.arange(h, device=dev, dtype=torch.float32),
+                                torch.arange(w, device=dev, dtype=torch.float32), indexing="ij")
+        coords0 = torch.stack([xs, ys], -1)[None].expand(P, h, w, 2).contiguous()
+        coords1 = coords0.clone()
+        corr = torch.empty((P, h, w, 656), dtype=dt, device=dev)
+        frow = torch.empty((P, h, w, 32), dtype=dt, device=dev)
+        zbuf = torch.empty((P, h, w, 256), dtype=dt, device=dev)
+        rh = torch.empty((P, h, w, 256), dtype=dt, device=dev)
+        delta = torch.zeros((P, h, w, 8), dtype=torch.float32, device=dev)
+        for it in range(iters):
+            hip.corr_lookup(levels, coords1, corr, split=True)
+            hip.raft_flow_taps(coords1, coords0, frow, flow_out=xbuf, flow_choff=126, split=True)
+            cor = self.convc2([self.convc1([corr], act="relu")], act="relu")
+            flo = self.convf2([self.convf1([frow], act="relu")], act="relu")
+            self.convm([cor, flo], out=xbuf, out_choff=0, act="relu")
+            for G, (pzr, pq) in zip(self.gru, pre):
+                G["zr"]([net, xbuf], out=zbuf, act="sigmoid", preadd=pzr, fuse=dict(kind="gru_zr", h=net, out2=rh, split=128))
+                G["q"]([rh, xbuf], out=net, act="tanh", preadd=pq, fuse=dict(kind="gru_h", h=net, z=zbuf))
+            self.fh2([self.fh1([net], act="relu")], out=delta, out_dtype=torch.float32)
+            coords1 = coords1 + delta[..., :2]
+        mask = self.mask2([self.mask0([net], act="relu")], out_scale=0.25, out_dtype=torch.float32)
+        return hip.convex_upsample((coords1 - coords0).contiguous(), mask)
+
+
 class RAFT_bi(nn.Module):
     """Bidirectional RAFT flow of consecutive frame pairs (reference: model/modules/flow_comp_raft.py:27-55)."""
 
@@ -240,8 +332,10 @@ class RAFT_bi(nn.Module):
         eng = self._engines.get(precision)
         if eng is None or eng[0] != key:
             sd = {k: v.detach().float().cpu() for k, v in self.fix_raft.state_dict().items()}
-            dt = torch.float16 if precision == "f16" else torch.float32
-            eng = (key, _RaftEngine(sd, dt, device, split3=(precision == "f16x3")))
+            if precision == "f16x3":
+                eng = (key, _RaftEngineSplit(sd, device))
+            else:
+                eng = (key, _RaftEngine(sd, torch.float16 if precision == "f16" else torch.float32, device))
             self._engines[precision] = eng
         return eng[1]
 
@@ -265,27 +359,37 @@ class RAFT_bi(nn.Module):
         dev = gt_local_frames.device
         fm, cx_ = [], []
         for s in range(0, b * l_t, fchunk):
-            x = hip.nchw_to_nhwc(fr[s:s + fchunk].contiguous(), out_dtype=dt, cpad=8)
+            if eng.split:     # split-plane engine: [n, H, W, 8 hi | 8 lo] fp16 planes of the fp32 frames
+                x = hip.nchw_to_nhwc(fr[s:s + fchunk].contiguous().float(), cpad=8, split=True)
+            else:
+                x = hip.nchw_to_nhwc(fr[s:s + fchunk].contiguous(), out_dtype=dt, cpad=8)
             f_, c_ = hip.fork_join(dev, [lambda: eng.encode(eng.fnet, x, True), lambda: eng.encode(eng.cnet, x, False)], streams)
             fm.append(f_)
-            cx_.append(c_)
-        fmap = (fm[0] if len(fm) == 1 else torch.cat(fm, 0)).view(b, l_t, h // 8, w // 8, 256)
-        ctx = (cx_[0] if len(cx_) == 1 else torch.cat(cx_, 0)).view(b, l_t, h // 8, w // 8, 256)
-        a_f, a_b = fmap[:, :-1].reshape(-1, h // 8, w // 8, 256), fmap[:, 1:].reshape(-1, h // 8, w // 8, 256)
-        c_f, c_b = ctx[:, :-1].reshape(-1, h // 8, w // 8, 256), ctx[:, 1:].reshape(-1, h // 8, w // 8, 256)
-        f1 = torch.cat([a_f, a_b], 0)
-        f2 = torch.cat([a_b, a_f], 0)
-        cx = torch.cat([c_f, c_b], 0)
+            cx_.append(c_ if isinstance(c_, (tuple, list)) else (c_,))      # (the split-plane engine returns the (tanh, relu) halves)
+        h8, w8 = h // 8, w // 8
+        # pair-directions: forward pairs (i, i + 1) then backward pairs (i + 1, i); the context comes from the first frame of a pair
+        def pairs(parts, first):
+            t = (parts[0] if len(parts) == 1 else torch.cat(parts, 0))
+            t = t.view(b, l_t, h8, w8, t.shape[-1])
+            fw, bw = t[:, :-1].reshape(-1, h8, w8, t.shape[-1]), t[:, 1:].reshape(-1, h8, w8, t.shape[-1])
+            return torch.cat([fw, bw], 0) if first else torch.cat([bw, fw], 0)
+        f1, f2 = pairs(fm, True), pairs(fm, False)
+        cxs = [pairs([c[k] for c in cx_], True) for k in range(len(cx_[0]))]
         P = f1.shape[0]
-        n8 = (h // 8) * (w // 8)
+        n8 = h8 * w8
+        lanes = streams if (streams > 1 and P >= 2 * streams) else 1
         if eng.corr_otf:      # largest activation of the update block: the [P, h8, w8, 328] lookup tile, < 2 GiB (32-bit buffer offsets)
             chunk = self.max_pairs or max(1, ((1 << 31) - 1) // (n8 * 328 * 2))
-        else:                 # fp32 all-pairs pyramid: 1.34 x n8^2 x 4 bytes per pair-direction, 40 GB per chunk
-            chunk = self.max_pairs or max(1, int(40e9 // (n8 * n8 * 4 * 1.34)))
-        if streams > 1 and P >= 2 * streams:
+        else:                 # fp32 all-pairs pyramid: 1.34 x n8^2 x 4 bytes per pair-direction, 40 GB over the chunks in flight
+            chunk = self.max_pairs or max(1, int(40e9 // lanes // (n8 * n8 * 4 * 1.34)))
+            if eng.split:     # ... and the largest split-plane activation (the [P, h8, w8, 2 x 328] lookup tile) below 2 GiB
+                chunk = min(chunk, max(1, ((1 << 31) - 1) // (n8 * 656 * 2)))
+        if lanes > 1:
             chunk = min(chunk, -(-P // streams))
-        parts = [(f1[i:i + chunk].contiguous(), f2[i:i + chunk].contiguous(), cx[i:i + chunk].contiguous()) for i in range(0, P, chunk)]
-        ups = hip.fork_join(dev, [(lambda a=a, b_=b_, c_=c_: eng.refine(a, b_, c_, iters)) for a, b_, c_ in parts], streams)
+        parts = [(f1[i:i + chunk].contiguous(), f2[i:i + chunk].contiguous(), [c[i:i + chunk].contiguous() for c in cxs])
+                 for i in range(0, P, chunk)]
+        ups = hip.fork_join(dev, [(lambda a=a, b_=b_, c_=c_: eng.refine(a, b_, c_[0] if len(c_) == 1 else tuple(c_), iters))
+                                  for a, b_, c_ in parts], streams)
         up = torch.cat(ups, 0).to(gt_local_frames.dtype)
         half = P // 2
         return up[:half].view(b, l_t - 1, 2, h, w), up[half:].view(b, l_t - 1, 2, h, w)

@@ -22,15 +22,53 @@ _ACT = {hip.ACT_NONE: lambda v, p: v, hip.ACT_RELU: lambda v, p: F.relu(v), hip.
         hip.ACT_GELU: lambda v, p: F.gelu(v)}
 
 
+def split_planes(x, cpad=None):
+    """fp32 [..., C] -> split-plane fp16 [..., 2 * cpad]: hi = fp16(v) | lo = fp16(v - hi) (what the SPLIT epilogues / packers write)."""
+    C_ = x.shape[-1]
+    cpad = cpad or C_
+    hi = x.float().half()
+    lo = (x.float() - hi.float()).half()
+    out = torch.zeros(x.shape[:-1] + (2 * cpad,), dtype=torch.float16)
+    out[..., :C_] = hi
+    out[..., cpad:cpad + C_] = lo
+    return out
+
+
+def merge_planes(t, choff=0, C_=None):
+    """split-plane fp16 [..., 2 * Cp] -> fp32 [..., C_] = hi + lo of the channel window [choff, choff + C_)."""
+    lo = t.shape[-1] // 2
+    C_ = lo - choff if C_ is None else C_
+    return t[..., choff:choff + C_].float() + t[..., lo + choff:lo + choff + C_].float()
+
+
+def _put(t, choff, y, split):
+    """writes fp32 y into the channel window of t starting at choff (both planes when split)"""
+    C_ = y.shape[-1]
+    tv = t.view(y.shape[:-1] + (t.shape[-1],))
+    if split and t.dtype == torch.float16:
+        lo = t.shape[-1] // 2
+        hi = y.half()
+        tv[..., choff:choff + C_] = hi
+        tv[..., lo + choff:lo + choff + C_] = (y - hi.float()).half()
+    else:
+        tv[..., choff:choff + C_] = y.to(t.dtype)
+
+
+def _get(t, choff, C_, split):
+    return merge_planes(t, choff, C_) if split else t.float()[..., choff:choff + C_]
+
+
 def _conv_call(self, srcs, out=None, out_choff=0, act=None, act_param=0.0, out_scale=1.0, residual=None, res_choff=0,
                act2=None, out_dtype=None, dcn_offmask=None, out_hw=None, preadd=None, fuse=None):
     srcs = [(s, 0) if torch.is_tensor(s) else s for s in srcs]
     x0 = srcs[0][0]
     N, H, W = x0.shape[:3]
     OH, OW = out_hw if out_hw is not None else self.out_hw(H, W)
+    sp = bool(getattr(self, "split", False))
     if out is None:
         cp = pconv.pad8(self.cout)
-        out = torch.zeros((N, OH, OW, cp), dtype=out_dtype or self.dtype)
+        odt = out_dtype or self.dtype
+        out = torch.zeros((N, OH, OW, 2 * cp if (sp and odt == torch.float16) else cp), dtype=odt)
     kt = self.ktable.cpu().numpy()[:self.kchunks]      # the last row is the kernels' 16-byte zero page
     oy = torch.arange(OH).view(1, OH, 1) * self.stride[0] - self.padding[0]
     ox = torch.arange(OW).view(1, 1, OW) * self.stride[1] - self.padding[1]
@@ -69,7 +107,7 @@ def _conv_call(self, srcs, out=None, out_choff=0, act=None, act_param=0.0, out_s
         win = lambda x: (x, 0) if torch.is_tensor(x) else x
         if preadd is not None:
             pt, pc = win(preadd)
-            y = y + pt.float()[..., pc:pc + self.cout_g].reshape(y.shape)
+            y = y + _get(pt, pc, self.cout_g, sp).reshape(y.shape)
         y = _ACT[pconv.ACTS[act]](y, act_param)
         if fuse is not None and fuse["kind"] == "dcn_om":
             Cs = int(fuse.get("split", 288))
@@ -85,21 +123,27 @@ def _conv_call(self, srcs, out=None, out_choff=0, act=None, act_param=0.0, out_s
             if fuse["kind"] == "gru_zr":
                 Cs = int(fuse["split"])
                 ot, oc = win(fuse["out2"])
-                hv = ht.float()[..., hc:hc + self.cout_g - Cs]
-                ot.view(N, OH, OW, -1)[..., oc:oc + self.cout_g - Cs] = (y[..., Cs:] * hv.reshape(y[..., Cs:].shape)).to(ot.dtype)
-                out.view(N, OH, OW, -1)[..., out_choff:out_choff + Cs] = y[..., :Cs].to(out.dtype)
+                hv = _get(ht, hc, self.cout_g - Cs, sp)
+                _put(ot, oc, y[..., Cs:] * hv.reshape(y[..., Cs:].shape), sp)
+                _put(out, out_choff, y[..., :Cs], sp)
                 continue
             zt, zc = win(fuse["z"])
-            hv = ht.float()[..., hc:hc + self.cout_g].reshape(y.shape)
-            zv = zt.float()[..., zc:zc + self.cout_g].reshape(y.shape)
+            hv = _get(ht, hc, self.cout_g, sp).reshape(y.shape)
+            zv = _get(zt, zc, self.cout_g, sp).reshape(y.shape)
             y = (1 - zv) * hv + zv * y
         c0 = out_choff + g * self.cout_g
         if residual is not None:
-            y = y + residual.float()[..., res_choff + g * self.cout_g: res_choff + (g + 1) * self.cout_g].reshape(y.shape)
+            y = y + _get(residual, res_choff + g * self.cout_g, self.cout_g, sp).reshape(y.shape)
         if pconv.ACTS[act2] == hip.ACT_RELU:
             y = F.relu(y)
-        out.view(N, OH, OW, -1)[..., c0:c0 + self.cout_g] = y.to(out.dtype)
+        _put(out, c0, y, sp)
     return out
+
+
+def _batched_gemm_nt_split(a, b, out_scale=1.0):
+    K = a.shape[-1] // 2
+    ah, al, bh, bl = a[..., :K].float(), a[..., K:].float(), b[..., :K].float(), b[..., K:].float()
+    return (torch.matmul(ah, bh.transpose(1, 2)) + torch.matmul(al, bh.transpose(1, 2)) + torch.matmul(ah, bl.transpose(1, 2))) * out_scale
 
 
 def _batched_gemm_nt(a, bt, out_scale=1.0, split3=False):
@@ -138,10 +182,10 @@ def _corr_avgpool(x, M, H, W):
     return F.avg_pool2d(x.view(M, 1, H, W), 2, 2)[:, 0].contiguous()
 
 
-def _corr_lookup(levels, coords, out):
+def _corr_lookup(levels, coords, out, split=False):
     ref = O.corr_lookup([l[:, None] for l in levels], coords.permute(0, 3, 1, 2))
-    out[..., :324] = ref.permute(0, 2, 3, 1).to(out.dtype)
-    out[..., 324:] = 0
+    out.zero_()
+    _put(out, 0, ref.permute(0, 2, 3, 1).contiguous(), split)
     return out
 
 
@@ -205,6 +249,14 @@ def _depthwise_pool(x, weight, bias, k=4):
     return y.permute(0, 2, 3, 1).contiguous().to(x.dtype)
 
 
+def _instance_norm_split(x, relu=False, eps=1e-5, residual=None, res_choff=0, relu2=False):
+    y = F.instance_norm(x.float().permute(0, 3, 1, 2), eps=eps).permute(0, 2, 3, 1)
+    y = F.relu(y) if relu else y
+    if residual is not None:
+        y = y + merge_planes(residual, res_choff, x.shape[-1])
+    return split_planes(F.relu(y) if relu2 else y)
+
+
 def _instance_norm(x, relu=False, eps=1e-5, out=None):
     y = F.instance_norm(x.float().permute(0, 3, 1, 2), eps=eps)
     y = (F.relu(y) if relu else y).permute(0, 2, 3, 1).contiguous().to(x.dtype)
@@ -228,15 +280,15 @@ def _dcn_act(om, mag, flow=None, fl_choff=0):
     return om
 
 
-def _raft_flow_taps(coords1, coords0, rows, flow_out=None, flow_choff=0):
+def _raft_flow_taps(coords1, coords0, rows, flow_out=None, flow_choff=0, split=False):
     flow = coords1 - coords0                                               # fp32 [P,h,w,2]
     fp = F.pad(flow, (0, 0, 3, 3))                                         # zero columns left / right
     w = flow.shape[2]
     rows.zero_()
     for kx in range(7):
-        rows[..., 2 * kx:2 * kx + 2] = fp[:, :, kx:kx + w].to(rows.dtype)
+        _put(rows, 2 * kx, fp[:, :, kx:kx + w], split)
     if flow_out is not None:
-        flow_out[..., flow_choff:flow_choff + 2] = flow.to(flow_out.dtype)
+        _put(flow_out, flow_choff, flow, split)
     return rows
 
 
@@ -251,11 +303,12 @@ def _gru_gate(zr, h, h_choff, Cc, out, out_choff, q=None):
     return out
 
 
-def _nchw_to_nhwc(x, out=None, out_choff=0, out_dtype=None, cpad=None, scale=1.0):
+def _nchw_to_nhwc(x, out=None, out_choff=0, out_dtype=None, cpad=None, scale=1.0, split=False):
     N, Cc, H, W = x.shape
     if out is None:
-        out = torch.zeros((N, H, W, cpad or (Cc + 7) // 8 * 8), dtype=out_dtype or x.dtype)
-    out[..., out_choff:out_choff + Cc] = (x.float() * scale).permute(0, 2, 3, 1).to(out.dtype)
+        cp = cpad or (Cc + 7) // 8 * 8
+        out = torch.zeros((N, H, W, 2 * cp if split else cp), dtype=torch.float16 if split else (out_dtype or x.dtype))
+    _put(out, out_choff, (x.float() * scale).permute(0, 2, 3, 1), split)
     return out
 
 
@@ -274,18 +327,20 @@ def emulated_device_ops():
         "sparse_window_attention": _attention, "fold_tokens": _fold_tokens, "layernorm": _layernorm,
         "depthwise_pool": _depthwise_pool, "instance_norm": _instance_norm, "upsample2x": _upsample2x,
         "dcn_offset_mask_act": _dcn_act, "gru_gate": _gru_gate, "nchw_to_nhwc": _nchw_to_nhwc, "nhwc_to_nchw": _nhwc_to_nchw,
+        "instance_norm_split": _instance_norm_split,
     }
     patches["require_gpu"] = lambda t, who: None
     saved = {k: getattr(hip, k) for k in patches}
     saved_call, saved_gemm = pconv.ConvLayer.__call__, pconv.batched_gemm_nt
     import propainter_amd.model.modules.flow_comp_raft as fr
-    saved_fr_gemm = fr.batched_gemm_nt
+    saved_fr_gemm, saved_fr_gemm_s, saved_gemm_s = fr.batched_gemm_nt, fr.batched_gemm_nt_split, pconv.batched_gemm_nt_split
     try:
         for k, f in patches.items():
             setattr(hip, k, f)
         pconv.ConvLayer.__call__ = _conv_call
         pconv.batched_gemm_nt = _batched_gemm_nt
         fr.batched_gemm_nt = _batched_gemm_nt
+        fr.batched_gemm_nt_split = pconv.batched_gemm_nt_split = _batched_gemm_nt_split
         yield
     finally:
         for k, f in saved.items():
@@ -293,3 +348,4 @@ def emulated_device_ops():
         pconv.ConvLayer.__call__ = saved_call
         pconv.batched_gemm_nt = saved_gemm
         fr.batched_gemm_nt = saved_fr_gemm
+        fr.batched_gemm_nt_split, pconv.batched_gemm_nt_split = saved_fr_gemm_s, saved_gemm_s

@@ -124,3 +124,53 @@ def test_raft_fp16_graph_uses_the_on_the_fly_correlation(models):
                         torch.cat([ctx[:-1], ctx[1:]]).contiguous(), int(g["iters"]))
     epe = (up[:2].float() - torch.from_numpy(g["flows_f"])).pow(2).sum(1).sqrt()
     assert epe.mean() < 0.05 and epe.max() < 0.5, (epe.mean(), epe.max())
+
+
+def test_raft_split_plane_engine_graph(models):
+    """Precision "f16x3" = the split-plane engine (fp16 hi / lo planes, K tables walking every block three times, W_hi / W_lo
+    packed in table order): the whole RAFT_bi.forward under the CPU emulation (which consumes exactly the tables and packed
+    weights the kernels get) must reproduce the REAL reference's golden flows at fp32-class accuracy."""
+    raft = models[0]
+    g = load_golden("raft_128x192.npz")
+    fr = torch.from_numpy(g["frames_u8"]).permute(0, 3, 1, 2).float().div(255)[None] * 2 - 1
+    with emulated_device_ops():
+        raft.precision = "f16x3"
+        try:
+            eng = raft._get_engine("f16x3", torch.device("cpu"))
+            assert eng.split and not eng.corr_otf and eng.convc2.split and eng.convc2.kchunks == 3 * 9 * 32
+            ff, fb = raft(fr, iters=int(g["iters"]))
+        finally:
+            raft.precision = None
+    ef = (ff[0] - torch.from_numpy(g["flows_f"])).pow(2).sum(1).sqrt()
+    eb = (fb[0] - torch.from_numpy(g["flows_b"])).pow(2).sum(1).sqrt()
+    print(f"split-plane RAFT (emulated) EPE vs golden: fw mean {ef.mean():.2e} max {ef.max():.2e}, bw mean {eb.mean():.2e} max {eb.max():.2e}")
+    assert ef.mean() < 1e-4 and ef.max() < 2e-3 and eb.mean() < 1e-4 and eb.max() < 2e-3
+
+
+def test_split_ktable_and_weight_packing():
+    """conv.split_ktable: every block of the base table appears three times in a row (hi plane x W_hi, lo plane x W_hi, hi plane x
+    W_lo), lo-plane chunks point src_lo channels further, padding chunks are dead; pack_weight follows the flags; the expanded
+    layer equals the fp32 convolution to ~2^-21 on split-plane inputs (CPU emulation of the kernel contract)."""
+    from propainter_amd import conv as pconv, hip
+    from tests.cpu_emulation import emulated_device_ops, merge_planes, split_planes
+    base = hip.build_ktable([(ky, kx) for ky in range(3) for kx in range(3)], [64, 96])
+    kt = pconv.split_ktable(base, [64, 128])
+    n_live = int(((base[:-1, 2] & 0xff) != 255).sum())
+    assert kt.shape[0] - 1 == (3 * n_live + 7) // 8 * 8 and (kt[-1] == 0).all()
+    live = kt[:-1][(kt[:-1, 2] & 0xff) != 255]
+    blk = 9 * 8                                   # first block: source 0, 64 channels, 9 taps
+    a, b, c = live[:blk], live[blk:2 * blk], live[2 * blk:3 * blk]
+    assert ((a[:, 2] >> 24) == 0).all() and ((b[:, 2] >> 24) == 1).all() and ((c[:, 2] >> 24) == 2).all()
+    assert (b[:, 3] == a[:, 3] + 64).all() and (c[:, 3] == a[:, 3]).all() and (a[:, :2] == b[:, :2]).all()
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(40, 160, 3, 3, generator=g) * 0.1
+    bias = torch.randn(40, generator=g)
+    x0, x1 = torch.randn(1, 9, 11, 64, generator=g), torch.randn(1, 9, 11, 96, generator=g) * 30
+    with emulated_device_ops():
+        layer = pconv.ConvLayer(w, bias, padding=1, src_channels=[64, 96], dtype=torch.float16, device="cpu", split=True, src_lo=[64, 128])
+        s1 = split_planes(x1, 128)               # a 96-channel window of a buffer whose planes are 128 wide
+        y = layer([split_planes(x0), s1], act="relu")
+    assert y.shape == (1, 9, 11, 80) and y.dtype == torch.float16
+    ref = torch.relu(torch.nn.functional.conv2d(torch.cat([x0, x1], -1).permute(0, 3, 1, 2).double(), w.double(), bias.double(), padding=1))
+    err = (merge_planes(y).double() - ref.permute(0, 2, 3, 1)).abs().max() / ref.abs().max()
+    assert err < 2e-6, err
