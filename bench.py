@@ -16,11 +16,13 @@ Rank 0 prints ONE JSON line (schema: see README / the driver contract) with thes
   "roofline":        the dominant kernel class of the step measured live with HIP events on the launch stream
                      (KernelProfiler in propainter_amd/hip.py) in one extra instrumented step after the timed region;
   "cpu_baseline":    the CPU oracle (oracle/propainter_oracle.py -- the checker, never the product) timed on this
-                     box's host cores on a bounded sample, rank 0, N=1 only;
-  "parity":          the HIP path at the TIMED precision configuration on the very clip the CPU oracle sample inpaints
-                     (432x240), compared byte for byte with the oracle's frames (PSNR, max |d|, fraction of differing bytes);
-  "raft_precisions": frames/s and parity of the same pass with RAFT at the reference's own precision class
-                     ("f16x3": fp32 tensors, products as 3 fp16 MFMAs; "f32": exact fp32 MFMA) next to the headline's;
+                     box's host cores on a bounded sample AT THE TIMED RESOLUTION (a 6-frame clip through the whole path),
+                     stage by stage; value = the clip's unit counts x the measured per-unit costs (SURVEY.md 8(d)), rank 0, N=1;
+  "parity":          the HIP path at the TIMED precision configuration and resolution on the very clip the CPU oracle sample
+                     inpaints, compared byte for byte with the oracle's frames (PSNR, max |d|, fraction of differing bytes) and
+                     |PSNR(HIP, ground truth) - PSNR(oracle, ground truth)| (north_star: within 0.05 dB);
+  "raft_precisions": frames/s and parity of the same pass at the other RAFT precisions ("f16": fp16 activations, NARROWER
+                     than the reference's fp32 RAFT; "f32": exact fp32 MFMA) next to the headline's;
   "memory":          peak device memory of the pass (the reference publishes only memory: README.md:192-195).
 """
 import argparse
@@ -35,30 +37,38 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"f16": 2500.0, "f32": 157.3}     # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_TFLOPS = {"f16": 2500.0, "f32": 157.3,     # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+               # split-plane ("f16x3") layers: every fp32-class product is three fp16 MFMA products, so the roofline of the
+               # ALGORITHMIC (fp32-layer) FLOPs on this hardware is the dense fp16 peak / 3 (identical fraction on executed FLOPs)
+               "f16x3": 2500.0 / 3.0}
 PEAK_HBM_GBS = 8000.0
 # KernelProfiler class -> kernel family of tools/rocprof_summary.py (profiles/*_hbm_traffic.json, PMC passes)
 TRAFFIC_FAMILY = {"conv_gemm_f16": "conv_gemm_f16 (LDS-DMA implicit GEMM)", "conv_gemm_f32": "conv_gemm_f32",
+                  "conv_gemm_f16x3": "conv_gemm_f16x3 (split-plane LDS-DMA implicit GEMM)",
                   "conv_gemm_dcn": "conv_gemm_dcn (patch-staged)", "corr_lookup_otf": "corr_lookup_otf", "sparse_window_attention": "sparse_window_attention",
                   "fold_tokens": "fold_tokens", "corr_lookup": "corr_lookup"}
 # minimal algorithmic FLOPs of BASELINE config 3 (720x1280x80, 25 % of the windows masked)
 C3_ALGORITHMIC_TFLOP = 599.0
 
 
-def pmc_traffic(kernel_class):
-    """HBM bytes per launch of a kernel class from the newest committed rocprofv3 --pmc summary (FETCH_SIZE / WRITE_SIZE
-    in separate passes, gfx950 correction applied by tools/rocprof_summary.py).  Returns (bytes or None, source file):
-    PMC counters cannot be collected inside this process, so the figure is the committed profile's, not this run's."""
+def pmc_traffic(kernel_class, raft_dtype):
+    """HBM bytes per launch of a kernel class from a committed rocprofv3 --pmc summary (FETCH_SIZE / WRITE_SIZE in separate
+    passes, gfx950 correction applied by tools/rocprof_summary.py).  PMC counters cannot be collected inside this process, so
+    the figure is a committed profile's, never this run's: only a profile that records the commit it was measured at and the
+    same RAFT precision is used, and both are reported.  Returns (bytes or None, source description or None)."""
     import glob
     fam = TRAFFIC_FAMILY.get(kernel_class)
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_traffic*.json")), key=os.path.getmtime, reverse=True):
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "*hbm_traffic*.json")):
         try:
-            rec = json.load(open(f))["families"].get(fam)
+            d = json.load(open(f))
+            rec = d["families"].get(fam)
         except Exception:
             continue
-        if rec:
-            return rec["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
-    return None, None
+        if rec and d.get("commit") and d.get("raft_dtype") == raft_dtype and (best is None or d.get("commit_time", 0) > best[0]):
+            best = (d.get("commit_time", 0), rec["hbm_bytes_per_launch"],
+                    f"{os.path.relpath(f, ROOT)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at commit {d['commit']}, RAFT {raft_dtype}; not collected in this run)")
+    return (best[1], best[2]) if best else (None, None)
 
 
 def parse():
@@ -74,12 +84,12 @@ def parse():
     ap.add_argument("--subvideo_length", type=int, default=80)
     ap.add_argument("--raft_iter", type=int, default=20)
     ap.add_argument("--fp32", action="store_true", help="run stages B-D in fp32 instead of fp16")
-    ap.add_argument("--raft-dtype", default="f16", choices=["f32", "f16x3", "f16"],
-                    help="RAFT precision of the TIMED pass: f16 (default) = fp16 activations/weights on MFMA with fp32 "
-                         "accumulation, fp32 correlation values, coordinates and flow; f16x3 = fp32 tensors, every product as "
-                         "three fp16 MFMAs (hi*hi + hi*lo + lo*hi, ~2^-21); f32 = exact fp32 MFMA.  The reference keeps RAFT "
-                         "fp32 under --fp16 (inference_propainter.py:311): the other two modes are timed once each and "
-                         "reported under raft_precisions")
+    ap.add_argument("--raft-dtype", default="f16x3", choices=["f32", "f16x3", "f16"],
+                    help="RAFT precision of the TIMED pass.  The reference keeps RAFT fp32 under --fp16 "
+                         "(inference_propainter.py:311), so the like-for-like default is f16x3 = fp32-class RAFT: split-plane fp16 "
+                         "activations / weights (22 significand bits), every product as three fp16 MFMAs (hi*hi + lo*hi + hi*lo, "
+                         "~2^-21) with fp32 accumulation.  f32 = exact fp32 MFMA; f16 = fp16 activations / weights (NARROWER than "
+                         "the reference: reported only as value_raft_f16 / under raft_precisions)")
     ap.add_argument("--sharded", action="store_true",
                     help="ONE clip of --frames frames sharded by sub-video over the ranks (propainter_amd/sharding.py, RCCL "
                          "point-to-point halo exchange; BASELINE configs 4 / 5) instead of one clip per rank; strong scaling")
@@ -97,22 +107,22 @@ def parse():
     ap.add_argument("--single-pass", action="store_true",
                     help="profiling aid: run exactly ONE eager pass of the clip and exit (what the rocprofv3 passes of "
                          "tools/gpu_profile.sh wrap, so that per-kernel counts are per pass)")
-    ap.add_argument("--cpu-sample-frames", type=int, default=16, help="frames of the 432x240 CPU-oracle sample (about 10-25 s on 16 threads)")
+    ap.add_argument("--cpu-sample-frames", type=int, default=6,
+                    help="frames of the CPU-oracle sample clip at the bench resolution (6 frames of 720x1280: ~2 min on 16 threads, "
+                         "next to the GPU legs)")
+    ap.add_argument("--cpu-timeout", type=float, default=480.0, help="hard limit of the CPU-oracle child process, seconds")
     ap.add_argument("--cpu-baseline-worker", default=None, help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
-SAMPLE_H, SAMPLE_W = 240, 432
-
-
 def sample_clip(args):
-    """The bounded sample both the CPU oracle and the parity check run on: a short 432x240 synthetic clip."""
+    """The bounded sample both the CPU oracle and the parity check run on: a short synthetic clip AT THE TIMED RESOLUTION."""
     import numpy as np
     import scipy.ndimage
     from propainter_amd.synthetic import synthetic_clip, synthetic_mask
     L = args.cpu_sample_frames
-    clip = synthetic_clip(L, SAMPLE_H, SAMPLE_W)
-    m = scipy.ndimage.binary_dilation(synthetic_mask(SAMPLE_H, SAMPLE_W), iterations=4).astype(np.uint8) * 255
+    clip = synthetic_clip(L, args.height, args.width)
+    m = scipy.ndimage.binary_dilation(synthetic_mask(args.height, args.width), iterations=4).astype(np.uint8) * 255
     return clip, np.repeat(m[None], L, 0)
 
 
@@ -131,20 +141,23 @@ def _cpu_baseline_worker(args):
            "fc": {k: v.float() for k, v in fc.state_dict().items()},
            "gen": {k: v.float() for k, v in gen.state_dict().items()}}
     t0 = time.perf_counter()
+    timers = {}
     with torch.no_grad():
         frames = O.inpaint_video(sds, clip, masks, masks, raft_iter=args.raft_iter, subvideo_length=args.subvideo_length,
-                                 neighbor_length=args.neighbor_length, ref_stride=args.ref_stride)
+                                 neighbor_length=args.neighbor_length, ref_stride=args.ref_stride, timers=timers)
     dt = time.perf_counter() - t0
     np.save(args.cpu_baseline_worker, np.stack(frames))
-    print(json.dumps({"seconds": dt, "frames": len(frames), "cores": cores, "H": SAMPLE_H, "W": SAMPLE_W}))
+    print(json.dumps({"seconds": dt, "frames": len(frames), "cores": cores, "H": args.height, "W": args.width, "timers": timers}))
 
 
 class CpuBaseline:
-    """CPU oracle (fp32) on a bounded sample: the full path over a short 432x240 clip in a child process with a hard
-    timeout, started next to the GPU work (it uses host cores only) and collected at the end; scaled to the bench
-    resolution by the algorithmic FLOPs per frame."""
+    """CPU oracle (fp32) on a bounded sample at the bench resolution: the full path over a short clip in a child process
+    with a hard timeout, started next to the GPU work (it uses host cores only) and collected at the end.  The per-unit
+    costs it measures (RAFT pair-direction, flow-completion flow, propagation step, generator window-frame) times the unit
+    counts of the timed clip give the baseline."""
 
-    def __init__(self, args, timeout=300):
+    def __init__(self, args, timeout=None):
+        timeout = timeout or args.cpu_timeout
         import subprocess
         self.args, self.timeout = args, timeout
         try:
@@ -159,6 +172,7 @@ class CpuBaseline:
         fd, self.out_path = tempfile.mkstemp(suffix=".npy", prefix="pp_oracle_")
         os.close(fd)
         cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", self.out_path,
+               "--height", str(args.height), "--width", str(args.width),
                "--cpu-sample-frames", str(args.cpu_sample_frames), "--raft_iter", str(args.raft_iter),
                "--subvideo_length", str(args.subvideo_length), "--neighbor_length", str(args.neighbor_length),
                "--ref_stride", str(args.ref_stride)]
@@ -187,27 +201,48 @@ class CpuBaseline:
                 os.unlink(self.out_path)
             except OSError:
                 pass
-        dt, L, H, W = rec["seconds"], rec["frames"], rec["H"], rec["W"]
-        fps_sample = L / dt
-        # per-frame algorithmic work: 7.49 TFLOP at 720x1280 vs 0.80 TFLOP at 240x432, ~ linear in pixels
-        scale = (args.height * args.width) / float(720 * 1280) * (7.49 / 0.80)
-        return ({"value": fps_sample / scale, "unit": "frames/s", "cores": cores, "kind": "port",
-                 "sample": f"CPU oracle fp32, full path on a {L}-frame {W}x{H} synthetic clip: {dt:.1f} s = {fps_sample:.4f} frames/s "
-                           f"on {cores} threads ({self.avail} available), measured while the GPU legs of this bench ran; "
-                           f"EXTRAPOLATED to {args.width}x{args.height} by algorithmic FLOPs/frame (/{scale:.2f}), not measured "
-                           f"at that size",
-                 "measured_sample_seconds": dt, "measured_sample_fps": fps_sample}, frames)
+        dt, Ls, H, W, tm = rec["seconds"], rec["frames"], rec["H"], rec["W"], rec["timers"]
+        # unit counts of the TIMED clip: RAFT pair-directions, completed flows (both directions), propagation
+        # steps, generator window-frames (sum of t over the windows)
+        from propainter_amd.pipeline import window_schedule
+        L = args.frames
+        sched = window_schedule(L, args.neighbor_length, args.ref_stride, args.subvideo_length)
+        units = {"raft_pair_directions": 2 * (L - 1), "fc_flows": 2 * (L - 1), "prop_steps": 2 * (L - 1),
+                 "gen_window_frames": sum(len(nb) + len(ref) for nb, ref in sched)}
+        per_unit = {"raft_pair_direction_s": tm["raft_s"] / tm["raft_pair_directions"], "fc_flow_s": tm["fc_s"] / tm["fc_flows"],
+                    "prop_step_s": tm["prop_s"] / tm["prop_steps"], "gen_window_frame_s": tm["gen_s"] / tm["gen_window_frames"]}
+        est = (units["raft_pair_directions"] * per_unit["raft_pair_direction_s"] + units["fc_flows"] * per_unit["fc_flow_s"] +
+               units["prop_steps"] * per_unit["prop_step_s"] + units["gen_window_frames"] * per_unit["gen_window_frame_s"])
+        return ({"value": L / est, "unit": "frames/s", "cores": cores, "kind": "port",
+                 "sample": f"CPU oracle fp32 (oracle/propainter_oracle.py), whole path on a {Ls}-frame {W}x{H} synthetic clip, measured at "
+                           f"this size on {cores} threads ({self.avail} available) while the GPU legs of this bench ran: {dt:.1f} s "
+                           f"(RAFT {tm['raft_s']:.1f} s / {tm['raft_pair_directions']} pair-directions, flow completion {tm['fc_s']:.1f} s / "
+                           f"{tm['fc_flows']} flows, image propagation {tm['prop_s']:.1f} s / {tm['prop_steps']} steps, generator "
+                           f"{tm['gen_s']:.1f} s / {tm['gen_windows']} windows of {tm['gen_window_frames'] // max(1, tm['gen_windows'])} frames); "
+                           f"value = {L} frames / (unit counts of the {L}-frame clip x these per-unit costs) = {est:.0f} s -- EXTRAPOLATED "
+                           f"in clip length only; the generator's per-frame cost grows with the window length (attention), so longer "
+                           f"windows (17 frames on average here) would cost the CPU more, not less",
+                 "measured_sample_seconds": dt, "measured_sample_fps": Ls / dt, "per_unit_seconds": per_unit, "unit_counts": units,
+                 "estimated_clip_seconds": est}, frames)
 
 
-def parity_of(got_u8, ref_u8, masks_u8):
+def parity_of(got_u8, ref_u8, masks_u8, gt_u8=None):
     """Byte-level comparison of composited frames with the oracle's (uint8 [L,H,W,3]); the PSNR is also given over the
-    hole only (outside the dilated mask both are the input frame, which inflates a whole-frame PSNR)."""
+    hole only (outside the dilated mask both are the input frame, which inflates a whole-frame PSNR).  gt_u8: the unmasked
+    clip -- PSNR(HIP, GT) and PSNR(oracle, GT) with core/metrics.py:20-36's formula and their difference (north_star: the
+    output PSNR within 0.05 dB of the reference's)."""
     import numpy as np
     from oracle import propainter_oracle as O
     d = np.abs(got_u8.astype(np.int16) - ref_u8.astype(np.int16))
     hole = np.broadcast_to((masks_u8 > 0)[..., None], got_u8.shape)
     mse_h = float((d[hole].astype(np.float64) ** 2).mean()) if hole.any() else 0.0
-    return {"psnr_db": round(O.psnr(got_u8, ref_u8), 2),
+    vs_gt = {}
+    if gt_u8 is not None:
+        pg = float(np.mean([O.psnr(got_u8[i], gt_u8[i]) for i in range(len(gt_u8))]))      # per frame, averaged (scripts/evaluate_propainter.py:199-205)
+        pr = float(np.mean([O.psnr(ref_u8[i], gt_u8[i]) for i in range(len(gt_u8))]))
+        vs_gt = {"psnr_vs_ground_truth_db": round(pg, 4), "oracle_psnr_vs_ground_truth_db": round(pr, 4),
+                 "psnr_delta_vs_oracle_db": round(abs(pg - pr), 4)}
+    return {**vs_gt, "psnr_db": round(O.psnr(got_u8, ref_u8), 2),
             "psnr_hole_db": round(float("inf") if mse_h == 0 else 20.0 * np.log10(255.0 / np.sqrt(mse_h)), 2),
             "max_abs": int(d.max()), "bytes_differ_frac": float((d > 0).mean()),
             "bytes_differ_frac_hole": float((d[hole] > 0).mean()) if hole.any() else 0.0,

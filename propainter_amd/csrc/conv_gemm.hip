@@ -572,8 +572,9 @@ extern "C" int pp_conv2d(const pp_conv_args_t* a, void* stream) {
     PP_REQUIRE((a->preadd == nullptr || a->preadd_lo > 0) && (a->fuse == PP_FUSE_NONE || a->fuse_a_lo > 0) &&
                    (a->fuse != PP_FUSE_GRU_ZR || a->out2_lo > 0) && (a->fuse != PP_FUSE_GRU_H || a->fuse_b_lo > 0),
                PP_ERR_ARG, "pp_conv2d: split-plane epilogue operands need their lo offsets");
-    int rc = conv_v3s_dispatch(p, a->impl == 71 || a->impl == 72 ? a->impl : 0, st);
-    if (rc == -1000) rc = conv_v2s_dispatch(p, (a->impl >= 10 && a->impl < 70) || a->impl >= 110 ? a->impl : 0, st);
+    const bool force_v2 = (a->impl >= 10 && a->impl < 70) || a->impl >= 110;      // a specific LDS-DMA tile (tests / tile sweeps)
+    int rc = force_v2 ? -1000 : conv_v3s_dispatch(p, a->impl == 71 || a->impl == 72 ? a->impl : 0, st);
+    if (rc == -1000) rc = conv_v2s_dispatch(p, force_v2 ? a->impl : 0, st);
     PP_REQUIRE(rc != -1000, PP_ERR_ARG, "pp_conv2d: no split-plane kernel for this layer (kchunks %d, impl %d)", a->kchunks, a->impl);
     return rc;
   }

@@ -28,7 +28,7 @@ def split_planes(x, cpad=None):
     cpad = cpad or C_
     hi = x.float().half()
     lo = (x.float() - hi.float()).half()
-    out = torch.zeros(x.shape[:-1] + (2 * cpad,), dtype=torch.float16)
+    out = torch.zeros(x.shape[:-1] + (2 * cpad,), dtype=torch.float16, device=x.device)
     out[..., :C_] = hi
     out[..., cpad:cpad + C_] = lo
     return out

@@ -1,0 +1,229 @@
+"""Parity of the split-plane ("f16x3") kernels -- RAFT at the reference's fp32 precision class on the fp16 matrix cores
+(the reference keeps RAFT fp32 even under --fp16: inference_propainter.py:311) -- against fp64 PyTorch on the very
+values the planes represent.  A split-plane tensor carries 22 significand bits per value and every product is
+hi*W_hi + lo*W_hi + hi*W_lo with fp32 accumulation, so the bar is fp32-class: 3e-6 of the output range (a plain fp16
+layer sits at ~1e-3, the exact fp32 MFMA kernel at ~1e-6)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import propainter_oracle as O
+from tests.cpu_emulation import merge_planes, split_planes
+from tests.helpers import report
+
+pytestmark = pytest.mark.gpu
+RTOL = 3e-6
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from propainter_amd import hip
+    hip.lib()
+    return torch.device("cuda:0")
+
+
+def planes(x_nchw, cpad=None):
+    """fp32 NCHW (CPU) -> split-plane NHWC on the device, and the fp64 values the planes represent (NCHW, CPU)."""
+    t = split_planes(x_nchw.permute(0, 2, 3, 1).contiguous(), cpad).cuda()
+    return t, merge_planes(t.cpu(), 0, x_nchw.shape[1]).double().permute(0, 3, 1, 2)
+
+
+def check(name, got, ref, rtol=RTOL):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    err = (got - ref).abs().max().item()
+    lim = rtol * max(ref.abs().max().item(), 1e-3)
+    print(f"SPLIT_PARITY {name}: max|d| {err:.3e} (limit {lim:.3e}, ref max {ref.abs().max().item():.3e})")
+    assert math.isfinite(err) and err <= lim, report(name, got.float(), ref.float()) + f" limit {lim:.3e}"
+
+
+CASES = [
+    # halo-tile kernel (3x3 / 1x5 / 5x1 over 64-channel-multiple sources), every cout tile width
+    dict(name="halo3x3_c128", cin=[128], cout=128, k=(3, 3), pad=1, act="relu"),
+    dict(name="halo3x3_c64_two_src", cin=[192, 64], cout=64, k=(3, 3), pad=1, act="relu"),
+    dict(name="halo3x3_c126_window", cin=[192, 64], cout=126, k=(3, 3), pad=1, act="relu", window=128),
+    dict(name="halo1x5_c256", cin=[128, 128], cout=256, k=(1, 5), pad=(0, 2), act="sigmoid"),
+    dict(name="halo5x1_c128", cin=[128, 128], cout=128, k=(5, 1), pad=(2, 0), act="tanh"),
+    dict(name="halo3x3_c2_f32out", cin=[256], cout=2, k=(3, 3), pad=1, out_f32=True),
+    dict(name="halo3x3_residual_relu2", cin=[64], cout=64, k=(3, 3), pad=1, act="relu", residual=True, act2="relu"),
+    dict(name="halo3x3_linear_residual", cin=[128], cout=128, k=(3, 3), pad=1, residual=True, act2="relu"),
+    dict(name="halo3x3_preadd", cin=[128], cout=128, k=(3, 3), pad=1, act="tanh", preadd=True),
+    # v2 LDS-DMA kernel: strided 7x7 over the 3-channel image, 96-channel layers, 1x1 over the 324-channel lookup, wide fp32 output
+    dict(name="v2_7x7s2_c3", cin=[3], cout=64, k=(7, 7), stride=2, pad=3, out_f32=True),
+    dict(name="v2_3x3s2_c96", cin=[64], cout=96, k=(3, 3), stride=2, pad=1, act="relu"),
+    dict(name="v2_3x3_c96_residual", cin=[96], cout=96, k=(3, 3), pad=1, act="relu", residual=True, act2="relu"),
+    dict(name="v2_1x1_c324", cin=[324], cout=256, k=(1, 1), pad=0, act="relu"),
+    dict(name="v2_1x1_576_f32out", cin=[256], cout=576, k=(1, 1), pad=0, out_f32=True, out_scale=0.25),
+    dict(name="v2_7x1_c16", cin=[16], cout=128, k=(7, 1), pad=(3, 0), act="relu"),
+    dict(name="v2_1x1_linear_residual_c128", cin=[128], cout=128, k=(1, 1), pad=0, residual=True),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_split_plane_conv(dev, case):
+    from propainter_amd.conv import ConvLayer, pad8
+    g = torch.Generator().manual_seed(11)
+    N, H, W = 2, 37, 45
+    cin, cout, k = case["cin"], case["cout"], case["k"]
+    stride, pad = case.get("stride", 1), case["pad"]
+    srcs, vals = zip(*[planes(torch.randn(N, c, H, W, generator=g) * (1.0 + 3.0 * i), pad8(c)) for i, c in enumerate(cin)])
+    w = torch.randn(cout, sum(cin), *k, generator=g) / math.sqrt(sum(cin) * k[0] * k[1])
+    b = torch.randn(cout, generator=g) * 0.3
+    layer = ConvLayer(w, b, stride=stride, padding=pad, src_channels=cin, dtype=torch.float16, device=dev, split=True)
+    assert layer.kchunks % 8 == 0 and layer.split
+    # the weights the kernel multiplies with: W_hi + W_lo (22 bits of w)
+    w_eff = (w.half().double() + (w - w.half().float()).half().double())
+    ref = F.conv2d(torch.cat(vals, 1), w_eff, b.double(), stride, pad) * case.get("out_scale", 1.0)
+    OH, OW = ref.shape[-2:]
+    kw = dict(act=case.get("act"), act2=case.get("act2"), out_scale=case.get("out_scale", 1.0))
+    if case.get("preadd"):
+        pt, pv = planes(torch.randn(N, cout, OH, OW, generator=g) * 2)
+        kw["preadd"] = pt
+        ref = ref + pv
+    act = {None: lambda v: v, "relu": torch.relu, "sigmoid": torch.sigmoid, "tanh": torch.tanh}[case.get("act")]
+    ref = act(ref)
+    if case.get("residual"):
+        rt, rv = planes(torch.randn(N, cout, OH, OW, generator=g) * 2)
+        kw["residual"] = rt
+        ref = ref + rv
+    if case.get("act2") == "relu":
+        ref = torch.relu(ref)
+    if case.get("out_f32"):
+        out = layer(list(srcs), out_dtype=torch.float32, **kw)
+        torch.cuda.synchronize()
+        assert out.dtype == torch.float32 and out.shape[-1] == pad8(cout)
+        got = out[..., :cout]
+        assert pad8(cout) == cout or (out[..., cout:] == 0).all()
+    elif case.get("window"):
+        Cp = case["window"]
+        buf = torch.full((N, OH, OW, 2 * Cp), 7.0, dtype=torch.float16, device=dev)
+        layer(list(srcs), out=buf, out_choff=0, **kw)
+        torch.cuda.synchronize()
+        assert (buf[..., cout:Cp] == 7).all() and (buf[..., Cp + cout:] == 7).all(), "channels outside the window must stay untouched"
+        got = merge_planes(buf, 0, cout)
+    else:
+        out = layer(list(srcs), **kw)
+        torch.cuda.synchronize()
+        assert out.dtype == torch.float16 and out.shape[-1] == 2 * pad8(cout)
+        got = merge_planes(out, 0, cout)
+    # transcendental epilogues use v_exp / v_rcp forms (1 ulp of fp32 on values <= 1)
+    check(case["name"], got.permute(0, 3, 1, 2), ref, RTOL if case.get("act") not in ("tanh", "sigmoid") else 2 * RTOL)
+
+
+@pytest.mark.parametrize("impl", [0, 12], ids=["halo", "v2"])
+@pytest.mark.parametrize("k,pad", [((1, 5), (0, 2)), ((5, 1), (2, 0))], ids=["1x5", "5x1"])
+def test_split_plane_fused_gru(dev, k, pad, impl):
+    """SepConvGRU half step (RAFT/update.py:45-60) with split-plane state: partial sums as pre-activation addends (both planes
+    through the matrix cores in the halo kernel), z / r*h / (1-z)*h + z*q out of the epilogues as hi + lo planes."""
+    from propainter_amd.conv import ConvLayer
+    g = torch.Generator().manual_seed(55)
+    N, H, W, C = 2, 19, 27, 128
+    (hd, h0), (inpd, inp), (mfd, mf) = (planes(torch.randn(N, C, H, W, generator=g) * 0.7) for _ in range(3))
+    wz, wr, wq = (torch.randn(C, 3 * C, *k, generator=g) / math.sqrt(3 * C * 5) for _ in range(3))
+    bz, br, bq = (torch.randn(C, generator=g) * 0.1 for _ in range(3))
+    eff = lambda w: w.half().double() + (w - w.half().float()).half().double()
+    hx = torch.cat([h0, inp, mf], 1)
+    z = torch.sigmoid(F.conv2d(hx, eff(wz), bz.double(), 1, pad))
+    r = torch.sigmoid(F.conv2d(hx, eff(wr), br.double(), 1, pad))
+    mk = lambda w, b, sc: ConvLayer(w, b, padding=pad, src_channels=sc, dtype=torch.float16, device=dev, split=True)
+    wzr, bzr = torch.cat([wz, wr], 0), torch.cat([bz, br], 0)
+    it = lambda w: torch.cat([w[:, :C], w[:, 2 * C:]], 1)
+    zr_pre, q_pre = mk(wzr[:, C:2 * C], bzr, [C]), mk(wq[:, C:2 * C], bq, [C])
+    zr_it, q_it = mk(it(wzr), None, [C, C]), mk(it(wq), None, [C, C])
+    zr_it.impl = q_it.impl = impl
+    pzr, pq = zr_pre([inpd]), q_pre([inpd])
+    zbuf = torch.empty((N, H, W, 2 * C), dtype=torch.float16, device=dev)
+    rh = torch.empty((N, H, W, 2 * C), dtype=torch.float16, device=dev)
+    net = hd.clone()
+    zr_it([net, mfd], out=zbuf, act="sigmoid", preadd=pzr, fuse=dict(kind="gru_zr", h=net, out2=rh, split=C))
+    torch.cuda.synchronize()
+    check("z", merge_planes(zbuf).permute(0, 3, 1, 2), z, 2 * RTOL)
+    check("r*h", merge_planes(rh).permute(0, 3, 1, 2), r * h0, 2 * RTOL)
+    # the q convolution sees the r*h the device produced (22-bit planes): use those values for the reference
+    rh_val = merge_planes(rh.cpu()).double().permute(0, 3, 1, 2)
+    z_val = merge_planes(zbuf.cpu()).double().permute(0, 3, 1, 2)
+    qv = torch.tanh(F.conv2d(torch.cat([rh_val, inp, mf], 1), eff(wq), bq.double(), 1, pad))
+    q_it([rh, mfd], out=net, act="tanh", preadd=pq, fuse=dict(kind="gru_h", h=net, z=zbuf))
+    torch.cuda.synchronize()
+    check("h_new", merge_planes(net).permute(0, 3, 1, 2), (1 - z_val) * h0 + z_val * qv, 2 * RTOL)
+
+
+def test_split_plane_batched_gemm(dev):
+    """All-pairs correlation volume (RAFT/corr.py:52-60) from split-plane feature maps."""
+    from propainter_amd.conv import batched_gemm_nt_split
+    g = torch.Generator().manual_seed(3)
+    B, M, K = 3, 23 * 31, 256
+    a = split_planes(torch.randn(B, M, K, generator=g) * 3).cuda()
+    b = split_planes(torch.randn(B, M, K, generator=g) * 3).cuda()
+    out = batched_gemm_nt_split(a, b, out_scale=1.0 / 16.0)
+    torch.cuda.synchronize()
+    av, bv = merge_planes(a.cpu()).double(), merge_planes(b.cpu()).double()
+    check("volume", out, torch.matmul(av, bv.transpose(1, 2)) / 16.0)
+
+
+def test_split_plane_aux_ops(dev):
+    """Split-plane outputs of the correlation lookup, the flow-tap gather, the NCHW packer and the fused InstanceNorm tail
+    against their fp32 forms / torch."""
+    from propainter_amd import hip
+    g = torch.Generator().manual_seed(9)
+    P, h, w = 2, 16, 24
+    # ---- correlation lookup: split output == fp32 output to 2^-22
+    f1, f2 = torch.randn(P, h * w, 256, generator=g), torch.randn(P, h * w, 256, generator=g)
+    vol = (torch.matmul(f1, f2.transpose(1, 2)) / 16.0).cuda()
+    levels = [vol.view(P * h * w, h, w)]
+    hh, ww = h, w
+    for _ in range(3):
+        levels.append(hip.corr_avgpool(levels[-1], P * h * w, hh, ww))
+        hh, ww = hh // 2, ww // 2
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+    coords = (torch.stack([xs, ys], -1)[None] + torch.randn(P, h, w, 2, generator=g) * 3).contiguous().cuda()
+    ref32 = hip.corr_lookup(levels, coords, torch.empty((P, h, w, 328), dtype=torch.float32, device=dev))
+    sp = hip.corr_lookup(levels, coords, torch.full((P, h, w, 656), 9.0, dtype=torch.float16, device=dev), split=True)
+    torch.cuda.synchronize()
+    check("corr_lookup", merge_planes(sp, 0, 324), ref32[..., :324], 1e-6)
+    assert (sp[..., 324:328] == 0).all() and (sp[..., 328 + 324:] == 0).all()
+    # ---- flow taps
+    c0 = torch.stack([xs, ys], -1)[None].expand(P, h, w, 2).contiguous().cuda()
+    rows32 = hip.raft_flow_taps(coords, c0, torch.empty((P, h, w, 16), dtype=torch.float32, device=dev))
+    xbuf = torch.full((P, h, w, 256), 5.0, dtype=torch.float16, device=dev)
+    rows = hip.raft_flow_taps(coords, c0, torch.empty((P, h, w, 32), dtype=torch.float16, device=dev), flow_out=xbuf, flow_choff=126, split=True)
+    torch.cuda.synchronize()
+    check("flow_taps", merge_planes(rows), rows32, 1e-6)
+    check("flow_window", merge_planes(xbuf, 126, 2), (coords - c0), 1e-6)
+    assert (xbuf[..., :126] == 5).all() and (xbuf[..., 128:254] == 5).all()
+    # ---- NCHW packer
+    img = torch.rand(3, 3, 40, 56, generator=g) * 2 - 1
+    x = hip.nchw_to_nhwc(img.cuda(), cpad=8, split=True)
+    torch.cuda.synchronize()
+    assert x.shape == (3, 40, 56, 16) and (x[..., 3:8] == 0).all() and (x[..., 11:] == 0).all()
+    check("nchw_to_nhwc", merge_planes(x, 0, 3).permute(0, 3, 1, 2), img, 1e-6)
+    # ---- InstanceNorm + residual tail
+    v = torch.randn(2, 33, 47, 64, generator=g) * 2 + 0.5
+    res_t, res_v = planes(torch.randn(2, 64, 33, 47, generator=g))
+    y = hip.instance_norm_split(v.cuda(), relu=True, residual=res_t, relu2=True)
+    y0 = hip.instance_norm_split(v.cuda(), relu=False)
+    torch.cuda.synchronize()
+    inorm = F.instance_norm(v.double().permute(0, 3, 1, 2), eps=1e-5)
+    check("instance_norm_split", merge_planes(y0).permute(0, 3, 1, 2), inorm, 2e-6)
+    check("instance_norm_split + residual", merge_planes(y).permute(0, 3, 1, 2), torch.relu(torch.relu(inorm) + res_v), 2e-6)
+
+
+def test_split_plane_raft_matches_reference_golden():
+    """RAFT_bi(precision="f16x3") end to end against the REAL reference's golden flows (tests/golden/raft_128x192.npz,
+    oracle/make_golden.py): fp32-class end-point error."""
+    from tests.helpers import load_golden, seeded_models
+    raft = seeded_models("cuda")[0]
+    g = load_golden("raft_128x192.npz")
+    fr = torch.from_numpy(g["frames_u8"]).permute(0, 3, 1, 2).float().div(255)[None] * 2 - 1
+    raft.precision = "f16x3"
+    ff, fb = raft(fr.cuda(), iters=int(g["iters"]))
+    ff2, fb2 = raft(fr.cuda(), iters=int(g["iters"]), streams=2)
+    torch.cuda.synchronize()
+    assert torch.equal(ff, ff2) and torch.equal(fb, fb2), "pair groups on two streams must give identical flows"
+    ef = (ff[0].cpu() - torch.from_numpy(g["flows_f"])).pow(2).sum(1).sqrt()
+    eb = (fb[0].cpu() - torch.from_numpy(g["flows_b"])).pow(2).sum(1).sqrt()
+    print(f"SPLIT_PARITY raft golden EPE: fw mean {ef.mean():.2e} max {ef.max():.2e}, bw mean {eb.mean():.2e} max {eb.max():.2e}")
+    assert ef.mean() < 5e-5 and ef.max() < 2e-3 and eb.mean() < 5e-5 and eb.max() < 2e-3
