@@ -411,17 +411,24 @@ def main():
             v["gbs"] = v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0.0
         dom = max(kernels.items(), key=lambda kv: kv[1]["ms"])
         name, v = dom
-        traffic, traffic_src = pmc_traffic(name)
-        common = {"kernel": name, "traffic": traffic,
-                  "traffic_source": (f"committed rocprofv3 --pmc profile {traffic_src} (not collected in this run)" if traffic_src else None),
+        traffic, traffic_src = pmc_traffic(name, args.raft_dtype)
+        common = {"kernel": name, "traffic": traffic, "traffic_source": traffic_src,
                   "launches": v["launches"], "avg_launch_us": v["avg_us"],
                   "timed_with": "HIP events around every launch of one eager pass, generator windows serialised (window_streams=1)",
                   "algorithmic_bytes_per_launch": v["bytes"] / max(1, v["launches"]),
                   "share_of_kernel_time": v["ms"] / sum(x["ms"] for x in kernels.values())}
         if name.startswith("conv_gemm") or name == "sparse_window_attention":
-            peak = PEAK_TFLOPS["f32" if name.endswith("f32") else "f16"]
+            peak = PEAK_TFLOPS["f32" if name.endswith("f32") else "f16x3" if name.endswith("f16x3") else "f16"]
             roof = dict(common, bound="mfma", achieved=v["tflops"], peak=peak, unit="TFLOP/s", frac=v["tflops"] / peak,
                         algorithmic_flop_per_launch=v["flops"] / max(1, v["launches"]))
+            if name.endswith("f16x3"):
+                roof["note"] = ("split-plane (fp32-class) convolutions of RAFT: `achieved` counts the ALGORITHMIC FLOPs of the fp32 layers; "
+                                "each product executes as three fp16 MFMA products, so `peak` = dense fp16 MFMA peak / 3 "
+                                f"(executed: {3 * v['tflops']:.0f} TFLOP/s of {PEAK_TFLOPS['f16']:.0f})")
+            # every matrix-core class of the pass next to the dominant one
+            roof["other_mfma_classes"] = {k: {"achieved": kv["tflops"], "frac": kv["tflops"] / PEAK_TFLOPS["f32" if k.endswith("f32") else "f16x3" if k.endswith("f16x3") else "f16"],
+                                              "launches": kv["launches"], "ms": kv["ms"]}
+                                          for k, kv in kernels.items() if k != name and (k.startswith("conv_gemm") or k == "sparse_window_attention") and kv["flops"] > 0}
         else:
             roof = dict(common, bound="hbm", achieved=v["gbs"], peak=PEAK_HBM_GBS, unit="GB/s", frac=v["gbs"] / PEAK_HBM_GBS)
         stages["instrumented_step_wall_ms"] = prof_wall * 1e3
@@ -436,7 +443,7 @@ def main():
         had_graph = graph is not None
         graph = None                      # releases the headline graph's private pool before the other engines are built
         torch.cuda.empty_cache()
-        for prec in ("f16x3", "f32"):
+        for prec in ("f16x3", "f16", "f32"):
             if prec == args.raft_dtype:
                 continue
             raft.precision = prec
@@ -475,7 +482,7 @@ def main():
     if cpu_job is not None:
         sclip, smasks = sample_clip(args)
         got = {}
-        for prec in ([args.raft_dtype] + ([p for p in ("f16x3", "f32") if p != args.raft_dtype] if raft_precisions else [])):
+        for prec in ([args.raft_dtype] + ([p for p in ("f16x3", "f16", "f32") if p != args.raft_dtype] if raft_precisions else [])):
             raft.precision = prec
             try:
                 got[prec] = run_clip(models, sclip, smasks, smasks, cfg, dev).cpu().numpy()
@@ -486,10 +493,11 @@ def main():
         torch.cuda.synchronize()
         cpu, ref_frames = cpu_job.collect()
         if ref_frames is not None:
-            desc = {"clip": f"{len(sclip)}-frame {SAMPLE_W}x{SAMPLE_H} synthetic clip of the cpu_baseline sample, seeded weights",
-                    "reference": "CPU oracle fp32 (oracle/propainter_oracle.py)", "stages_dtype": "f16" if fp16 else "f32"}
+            desc = {"clip": f"{len(sclip)}-frame {W}x{H} synthetic clip of the cpu_baseline sample (the TIMED resolution), seeded weights",
+                    "reference": "CPU oracle fp32 (oracle/propainter_oracle.py)", "stages_dtype": "f16" if fp16 else "f32",
+                    "ground_truth": "the unmasked synthetic frames (PSNR per frame, averaged: core/metrics.py:20-36, scripts/evaluate_propainter.py)"}
             for prec, g in got.items():
-                rec = parity_of(g, ref_frames, smasks) if not isinstance(g, str) else {"error": g}
+                rec = parity_of(g, ref_frames, smasks, gt_u8=sclip) if not isinstance(g, str) else {"error": g}
                 if prec == args.raft_dtype:
                     parity = dict(desc, raft_dtype=prec, dtype="f16" if fp16 else "f32", **rec)
                 if raft_precisions and prec in raft_precisions:
@@ -509,7 +517,10 @@ def main():
             "metric": "inpainted frames/sec (whole path, 80-frame window)", "value": fps, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
-            "dtype": "f16" if fp16 else "f32",
+            # arithmetic of the timed pass: stages B-D / RAFT (the reference's --fp16 run: fp16 stages, fp32 RAFT -- inference_propainter.py:311,333-337)
+            "dtype": ("f16" if fp16 else "f32") + " stages + " + {"f16x3": "f16x3 RAFT (fp32-class: 3 fp16 MFMA products per product, fp32 accumulate)",
+                                                                  "f32": "f32 RAFT", "f16": "f16 RAFT (narrower than the reference's fp32 RAFT)"}[args.raft_dtype],
+            "value_raft_f16": (raft_precisions or {}).get("f16", {}).get("value") if args.raft_dtype != "f16" else fps,
             "data": "synthetic (seeded clip + rectangular mask dilated x4, seeded weights of the reference architecture)",
             "config": {"workload": work, "height": H, "width": W, "frames": L, "windows": len(sched),
                        "raft_dtype": args.raft_dtype, "stages_dtype": "f16" if fp16 else "f32", "parallelism": par,
