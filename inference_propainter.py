@@ -138,11 +138,16 @@ def main(argv=None):
     comp = None
     if world > 1:
         from propainter_amd.sharding import can_shard, gather_frames, run_clip_sharded
+        if args.save_flow or args.load_flow:
+            raise SystemExit('--save_flow / --load_flow describe ONE unsharded clip: run them without torch.distributed.run '
+                             '(under sharding every rank computes the RAFT flows of its own sub-videos)')
         if can_shard(L, cfg, world):
             lo, part = run_clip_sharded(models, frames_u8, flow_masks, masks_dilated, cfg, device)
             comp = gather_frames(lo, part, L, dst=0)
-        elif rank == 0:      # a single sub-video: nothing to shard, rank 0 runs the unsharded pass, the others idle
-            print(f'{L} frames are a single sub-video at --subvideo_length {cfg.subvideo_length}: running on one GPU')
+        elif rank == 0:      # nothing to shard: rank 0 runs the unsharded pass, the others idle
+            why = (f'--subvideo_length {cfg.subvideo_length} > 100 (image propagation then runs in chunks of 100: inference_propainter.py:373 of the reference)'
+                   if cfg.subvideo_length > 100 else f'{L} frames are a single sub-video at --subvideo_length {cfg.subvideo_length}')
+            print(f'not sharding over {world} GPUs: {why}; running on one GPU')
             comp = run_clip(models, frames_u8, flow_masks, masks_dilated, cfg, device)
     else:
         from propainter_amd import flow_io
@@ -165,6 +170,7 @@ def main(argv=None):
         print(f'\nAll results are saved in {save_root}')
     if world > 1:
         import torch.distributed as dist
+        dist.barrier()           # idle ranks wait for the working ones before the group is torn down
         dist.destroy_process_group()
 
 

@@ -231,7 +231,7 @@ extern "C" int pp_deform_conv2d(const void* x, const void* offset, const void* m
 // ------------------------------------------------------------------------------------------------------------------
 extern "C" int64_t pp_corr_pyramid_workspace_size(int B, int h, int w, int dtype) {
   if (B <= 0 || h < 16 || w < 16 || (dtype != PP_F32 && dtype != PP_F16)) return PP_ERR_ARG;
-  return 2 * align256((int64_t)B * h * w * 256 * esize(dtype)) + align256(17 * 16) + 256;
+  return 2 * align256((int64_t)B * h * w * 256 * esize(dtype)) + align256(33 * 16) + 256;      // (K table: 32 chunks + the zero page)
 }
 
 extern "C" int pp_corr_pyramid(const void* fmap1, const void* fmap2, float* lvl0, float* lvl1, float* lvl2, float* lvl3, int B, int h,
@@ -245,7 +245,7 @@ extern "C" int pp_corr_pyramid(const void* fmap1, const void* fmap2, float* lvl0
   const int64_t n8 = (int64_t)h * w;
   void* a_ = ws.take(B * n8 * 256 * esize(dtype));
   void* b_ = ws.take(B * n8 * 256 * esize(dtype));
-  void* d_kt = ws.take(17 * 16);
+  void* d_kt = ws.take(33 * 16);
   RL_CHECK(pp_nchw_to_nhwc(fmap1, dtype, a_, dtype, 256, 0, B, 256, h, w, 1.f, stream));
   RL_CHECK(pp_nchw_to_nhwc(fmap2, dtype, b_, dtype, 256, 0, B, 256, h, w, 1.f, stream));
   int32_t kt[33 * 4], zero = 0, c256 = 256;

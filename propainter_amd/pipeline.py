@@ -158,7 +158,11 @@ class Compositor:
             self.done[idx] = True
 
 
-_index_cache = {}
+import collections
+
+_index_cache = collections.OrderedDict()      # LRU: (ids, device) -> int64 index tensor
+_INDEX_CACHE_MAX = 4096
+_index_recorder = None                        # list collecting every index tensor handed out while a ClipGraph is being built
 
 
 def _window_streams(device, n):
@@ -173,12 +177,19 @@ def _dev_index(ids, device):
     key = (tuple(ids), str(device))
     t = _index_cache.get(key)
     if t is None:
-        if len(_index_cache) > 4096:          # a long-running server sees many clip lengths: keep the cache bounded
-            _index_cache.clear()
         if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
             raise RuntimeError("window index tensors must be created by an eager pass before graph capture")
         t = torch.tensor(list(ids), dtype=torch.long, device=device)
         _index_cache[key] = t
+        # a long-running server sees many clip lengths: least-recently-used entries leave the cache one at a time.  A captured
+        # hipGraph has the device pointers of the tensors it used baked in, so every ClipGraph keeps its own references
+        # (`_index_recorder`): eviction only drops the cache's reference, the memory a graph replays from is never freed
+        while len(_index_cache) > _INDEX_CACHE_MAX:
+            _index_cache.popitem(last=False)
+    else:
+        _index_cache.move_to_end(key)
+    if _index_recorder is not None:
+        _index_recorder.append(t)
     return t
 
 
@@ -281,6 +292,15 @@ class ClipGraph:
         if example is not None:
             self._load(*example)
         run = lambda: run_clip(models, self.frames, self.flow_masks, self.masks_dilated, cfg, device)
+        global _index_recorder
+        self._pinned = []                        # every cached index tensor the pass reads: the graph owns a reference (see _dev_index)
+        prev, _index_recorder = _index_recorder, self._pinned
+        try:
+            self._build(run, device, release_eager_pool)
+        finally:
+            _index_recorder = prev
+
+    def _build(self, run, device, release_eager_pool):
         side = torch.cuda.Stream(device=device)
         side.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(side):            # eager pass: builds engines, window tables, index tensors

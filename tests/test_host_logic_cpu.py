@@ -249,3 +249,23 @@ def test_fork_join_is_sequential_without_a_gpu():
     import torch
     out = hip.fork_join("cpu", [lambda: torch.ones(2), lambda: (torch.zeros(1), torch.ones(1))], 2)
     assert torch.equal(out[0], torch.ones(2)) and isinstance(out[1], tuple)
+
+
+def test_window_index_cache_is_lru_and_graphs_keep_their_tensors(monkeypatch):
+    """pipeline._dev_index: least-recently-used eviction one entry at a time (never a wholesale clear), and every tensor handed out
+    while a ClipGraph is being built is also referenced by that graph -- a captured hipGraph replays from those device pointers."""
+    from propainter_amd import pipeline as P
+    monkeypatch.setattr(P, "_INDEX_CACHE_MAX", 3)
+    monkeypatch.setattr(P, "_index_cache", type(P._index_cache)())
+    pinned = []
+    monkeypatch.setattr(P, "_index_recorder", pinned)
+    a = P._dev_index([0, 1, 2], "cpu")
+    b = P._dev_index([3, 4], "cpu")
+    assert P._dev_index([0, 1, 2], "cpu") is a            # hit: refreshed, handed out again
+    monkeypatch.setattr(P, "_index_recorder", None)
+    c = P._dev_index([5], "cpu")
+    d = P._dev_index([6], "cpu")                          # evicts the least recently used entry: [3, 4]
+    keys = [k[0] for k in P._index_cache]
+    assert (3, 4) not in keys and (0, 1, 2) in keys and len(keys) == 3
+    assert pinned[0] is a and pinned[1] is b and pinned[2] is a and b.tolist() == [3, 4]      # the graph's references survive eviction
+    assert P._dev_index([3, 4], "cpu") is not b          # re-created on demand for later eager passes

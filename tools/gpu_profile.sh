@@ -16,6 +16,7 @@ if [ -z "$SKIP_PMC" ]; then
 fi
 cd $R
 python tools/rocprof_summary.py stats gpurun_out/prof_trace gpurun_out/${TAG}_rocprof_kernel_stats_720p.md | head -60
-[ -z "$SKIP_PMC" ] && python tools/rocprof_summary.py traffic gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/${TAG}_hbm_traffic_720p.json | head -40
+# (the snapshot on the GPU box has no .git: the caller passes the commit it pushed as COMMIT / COMMIT_TIME)
+[ -z "$SKIP_PMC" ] && python tools/rocprof_summary.py traffic gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/${TAG}_hbm_traffic_720p.json "${COMMIT:-unknown}" "${COMMIT_TIME:-0}" "${RAFT_DTYPE:-f16x3}" | head -40
 find gpurun_out/prof_trace gpurun_out/pmc_fetch gpurun_out/pmc_write -name "*.csv" -size +8M -delete 2>/dev/null
 du -sh gpurun_out

@@ -18,6 +18,7 @@ import json
 import re
 import sys
 
+SPLIT_FAMILY = "conv_gemm_f16x3 (split-plane LDS-DMA implicit GEMM)"
 FAMILIES = [   # (substring of the demangled OR mangled kernel name, family)
     ("conv_halo_kernel", "conv_gemm_f16 (LDS-DMA implicit GEMM)"),
     ("conv_ast_kernel", "conv_gemm_f16 (LDS-DMA implicit GEMM)"),
@@ -52,6 +53,9 @@ FAMILIES = [   # (substring of the demangled OR mangled kernel name, family)
 
 
 def family(name):
+    # split-plane ("f16x3") instantiations: the LAST template argument (SPLIT) of conv_halo_kernel / conv_gemm_v2_kernel is true
+    if ("conv_halo_kernel" in name or "conv_gemm_v2_kernel" in name) and (re.search(r", true>\(", name + "(") or "Lb1EEEv" in name):
+        return SPLIT_FAMILY
     for pat, fam in FAMILIES:
         if pat in name:
             return fam
@@ -115,8 +119,12 @@ def cmd_traffic(fetch_dir, write_dir, out):
         res[fam] = {"launches": n, "fetch_kb_raw_per_launch": f / max(nf, 1), "write_kb_raw_per_launch": w / max(nw, 1),
                     # gfx950 correction: FETCH_SIZE tallies 128-B requests at 64 B -> x2 for wide streaming reads
                     "hbm_bytes_per_launch": (2.0 * f / max(nf, 1) + w / max(nw, 1)) * 1024.0}
+    meta = {}
+    if len(sys.argv) > 5:         # commit the passes were measured at, its time, RAFT precision of the profiled command
+        meta = {"commit": sys.argv[5], "commit_time": int(sys.argv[6]) if len(sys.argv) > 6 and sys.argv[6].isdigit() else 0,
+                "raft_dtype": sys.argv[7] if len(sys.argv) > 7 else "f16x3"}
     json.dump({"note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B); WRITE_SIZE as reported; "
-                       "both in KiB; separate --pmc passes", "families": res}, open(out, "w"), indent=1)
+                       "both in KiB; separate --pmc passes", **meta, "families": res}, open(out, "w"), indent=1)
     for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"]):
         print(f"{k:46s} n={v['launches']:6d}  HBM bytes/launch = {v['hbm_bytes_per_launch'] / 1e6:10.2f} MB")
 
@@ -139,8 +147,54 @@ def cmd_counters(root, out, names):
             print(f"{k:92s} " + " ".join(f"{n}={v.get(n, 0):.3e}" for n in names) + f"  {names[0]}/{names[-1]}={ratio:.3f}")
 
 
+def cmd_mfma(root, out, commit=""):
+    """--pmc SQ_VALU_MFMA_BUSY_CYCLES ... GRBM_GUI_ACTIVE pass taken WITH --kernel-trace: per kernel family the matrix-pipe
+    utilisation (busy cycles / (duration x clock x 1024 SIMDs)) at the nominal 2.4 GHz and at the effective clock
+    (GRBM_GUI_ACTIVE / duration; the counter is summed over the 8 XCDs)."""
+    NSIMD, NOMINAL_HZ, NXCD = 256 * 4, 2.4e9, 8
+    dur = {}
+    for f in glob.glob(root + "/**/*kernel_trace.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            dur[r["Dispatch_Id"]] = (r.get("Kernel_Name", "?"), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9)
+    fam = collections.defaultdict(lambda: collections.defaultdict(float))
+    seen = collections.defaultdict(set)
+    for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            fm = family(r.get("Kernel_Name", "?"))
+            fam[fm][r["Counter_Name"]] += float(r["Counter_Value"])
+            did = r.get("Dispatch_Id")
+            if did not in seen[fm]:
+                seen[fm].add(did)
+                fam[fm]["launches"] += 1
+                fam[fm]["seconds"] += dur.get(did, ("?", 0.0))[1]
+    res = {}
+    for k, v in fam.items():
+        s = v["seconds"]
+        if s <= 0:
+            continue
+        gui = v.get("GRBM_GUI_ACTIVE", 0.0)
+        clk = gui / NXCD / s if gui else None
+        busy = v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
+        res[k] = {"launches": int(v["launches"]), "ms": s * 1e3, "mfma_busy_cycles": busy,
+                  "mfma_ops_f16": v.get("SQ_INSTS_VALU_MFMA_MOPS_F16", 0.0), "grbm_gui_active": gui,
+                  "effective_clock_ghz_if_gui_counts_per_xcd": None if clk is None else clk / 1e9,
+                  "effective_clock_ghz_if_gui_counts_once": None if not gui else gui / s / 1e9,
+                  "mfma_util_at_nominal_2p4ghz": busy / (s * NOMINAL_HZ * NSIMD),
+                  "sq_busy_cycles": v.get("SQ_BUSY_CYCLES", 0.0), "sq_wave_cycles": v.get("SQ_WAVE_CYCLES", 0.0)}
+    json.dump({"commit": commit, "note": "one rocprofv3 --pmc pass with --kernel-trace over bench.py --single-pass (profiled passes run ~3 % slower "
+                                         "than un-profiled ones); mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (kernel seconds x 2.4 GHz x 1024 SIMDs): a "
+                                         "16x16x32 fp16 MFMA occupies its pipe 16 cycles, which IS the dense peak rate, so the ratio is the fraction "
+                                         "of the 2.5 PFLOP/s peak the matrix pipes were busy", "families": res}, open(out, "w"), indent=1)
+    print(f"{'family':58s} {'n':>6s} {'ms':>9s} {'MFMA util @2.4GHz':>18s} {'GUI/s/8 GHz':>12s} {'GUI/s GHz':>10s}")
+    for k, v in sorted(res.items(), key=lambda kv: -kv[1]["ms"]):
+        a, b = v["effective_clock_ghz_if_gui_counts_per_xcd"], v["effective_clock_ghz_if_gui_counts_once"]
+        print(f"{k:58s} {v['launches']:6d} {v['ms']:9.2f} {v['mfma_util_at_nominal_2p4ghz']:18.3f} {a if a is None else round(a, 3)!s:>12s} {b if b is None else round(b, 3)!s:>10s}")
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "counters":
+    if sys.argv[1] == "mfma":
+        cmd_mfma(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else "")
+    elif sys.argv[1] == "counters":
         cmd_counters(sys.argv[2], sys.argv[3], sys.argv[4].split(","))
     elif sys.argv[1] == "stats":
         cmd_stats(sys.argv[2], sys.argv[3])
