@@ -149,7 +149,12 @@ typedef struct {
    *     fp32 accumulation (the dropped lo*lo term is < 2^-22 relative);
    *   - every fp16 operand of the EPILOGUE (out when out_dtype == PP_F16, out2, preadd, residual, fuse_a, fuse_b) is split-plane with
    *     the lo offsets below (multiples of 8 elements); out_dtype == PP_F32 writes plain fp32;
-   *   - PP_FUSE_DCN_OFFMASK, groups > 1 and the deformable mode are not available.                                                */
+   *   - PP_FUSE_DCN_OFFMASK, groups > 1 and the deformable mode are not available.
+   * split = 2: TRI-PRODUCT K format for the halo-tile kernel (tap_h x tap_w in {3x3, 1x5, 5x1}, stride 1, "same" padding, sources
+   *   multiples of 32 channels): a K block is 32 channels of BOTH planes of one source -- per tap 8 table chunks, 4 of the hi plane then
+   *   the same 4 channel chunks of the lo plane (choff + lo offset) -- and the packed weight row holds [32 ch W_hi | 32 ch W_lo] per tap
+   *   in that order; the kernel issues W_hi x A_hi + W_hi x A_lo + W_lo x A_hi per tap step (a third fewer LDS reads, weight-tile
+   *   fetches and barriers per product than split = 1).  Epilogue operands as for split = 1.                                       */
   int32_t split;
   int32_t out_lo, out2_lo, preadd_lo, res_lo, fuse_a_lo, fuse_b_lo;
   int32_t pad2_;

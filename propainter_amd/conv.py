@@ -66,6 +66,24 @@ def split_ktable(ktable, src_lo):
     return np.ascontiguousarray(np.concatenate([out, tail], 0).astype(np.int32))
 
 
+def tri_ktable(taps, src_cpad, src_lo):
+    """K table of the TRI-PRODUCT split-plane format (halo-tile kernel, csrc/conv_halo.h SPLIT): one block = 32 channels of BOTH
+    planes of one source; per tap 8 chunks -- 4 of the hi plane, then the same 4 channel chunks of the lo plane (flags PLANE_LO |
+    WEIGHT_LO: the packed weight row holds [32 ch W_hi | 32 ch W_lo] per tap).  The kernel multiplies the four fragment sets of a
+    tap step as W_hi x A_hi + W_hi x A_lo + W_lo x A_hi, so -- unlike split_ktable's -- this table is NOT a plain K walk: only the
+    halo-tile kernel (and the CPU emulation's matching branch) may consume it.  Returns int32 [chunks + 1, 4]."""
+    rows = []
+    for s, (c, lo) in enumerate(zip(src_cpad, src_lo)):
+        assert c % 32 == 0 and lo % 8 == 0 and lo >= c
+        for cb in range(0, c, 32):
+            for t, (dy, dx) in enumerate(taps):
+                for plane in (0, 1):
+                    for j in range(4):
+                        rows.append([dy, dx, s | (t << 16) | ((KT_PLANE_LO | KT_WEIGHT_LO) if plane else 0), cb + 8 * j + (lo if plane else 0)])
+    rows.append([0, 0, 0, 0])
+    return np.ascontiguousarray(np.asarray(rows, dtype=np.int32))
+
+
 def pack_weight(weight, src_channels, groups=1, ktable=None, src_lo=None):
     """weight [Cout, Cin_g, kh, kw] (any float dtype, CPU or GPU) -> (packed fp32 [groups, cout_pad, K], K, cout_g).
 
@@ -120,7 +138,7 @@ class ConvLayer:
     """One convolution / linear layer prepared for pp_conv2d (weights packed once, on the device)."""
 
     def __init__(self, weight, bias, *, stride=1, padding=0, dilation=1, groups=1, src_channels=None,
-                 pad_mode="zeros", dtype=torch.float16, device="cuda", taps=None, dcn_groups=0, split3=False, split=False, src_lo=None):
+                 pad_mode="zeros", dtype=torch.float16, device="cuda", taps=None, dcn_groups=0, split3=False, split=False, src_lo=None, tri=None):
         if weight.dim() == 2:                       # nn.Linear
             weight = weight[:, :, None, None]
         cout, cin_g, kh, kw = weight.shape
@@ -139,12 +157,21 @@ class ConvLayer:
         # split=True: split-plane ("f16x3") layer -- fp16 kernels, every source / epilogue operand a pair of fp16 planes
         # (hi, lo) of one buffer, lo plane src_lo[i] channels after the hi plane (default: a dedicated buffer [.., 2 * cpad])
         self.split = bool(split)
+        self.tri = False
         if self.split:
             if dtype != torch.float16 or dcn_groups or groups != 1:
                 raise ValueError("split-plane layers are plain fp16 convolutions (groups == 1)")
             self.src_lo = [int(v) for v in (src_lo if src_lo is not None else self.src_cpad)]
             assert len(self.src_lo) == len(self.src_cpad) and all(l >= c and l % 8 == 0 for l, c in zip(self.src_lo, self.src_cpad))
-            kt = split_ktable(kt, self.src_lo)
+            # tri-product format (halo-tile kernel: 48 MFMAs per 16 fragment reads) for the stride-1 "same" 3x3 / 1x5 / 5x1 layers
+            # over 32-channel-multiple sources; every other layer walks its blocks three times through the LDS-DMA (v2) kernel
+            pad_same = self.padding == ((kh - 1) // 2, (kw - 1) // 2) and self.stride == (1, 1)
+            self.tri = (self.tap_hw in ((3, 3), (1, 5), (5, 1)) and pad_same and all(c % 32 == 0 for c in self.src_cpad) and
+                        not (16 < cout < 48) and self.pad_mode == 0)
+            if tri is not None:      # (tests: tri=False walks a halo-eligible layer through the v2 kernel's plain format)
+                assert self.tri or not tri, "layer outside the halo-tile family"
+                self.tri = bool(tri)
+            kt = tri_ktable(taps, self.src_cpad, self.src_lo) if self.tri else split_ktable(kt, self.src_lo)
         packed, K, cout_g = pack_weight(weight, self.src_channels, groups, ktable=kt,     # K order = the table's order
                                         src_lo=self.src_lo if self.split else None)
         self.cout_g, self.cout = cout_g, cout
@@ -158,6 +185,8 @@ class ConvLayer:
         self.dcn = dcn_groups > 0
         # K steps of 4 / 8 chunks are (tap, source)-uniform when every source is a multiple of 32 / 64 channels
         self.ktable_uniform = (4 if all(c % 32 == 0 for c in self.src_cpad) else 0) | (8 if all(c % 64 == 0 for c in self.src_cpad) else 0)
+        if self.split and self.tri:
+            self.ktable_uniform = 8      # every run of 8 chunks is one (tap, source) [4 hi + 4 lo chunks]: what the halo kernel needs
         self.impl = 0            # pp_conv_args_t.impl: 0 auto, 1 register-staged kernel, >= 10 a specific LDS-DMA tile
         # fp32 tensors, products on the fp16 matrix cores as hi*hi + hi*lo + lo*hi (fp32 accumulate): ~2^-21 per
         # product instead of fp32's 2^-24, 5x the rate of the exact fp32 MFMA (pp_conv_args_t.impl 3)
@@ -223,7 +252,7 @@ class ConvLayer:
             a.dcn_offmask, a.dcn_cstride, a.dcn_mask_off = dcn_offmask.data_ptr(), dcn_offmask.shape[-1], 288
         win = lambda x: (x, 0) if torch.is_tensor(x) else x
         if self.split:      # every fp16 operand of the epilogue is split-plane: lo plane half a pixel row after the hi plane
-            a.split = 1
+            a.split = 2 if self.tri else 1
             a.out_lo = out.shape[-1] // 2 if split_out else 0
             a.res_lo = residual.shape[-1] // 2 if residual is not None else 0
             assert fuse is None or fuse["kind"] != "dcn_om"
@@ -263,7 +292,7 @@ class ConvLayer:
         a.ktable_uniform = self.ktable_uniform
         a.tap_h, a.tap_w = self.tap_hw
         self._keep = (srcs, out, residual, dcn_offmask, preadd, fuse)
-        hip.conv2d_raw(a, cin_read=sum(self.src_cpad) * self.groups, on=x0, split_k=self.split)
+        hip.conv2d_raw(a, cin_read=sum(self.src_cpad) * self.groups, on=x0, split_k=(2 if self.tri else 3) if self.split else 0)
         return out
 
 
@@ -306,7 +335,7 @@ def batched_gemm_nt_split(a, b, out_scale=1.0):
     g.ktable_uniform = 12
     g.out, g.out_cstride, g.out_choff, g.out_cgroup = out.data_ptr(), Nn, 0, 0
     g.src_gstride, g.out_gstride = M * K2, M * Nn
-    hip.conv2d_raw(g, cin_read=K * B, on=a, split_k=True)
+    hip.conv2d_raw(g, cin_read=K * B, on=a, split_k=3)
     del bt
     return out
 

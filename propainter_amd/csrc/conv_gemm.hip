@@ -560,8 +560,8 @@ extern "C" int pp_conv2d(const pp_conv_args_t* a, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (a->split) {
     // split-plane ("f16x3") layer: the LDS-DMA kernels with the split epilogue only -- there is no register-staged fallback
-    PP_REQUIRE(a->split == 1 && a->dtype == PP_F16 && !deform && a->groups == 1 && a->fuse != PP_FUSE_DCN_OFFMASK, PP_ERR_ARG,
-               "pp_conv2d: split-plane layers need dtype PP_F16, groups == 1, no deformable sampling, no PP_FUSE_DCN_OFFMASK");
+    PP_REQUIRE((a->split == 1 || a->split == 2) && a->dtype == PP_F16 && !deform && a->groups == 1 && a->fuse != PP_FUSE_DCN_OFFMASK, PP_ERR_ARG,
+               "pp_conv2d: split-plane layers (split 1 / 2) need dtype PP_F16, groups == 1, no deformable sampling, no PP_FUSE_DCN_OFFMASK");
     PP_REQUIRE(((a->out_lo | a->out2_lo | a->preadd_lo | a->res_lo | a->fuse_a_lo | a->fuse_b_lo) & 7) == 0 && a->out_lo >= 0 &&
                    a->out2_lo >= 0 && a->preadd_lo >= 0 && a->res_lo >= 0 && a->fuse_a_lo >= 0 && a->fuse_b_lo >= 0,
                PP_ERR_ALIGN, "pp_conv2d: split-plane lo offsets must be non-negative multiples of 8 elements");
@@ -572,10 +572,12 @@ extern "C" int pp_conv2d(const pp_conv_args_t* a, void* stream) {
     PP_REQUIRE((a->preadd == nullptr || a->preadd_lo > 0) && (a->fuse == PP_FUSE_NONE || a->fuse_a_lo > 0) &&
                    (a->fuse != PP_FUSE_GRU_ZR || a->out2_lo > 0) && (a->fuse != PP_FUSE_GRU_H || a->fuse_b_lo > 0),
                PP_ERR_ARG, "pp_conv2d: split-plane epilogue operands need their lo offsets");
-    const bool force_v2 = (a->impl >= 10 && a->impl < 70) || a->impl >= 110;      // a specific LDS-DMA tile (tests / tile sweeps)
-    int rc = force_v2 ? -1000 : conv_v3s_dispatch(p, a->impl == 71 || a->impl == 72 ? a->impl : 0, st);
-    if (rc == -1000) rc = conv_v2s_dispatch(p, force_v2 ? a->impl : 0, st);
-    PP_REQUIRE(rc != -1000, PP_ERR_ARG, "pp_conv2d: no split-plane kernel for this layer (kchunks %d, impl %d)", a->kchunks, a->impl);
+    // split == 2: TRI-PRODUCT K format (per tap 4 hi + 4 lo chunks of 32 channels, weights [W_hi | W_lo]): the halo-tile kernel only;
+    // split == 1: every block walked three times by a plain K loop: the LDS-DMA (v2) kernel
+    const int rc = a->split == 2 ? conv_v3s_dispatch(p, a->impl == 71 || a->impl == 72 ? a->impl : 0, st)
+                                 : conv_v2s_dispatch(p, (a->impl >= 10 && a->impl < 70) || a->impl >= 110 ? a->impl : 0, st);
+    PP_REQUIRE(rc != -1000, PP_ERR_ARG, "pp_conv2d: no split-plane kernel for this layer (split %d, kchunks %d, %dx%d taps, impl %d)", a->split,
+               a->kchunks, a->tap_h, a->tap_w, a->impl);
     return rc;
   }
   if (a->dtype == PP_F16 && !deform && (a->impl == 80 || a->impl == 81)) {

@@ -1,9 +1,10 @@
 // Halo-tile convolution kernel (conv_halo.h), split-plane "f16x3" instantiations: RAFT at the reference's precision class on the
 // fp16 matrix cores.  The reference keeps RAFT in fp32 even under --fp16 (inference_propainter.py:311); here every RAFT
 // activation is a pair of fp16 planes (hi = fp16(v), lo = fp16(v - hi)), every weight a pair (W_hi, W_lo), and every product runs
-// as hi*W_hi + lo*W_hi + hi*W_lo with fp32 accumulation: the K table of a split layer simply walks each 64-channel block three
-// times (propainter_amd/conv.py, split_ktable), so the K loop, the LDS-DMA gather and the swizzles are the fp16 kernel's own.
-// Only the epilogue differs (conv_epilogue.h, SPLIT): operands are read as hi + lo, results are written as two planes.
+// as hi*W_hi + lo*W_hi + hi*W_lo with fp32 accumulation.  TRI-PRODUCT K format (propainter_amd/conv.py, tri_ktable; pp_conv_args_t.split
+// == 2): a K block is 32 channels of both planes, a tap step reads the four fragment sets (A_hi, A_lo, W_hi, W_lo) once and issues the
+// three products -- the LDS-DMA gather, the swizzles and the LDS image are the fp16 kernel's own (a 128-byte patch row = [hi | lo]).
+// The epilogue reads its operands as hi + lo and writes two planes (conv_epilogue.h, SPLIT).
 #include "conv_halo.h"
 
 namespace pp {
@@ -26,7 +27,7 @@ int conv_v3s_dispatch(const ConvParams& p, int cfg, hipStream_t stream) {
   if ((long long)p.cout_pad * p.kchunks * 16 >= (1ll << 31)) return -1000;
   for (int i = 0; i < p.nsrc; ++i)
     if ((long long)p.N * p.H * p.W * p.src[i].cstride * 2 >= (1ll << 31)) return -1000;
-  if (cfg == 0 && ((p.cout_g > 16 && p.cout_g < 48) || p.H < 8 || p.W < 8)) return -1000;
+  if ((p.cout_g > 16 && p.cout_g < 48) || p.H < 8 || p.W < 8) return -1000;     // (the host does not build tri-product tables for such layers)
   if (!((kh == 3 && kw == 3) || (kh == 1 && kw == 5) || (kh == 5 && kw == 1))) return -1000;
   const long long blk128 = (long long)p.N * ((p.H + 7) / 8) * ((p.W + 15) / 16) * ((p.cout_g + 127) / 128);
   const bool n64 = cfg == 72 || (cfg != 71 && (p.cout_g <= 64 || (p.cout_g <= 192 && p.cout_g % 128 != 0 && p.cout_g % 128 <= 64) ||

@@ -27,9 +27,13 @@ static __device__ unsigned long long g_v3_prof[12];     // (per translation unit
 // 32: 32 x 64 wave tiles, 8 waves per block tile, FOUR waves per SIMD at <= 128 registers -- more LDS fragment traffic per
 // MFMA (0.75 vs 0.5 KB) for twice the latency hiding (ablations, tools/kbench impl 86..89: the phases of the 2-waves-per-SIMD
 // kernel barely overlap -- MFMA 75 + fragment reads 43 + DMA 38 + epilogue/sync 40 us of a 193 us launch).
-// SPLIT: split-plane ("f16x3") operands -- every fp16 operand the epilogue touches (out, out2, preadd, residual, h, z) is a
-// hi plane + a lo plane `*_lo` elements further along the pixel row, value = hi + lo (pp_conv_args_t.split).  The K loop is
-// unchanged: the host's K table walks every source block three times (hi x W_hi, lo x W_hi, hi x W_lo).
+// SPLIT: split-plane ("f16x3", pp_conv_args_t.split == 2, "tri-product" K format) -- every fp16 operand is a hi plane + a lo plane,
+// value = hi + lo.  A K block is 32 channels of BOTH planes: the 128-byte patch row of a pixel holds [32 ch hi | 32 ch lo] (the DMA
+// fetches slots 0..3 from the hi plane and slots 4..7 from the lo plane, `lo offset` = table entry 4 minus entry 0 of the block),
+// the weight row of a tap holds [32 ch W_hi | 32 ch W_lo], and a tap step multiplies the FOUR fragment sets it has read as
+// W_hi x A_hi + W_hi x A_lo + W_lo x A_hi: 48 MFMAs per 16 fragment reads, one weight stage and one barrier (the plain fp16 step:
+// 32 MFMAs per 16 reads; walking a block three times through the plain kernel: 48 MFMAs per 24 reads, 1.5 stages, 1.5 barriers).
+// The epilogue reads its operands (preadd, residual, h, z) as hi + lo and writes two planes (conv_epilogue.h).
 template <int TH, int TW, int KH, int KW, int BN, bool PROF = false, int STAGGER = 0, int WMT = 64, bool SPLIT = false>
 __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : (SPLIT && BN == 128 ? 2 : 1)) void conv_halo_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -115,12 +119,15 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : (SPLIT && BN =
   const __amdgpu_buffer_rsrc_t rs3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.src[3].ptr + p.src[3].choff * 2), 0, nrec * rb3, 0x00020000);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.weight), 0, p.cout_pad * p.kchunks * 16, 0x00020000);
 
-#define V3_ISSUE_PIECE(j, pbuf, e)                                                                              \
+  // (SPLIT: logical chunks 0..3 of a patch row are 32 channels of the hi plane, chunks 4..7 the same channels of the lo plane,
+  //  `lob` bytes further -- lob = 2 * (choff of table entry 4 - choff of entry 0) of the block, wave-uniform)
+#define V3_ISSUE_PIECE(j, pbuf, e, lob)                                                                         \
   do {                                                                                                          \
     const int s_ = (e)[2] & 0xff;                                                                               \
     const __amdgpu_buffer_rsrc_t r_ = s_ == 1 ? rs1 : s_ == 2 ? rs2 : s_ == 3 ? rs3 : rs0;                      \
     const int rowbytes_ = s_ == 1 ? rb1 : s_ == 2 ? rb2 : s_ == 3 ? rb3 : rb0;                                  \
-    const int voff_ = ppix[j] >= 0 ? ppix[j] * rowbytes_ + (e)[3] * 2 + lca * 16 : (int)0x80000000;             \
+    const int coff_ = SPLIT ? (lca & 3) * 16 + ((lca & 4) ? (lob) : 0) : lca * 16;                              \
+    const int voff_ = ppix[j] >= 0 ? ppix[j] * rowbytes_ + (e)[3] * 2 + coff_ : (int)0x80000000;                \
     v3_dma16(r_, patch0 + (pbuf) * PATCH_BYTES + ((j) * NW + wave) * 1024, voff_, 0);                           \
   } while (0)
 #define V3_ISSUE_B(ks_, par_)                                                                                   \
@@ -163,18 +170,25 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : (SPLIT && BN =
   if constexpr (PROF) pf_t0 = __builtin_readcyclecounter();
   // ---- prologue: patch of block 0 (all pieces) + weights of step 0
   {
-    i32x4s e;
+    i32x4s e, el;
     v3_fetch_entry(p.ktable, e);
+    if constexpr (SPLIT) v3_fetch_entry(p.ktable + 4, el);
     v3_entry_ready(e);
+    if constexpr (SPLIT) v3_entry_ready(el);
+    const int lob0 = SPLIT ? (el[3] - e[3]) * 2 : 0;
 #pragma unroll
-    for (int j = 0; j < PPW; ++j) V3_ISSUE_PIECE(j, 0, e);
+    for (int j = 0; j < PPW; ++j) V3_ISSUE_PIECE(j, 0, e, lob0);
     V3_ISSUE_B(0, 0);
   }
   int ks = 0, par = 0;
   for (int blk = 0; blk < nblocks; ++blk) {
     const bool have_next = blk + 1 < nblocks;
-    i32x4s en;
-    if (have_next) v3_fetch_entry(p.ktable + (blk + 1) * (NTAPS * 8), en);
+    i32x4s en, enl;
+    if (have_next) {
+      v3_fetch_entry(p.ktable + (blk + 1) * (NTAPS * 8), en);
+      if constexpr (SPLIT) v3_fetch_entry(p.ktable + (blk + 1) * (NTAPS * 8) + 4, enl);
+    }
+    int lobn = 0;
     const char* pcur = patch0 + (blk & 1) * PATCH_BYTES;
     const int pnext = (blk + 1) & 1;
 #pragma unroll
@@ -201,17 +215,47 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : (SPLIT && BN =
       if constexpr (PROF) { pf_b = __builtin_readcyclecounter(); pf_vm += pf_b - pf_a; }
       __builtin_amdgcn_s_barrier();          // weights of step ks (and, at t == 0, the whole patch of this block) are in LDS
       if constexpr (PROF) { pf_c = __builtin_readcyclecounter(); pf_wait += pf_c - pf_b; }
-      if (t == 0 && have_next) v3_entry_ready(en);
+      if (t == 0 && have_next) {
+        v3_entry_ready(en);
+        if constexpr (SPLIT) { v3_entry_ready(enl); lobn = (enl[3] - en[3]) * 2; }
+      }
       const bool more_b = ks + 1 < nk;
       if constexpr (STAGGER != 3 && STAGGER != 6 && STAGGER != 9) { if (more_b) V3_ISSUE_B(ks + 1, par ^ 1); }
       if constexpr (STAGGER != 9) {
         if (have_next) {
 #pragma unroll
-          for (int jj = t; jj < PPW; jj += NTAPS) V3_ISSUE_PIECE(jj, pnext, en);     // (one piece per step for the shipped tiles: PPW <= NTAPS)
+          for (int jj = t; jj < PPW; jj += NTAPS) V3_ISSUE_PIECE(jj, pnext, en, lobn);     // (one piece per step for the shipped tiles: PPW <= NTAPS)
         }
       }
       if constexpr (PROF) { pf_a = __builtin_readcyclecounter(); pf_issue += pf_a - pf_c; }
       const char* sb = bst0 + par * BSTAGE;
+      if constexpr (SPLIT) {
+        // tri-product step: fragments of both planes (kk 0 = hi / W_hi, kk 1 = lo / W_lo), then the three products with the
+        // accumulators interleaved (an accumulator is revisited every 16 MFMAs; small terms first)
+        f16x8 af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+          for (int f = 0; f < TM; ++f) {
+            const int row = pp0[f] + sh;
+            af[kk][f] = *reinterpret_cast<const f16x8*>(pcur + row * 128 + (((kk * 4 + l4) ^ (row & 7)) << 4));
+          }
+#pragma unroll
+          for (int f = 0; f < TN; ++f) bf[kk][f] = *reinterpret_cast<const f16x8*>(sb + b_off + f * 16 * 128 + (((kk * 4 + l4) ^ bswz) << 4));
+        }
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+          for (int b = 0; b < TM; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[0][a], af[1][b], acc[a][b], 0, 0, 0);   // W_hi x A_lo
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+          for (int b = 0; b < TM; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[1][a], af[0][b], acc[a][b], 0, 0, 0);   // W_lo x A_hi
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+          for (int b = 0; b < TM; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[0][a], af[0][b], acc[a][b], 0, 0, 0);   // W_hi x A_hi
+      } else {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         f16x8 af[TM], bf[TN];
@@ -252,6 +296,7 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : (SPLIT && BN =
             }
           }
         }
+      }
       }
       if constexpr (PROF) { asm volatile("s_nop 0" ::: "memory"); pf_comp += __builtin_readcyclecounter() - pf_a; }
       ++ks;

@@ -290,7 +290,7 @@ def window_tables(Hp, Wp, wh=5, ww=9):
 # ----------------------------------------------------------------------------------------------
 # device ops
 # ----------------------------------------------------------------------------------------------
-def conv2d_raw(args: ConvArgs, cin_read=None, on=None, split_k=False):
+def conv2d_raw(args: ConvArgs, cin_read=None, on=None, split_k=0):
     """cin_read: channels read per input pixel (for the profiler's byte model; defaults to K per group x groups);
     on: a tensor of the launch (names the device / stream); split_k: the K table is a split-plane expansion (profiler accounting)."""
     if _profiler is None:
@@ -303,8 +303,8 @@ def conv2d_raw(args: ConvArgs, cin_read=None, on=None, split_k=False):
     osz = 2 if args.out_dtype == PP_F16 else 4
     # executed_k_mult = 3 for a split-plane ("f16x3") layer: its K table walks every block three times (hi*W_hi, lo*W_hi, hi*W_lo);
     # the ALGORITHMIC work is that of the fp32 layer it stands for: K / 3 products of 4-byte values
-    if split_k:
-        K //= 3
+    if split_k:            # 3: blocks walked three times; 2: tri-product format (both planes of a block in one K step)
+        K //= split_k
         esz = 4
         osz = 4
     flops = 2.0 * M * args.cout_g * K * args.groups

@@ -100,7 +100,15 @@ def _conv_call(self, srcs, out=None, out_choff=0, act=None, act_param=0.0, out_s
                 A[..., kc * 8:kc * 8 + 8] = smp.permute(0, 2, 3, 1) * om[..., 288 + grp * 9 + tap][..., None]
         if self.dtype == torch.float16:
             A = A.half().float()
-        y = A @ self.weight[g, :self.cout_g].float().t()
+        Wg = self.weight[g, :self.cout_g].float()
+        if getattr(self, "tri", False):
+            # tri-product format: per (block, tap) the K range holds [32 ch hi | 32 ch lo] on the A side and [W_hi | W_lo] on the weight
+            # side; the kernel computes W_hi x A_hi + W_hi x A_lo + W_lo x A_hi (NOT the plain K walk hi x W_hi + lo x W_lo)
+            lo = np.repeat((kt[:, 2].astype(np.int64) & pconv.KT_PLANE_LO) != 0, 8)
+            hi_c, lo_c = torch.from_numpy(np.nonzero(~lo)[0]), torch.from_numpy(np.nonzero(lo)[0])
+            y = A[..., hi_c] @ Wg[:, hi_c].t() + A[..., lo_c] @ Wg[:, hi_c].t() + A[..., hi_c] @ Wg[:, lo_c].t()
+        else:
+            y = A @ Wg.t()
         if self.bias is not None:
             y = y + self.bias[g * self.cout_g:(g + 1) * self.cout_g]
         y = y * out_scale

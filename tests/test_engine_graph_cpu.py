@@ -137,7 +137,9 @@ def test_raft_split_plane_engine_graph(models):
         raft.precision = "f16x3"
         try:
             eng = raft._get_engine("f16x3", torch.device("cpu"))
-            assert eng.split and not eng.corr_otf and eng.convc2.split and eng.convc2.kchunks == 3 * 9 * 32
+            assert eng.split and not eng.corr_otf
+            assert eng.convc2.tri and eng.convc2.kchunks == 2 * 9 * 32           # halo-tile layer: tri-product format (both planes per K block)
+            assert eng.convc1.split and not eng.convc1.tri and eng.convc1.kchunks == 128      # 1x1 over 328 channels: blocks walked three times
             ff, fb = raft(fr, iters=int(g["iters"]))
         finally:
             raft.precision = None
@@ -174,3 +176,15 @@ def test_split_ktable_and_weight_packing():
     ref = torch.relu(torch.nn.functional.conv2d(torch.cat([x0, x1], -1).permute(0, 3, 1, 2).double(), w.double(), bias.double(), padding=1))
     err = (merge_planes(y).double() - ref.permute(0, 2, 3, 1)).abs().max() / ref.abs().max()
     assert err < 2e-6, err
+    # the same layer shape with 64 couts takes the TRI-PRODUCT format (halo-tile kernel): per tap 4 hi + 4 lo chunks of a 32-channel
+    # block, weights [W_hi | W_lo]; the emulation's tri branch mirrors the kernel's three products
+    w2, b2 = torch.randn(64, 160, 3, 3, generator=g) * 0.1, torch.randn(64, generator=g)
+    with emulated_device_ops():
+        tri = pconv.ConvLayer(w2, b2, padding=1, src_channels=[64, 96], dtype=torch.float16, device="cpu", split=True, src_lo=[64, 128])
+        assert tri.tri and tri.kchunks == (2 + 3) * 9 * 8 and tri.ktable_uniform == 8
+        kt2 = tri.ktable.numpy()
+        assert (kt2[4, 3] - kt2[0, 3] == 64) and (kt2[2 * 72 + 4, 3] - kt2[2 * 72, 3] == 128)       # lo offsets of source 0 / source 1
+        y2 = tri([split_planes(x0), s1], act="relu")
+    ref2 = torch.relu(torch.nn.functional.conv2d(torch.cat([x0, x1], -1).permute(0, 3, 1, 2).double(), w2.double(), b2.double(), padding=1))
+    err2 = (merge_planes(y2).double() - ref2.permute(0, 2, 3, 1)).abs().max() / ref2.abs().max()
+    assert err2 < 2e-6, err2

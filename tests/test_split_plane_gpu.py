@@ -59,6 +59,12 @@ CASES = [
     dict(name="v2_1x1_576_f32out", cin=[256], cout=576, k=(1, 1), pad=0, out_f32=True, out_scale=0.25),
     dict(name="v2_7x1_c16", cin=[16], cout=128, k=(7, 1), pad=(3, 0), act="relu"),
     dict(name="v2_1x1_linear_residual_c128", cin=[128], cout=128, k=(1, 1), pad=0, residual=True),
+    # halo-eligible layers forced through the v2 kernel's plain split format (every block walked three times)
+    dict(name="v2_plain_3x3_c128_preadd", cin=[128], cout=128, k=(3, 3), pad=1, act="tanh", preadd=True, tri=False),
+    dict(name="v2_plain_3x3_c64_two_src", cin=[192, 64], cout=64, k=(3, 3), pad=1, act="relu", tri=False),
+    # tri-product format over a 96-channel source (32-channel blocks) and 32 + 64 channel sources
+    dict(name="halo3x3_c96_src96", cin=[96], cout=96, k=(3, 3), pad=1, act="relu", residual=True, act2="relu"),
+    dict(name="halo5x1_c64_src32_64", cin=[32, 64], cout=64, k=(5, 1), pad=(2, 0), act="relu"),
 ]
 
 
@@ -72,8 +78,8 @@ def test_split_plane_conv(dev, case):
     srcs, vals = zip(*[planes(torch.randn(N, c, H, W, generator=g) * (1.0 + 3.0 * i), pad8(c)) for i, c in enumerate(cin)])
     w = torch.randn(cout, sum(cin), *k, generator=g) / math.sqrt(sum(cin) * k[0] * k[1])
     b = torch.randn(cout, generator=g) * 0.3
-    layer = ConvLayer(w, b, stride=stride, padding=pad, src_channels=cin, dtype=torch.float16, device=dev, split=True)
-    assert layer.kchunks % 8 == 0 and layer.split
+    layer = ConvLayer(w, b, stride=stride, padding=pad, src_channels=cin, dtype=torch.float16, device=dev, split=True, tri=case.get("tri"))
+    assert layer.kchunks % 8 == 0 and layer.split and layer.tri == (case["name"].startswith("halo"))
     # the weights the kernel multiplies with: W_hi + W_lo (22 bits of w)
     w_eff = (w.half().double() + (w - w.half().float()).half().double())
     ref = F.conv2d(torch.cat(vals, 1), w_eff, b.double(), stride, pad) * case.get("out_scale", 1.0)
@@ -128,12 +134,13 @@ def test_split_plane_fused_gru(dev, k, pad, impl):
     hx = torch.cat([h0, inp, mf], 1)
     z = torch.sigmoid(F.conv2d(hx, eff(wz), bz.double(), 1, pad))
     r = torch.sigmoid(F.conv2d(hx, eff(wr), br.double(), 1, pad))
-    mk = lambda w, b, sc: ConvLayer(w, b, padding=pad, src_channels=sc, dtype=torch.float16, device=dev, split=True)
+    mk = lambda w, b, sc: ConvLayer(w, b, padding=pad, src_channels=sc, dtype=torch.float16, device=dev, split=True, tri=(impl == 0))
     wzr, bzr = torch.cat([wz, wr], 0), torch.cat([bz, br], 0)
     it = lambda w: torch.cat([w[:, :C], w[:, 2 * C:]], 1)
     zr_pre, q_pre = mk(wzr[:, C:2 * C], bzr, [C]), mk(wq[:, C:2 * C], bq, [C])
     zr_it, q_it = mk(it(wzr), None, [C, C]), mk(it(wq), None, [C, C])
     zr_it.impl = q_it.impl = impl
+    assert zr_it.tri == (impl == 0)          # halo: tri-product format; v2: every block walked three times
     pzr, pq = zr_pre([inpd]), q_pre([inpd])
     zbuf = torch.empty((N, H, W, 2 * C), dtype=torch.float16, device=dev)
     rh = torch.empty((N, H, W, 2 * C), dtype=torch.float16, device=dev)
