@@ -287,6 +287,9 @@ typedef struct {
   int32_t work_ints;           /* capacity of `work` in int32 elements (>= 1 + B*nW)                */
   void* work;                  /* optional device scratch: compacted list of masked windows for the persistent,
                                   load-balanced launch of the masked-window kernel; NULL = grid-mapped launch */
+  int32_t out_h, out_w;        /* both 0: `out` is the padded grid [B,T,Hp,Wp,C]; both > 0: `out` is the COMPACT token grid
+                                  [B,T,out_h,out_w,C] (out_h <= Hp, out_w <= Wp) -- the crop of sparse_transformer.py:276-277 happens in
+                                  the store, padding tokens are not written                                              */
 } pp_attn_args_t;
 
 int pp_sparse_window_attention(const pp_attn_args_t* args, void* stream);
@@ -305,6 +308,11 @@ int pp_fold_tokens(const void* tokens, void* out, int BT, int fh, int fw, int C,
 /* LayerNorm over the last dim (C multiple of 64, <= 1024): in/out [rows, C]. */
 int pp_layernorm(const void* in, const float* gamma, const float* beta, void* out, int64_t rows, int C, float eps,
                  int dtype, void* stream);
+/* The same over a token grid in [N, gh, gw, C], written into the top-left corner of a PADDED grid out [N, Hp, Wp, C] (Hp >= gh, Wp >=
+ * gw): the zero padding AFTER LayerNorm of sparse_transformer.py:169-171 without a copy -- the padding tokens of `out` are not
+ * written (the caller zero-fills the buffer once). */
+int pp_layernorm_grid(const void* in, const float* gamma, const float* beta, void* out, int N, int gh, int gw, int Hp, int Wp, int C,
+                      float eps, int dtype, void* stream);
 
 /* depthwise kxk stride-k conv ("pool_layer", sparse_transformer.py:136,209): in NHWC [N,H,W,C] -> [N,H/k,W/k,C];
  * weight fp32 [C,k,k], bias fp32 [C]. */

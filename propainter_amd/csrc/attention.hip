@@ -30,7 +30,16 @@ struct AttnParams {
   const float* wmask;
   char* out;
   const int* work;     // [1 + B*nW]: count of masked windows, then their flat (b*nW + w) ids (attn_compact_kernel)
+  int out_h, out_w;    // > 0: `out` is the COMPACT [B, T, out_h, out_w, C] grid (padding tokens are not written); 0: padded [B, T, Hp, Wp, C]
 };
+
+// element offset (in tokens) of query token `idx` (= y * Wp + x in the padded grid) of frame (b, f) in `out`, or -1 for a padding
+// token of a compact output
+__device__ __forceinline__ long long attn_out_token(const AttnParams& p, int b, int f, int idx) {
+  if (p.out_h <= 0) return ((long long)b * p.T + f) * p.Hp * p.Wp + idx;
+  const int y = idx / p.Wp, x = idx - y * p.Wp;
+  return (y < p.out_h && x < p.out_w) ? (((long long)b * p.T + f) * p.out_h + y) * p.out_w + x : -1ll;
+}
 
 constexpr int HD = 128;  // head dim
 
@@ -86,7 +95,9 @@ __global__ __launch_bounds__(256) void attn_ref_kernel(const AttnParams p) {
     a1 = a1 * alpha + pe * to_f32(vp[lane + 64]);
     m = mn;
   }
-  T* op = reinterpret_cast<T*>(p.out) + qoff * p.C + head * HD;
+  const long long otok = attn_out_token(p, b, fq, idx_lds[tok]);
+  if (otok < 0) return;
+  T* op = reinterpret_cast<T*>(p.out) + otok * p.C + head * HD;
   op[lane] = from_f32<T>(a0 / l);
   op[lane + 64] = from_f32<T>(a1 / l);
 }
@@ -153,7 +164,7 @@ __device__ __forceinline__ void attn_block(const AttnParams& p, const int b, con
   const T* pvg = reinterpret_cast<const T*>(p.pv);
 
   // ---- this lane's queries (column lane&15 of each of the wave's QT 16-query tiles), held as MFMA B fragments
-  long long qoff[QT];
+  long long qoff[QT], otok[QT];
   bool qvalid[QT];
   f16x8 qf[QT][4];
 #pragma unroll
@@ -171,6 +182,7 @@ __device__ __forceinline__ void attn_block(const AttnParams& p, const int b, con
       tok = qvalid[qt] ? ql : 0;
     }
     qoff[qt] = ((long long)b * p.T + fq) * p.Hp * p.Wp + idx_lds[tok];
+    otok[qt] = attn_out_token(p, b, fq, idx_lds[tok]);
     const T* qp = qg + qoff[qt] * p.qkv_cs + head * HD + (lane >> 4) * 8;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -365,10 +377,10 @@ __device__ __forceinline__ void attn_block(const AttnParams& p, const int b, con
     float l = l_run[qt];
     l += __shfl_xor(l, 16);
     l += __shfl_xor(l, 32);
-    if (qvalid[qt]) {
+    if (qvalid[qt] && otok[qt] >= 0) {
       const float inv = 1.f / l;
       // lane holds rows (lane>>4)*4 + r of every tile dt -> channels (lane>>4)*32 + dt*4 + r: 32 consecutive channels
-      T* op = reinterpret_cast<T*>(p.out) + qoff[qt] * p.C + head * HD + (lane >> 4) * 32;
+      T* op = reinterpret_cast<T*>(p.out) + otok[qt] * p.C + head * HD + (lane >> 4) * 32;
 #pragma unroll
       for (int d2 = 0; d2 < 4; ++d2) {
         f16x8 o;
@@ -535,6 +547,9 @@ extern "C" int pp_sparse_window_attention(const pp_attn_args_t* a, void* stream)
   p.q = (const char*)a->q; p.k = (const char*)a->k; p.v = (const char*)a->v; p.qkv_cs = a->qkv_cstride;
   p.pk = (const char*)a->pk; p.pv = (const char*)a->pv; p.pkv_cs = a->pkv_cstride;
   p.own = a->own; p.rolled = a->rolled; p.tind = a->tind; p.wmask = a->wmask; p.out = (char*)a->out; p.work = nullptr;
+  PP_REQUIRE((a->out_h == 0 && a->out_w == 0) || (a->out_h > 0 && a->out_h <= a->Hp && a->out_w > 0 && a->out_w <= a->Wp), PP_ERR_ARG,
+             "pp_sparse_window_attention: compact output grid %dx%d outside the padded grid %dx%d", a->out_h, a->out_w, a->Hp, a->Wp);
+  p.out_h = a->out_h; p.out_w = a->out_w;
   hipStream_t st = (hipStream_t)stream;
   const unsigned gx = (unsigned)(p.B * p.nW * p.heads);
   if (a->dtype == PP_F16 && a->impl != 1) {

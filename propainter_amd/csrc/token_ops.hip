@@ -54,10 +54,15 @@ __global__ __launch_bounds__(256) void fold_tokens_kernel(const T* __restrict__ 
 template <typename T, int PER_LANE>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ in, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, T* __restrict__ out, long long rows,
-                                                        int C, float eps) {
+                                                        int C, float eps, int gh, int gw, int Hp, int Wp) {
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
+  long long orow = row;                         // gh > 0: token (n, y, x) of a [N, gh, gw] grid goes to (n, y, x) of a padded [N, Hp, Wp] grid
+  if (gh > 0) {
+    const int x = (int)(row % gw), y = (int)((row / gw) % gh);
+    orow = ((row / ((long long)gw * gh)) * Hp + y) * Wp + x;
+  }
   const T* ip = in + row * C;
   float v[PER_LANE];
   float s = 0.f;
@@ -72,7 +77,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ in
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
   const float rstd = rsqrtf(q / (float)C + eps);
-  T* op = out + row * C;
+  T* op = out + orow * C;
 #pragma unroll
   for (int i = 0; i < PER_LANE; ++i) {
     const int c = lane + 64 * i;
@@ -395,8 +400,20 @@ extern "C" int pp_layernorm(const void* in, const float* gamma, const float* bet
   PP_REQUIRE(dtype == PP_F32 || dtype == PP_F16, PP_ERR_DTYPE, "pp_layernorm: dtype %d", dtype);
   const unsigned g = (unsigned)((rows + 3) / 4);
   PP_DISPATCH_T(dtype, hipLaunchKernelGGL((layernorm_kernel<T, 8>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const T*)in, gamma,
-                                          beta, (T*)out, (long long)rows, C, eps);)
+                                          beta, (T*)out, (long long)rows, C, eps, 0, 0, 0, 0);)
   return launch_status("pp_layernorm");
+}
+
+extern "C" int pp_layernorm_grid(const void* in, const float* gamma, const float* beta, void* out, int N, int gh, int gw, int Hp, int Wp,
+                                 int C, float eps, int dtype, void* stream) {
+  PP_REQUIRE(in && gamma && beta && out && N > 0 && gh > 0 && gw > 0 && Hp >= gh && Wp >= gw, PP_ERR_ARG, "pp_layernorm_grid: bad arguments");
+  PP_REQUIRE(C == 512, PP_ERR_ARG, "pp_layernorm_grid: C=%d (only 512 is instantiated)", C);
+  PP_REQUIRE(dtype == PP_F32 || dtype == PP_F16, PP_ERR_DTYPE, "pp_layernorm_grid: dtype %d", dtype);
+  const long long rows = (long long)N * gh * gw;
+  const unsigned g = (unsigned)((rows + 3) / 4);
+  PP_DISPATCH_T(dtype, hipLaunchKernelGGL((layernorm_kernel<T, 8>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const T*)in, gamma,
+                                          beta, (T*)out, rows, C, eps, gh, gw, Hp, Wp);)
+  return launch_status("pp_layernorm_grid");
 }
 
 extern "C" int pp_depthwise_pool(const void* in, const float* weight, const float* bias, void* out, int N, int H, int W, int C,

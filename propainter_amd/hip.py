@@ -54,6 +54,7 @@ class AttnArgs(C.Structure):
         ("qkv_cstride", C.c_int32), ("pk", C.c_void_p), ("pv", C.c_void_p), ("pkv_cstride", C.c_int32),
         ("own", C.c_void_p), ("rolled", C.c_void_p), ("tind", C.c_void_p), ("wmask", C.c_void_p),
         ("out", C.c_void_p), ("impl", C.c_int32), ("work_ints", C.c_int32), ("work", C.c_void_p),
+        ("out_h", C.c_int32), ("out_w", C.c_int32),
     ]
 
 
@@ -448,9 +449,9 @@ def window_mask(mask, wh=5, ww=9):
 
 
 def sparse_window_attention(q, k, v, pk, pv, own, rolled, tind, wmask, heads=4, wh=5, ww=9, qkv_cstride=None,
-                            pkv_cstride=None, C_=None, impl=0):
+                            pkv_cstride=None, C_=None, impl=0, out_hw=None):
     """q/k/v: [B,T,Hp,Wp,*] token grids (possibly channel windows of one fused buffer: pass cstride);
-    pk/pv: [B,T,P,*]; returns [B,T,Hp,Wp,C]."""
+    pk/pv: [B,T,P,*]; returns [B,T,Hp,Wp,C], or the cropped [B,T,oh,ow,C] when out_hw=(oh, ow) (padding tokens are not stored)."""
     B, T, Hp, Wp = q.shape[:4]
     C_ = q.shape[-1] if C_ is None else C_
     a = AttnArgs()
@@ -465,7 +466,11 @@ def sparse_window_attention(q, k, v, pk, pv, own, rolled, tind, wmask, heads=4, 
     a.pv = pv.data_ptr() if pv is not None else None
     a.pkv_cstride = pkv_cstride if pkv_cstride is not None else (pk.shape[-1] if pk is not None else 0)
     a.own, a.rolled, a.tind, a.wmask = own.data_ptr(), rolled.data_ptr(), tind.data_ptr(), wmask.data_ptr()
-    out = torch.empty((B, T, Hp, Wp, C_), dtype=q.dtype, device=q.device)
+    if out_hw is not None:
+        a.out_h, a.out_w = int(out_hw[0]), int(out_hw[1])
+        out = torch.empty((B, T, a.out_h, a.out_w, C_), dtype=q.dtype, device=q.device)
+    else:
+        out = torch.empty((B, T, Hp, Wp, C_), dtype=q.dtype, device=q.device)
     a.out = out.data_ptr()
     a.impl = impl
     work = torch.empty((1 + B * wmask.shape[-1],), dtype=torch.int32, device=q.device)   # compacted masked-window list
@@ -508,6 +513,17 @@ def layernorm(x, gamma, beta, eps=1e-5):
     timed("layernorm", 0, _nbytes(x) + _nbytes(out), lambda: _check(lib().pp_layernorm(_p(x), _p(gamma), _p(beta), _p(out), C.c_int64(x.numel() // Cc), _i(Cc),
                               C.c_float(eps), _i(dtype_code(x.dtype)), _stream(x)),
            "pp_layernorm"))
+    return out
+
+
+def layernorm_grid(x, gamma, beta, out, eps=1e-5):
+    """LayerNorm of a token grid x [N,gh,gw,C] written into the top-left corner of the padded grid out [N,Hp,Wp,C] (padding tokens of
+    `out` are left as they are: zero-filled once by the caller)."""
+    N, gh, gw, Cc = x.shape
+    assert out.shape[0] == N and out.shape[3] == Cc and out.dtype == x.dtype and x.is_contiguous() and out.is_contiguous()
+    timed("layernorm", 0, 2 * _nbytes(x), lambda: _check(lib().pp_layernorm_grid(_p(x), _p(gamma), _p(beta), _p(out), _i(N), _i(gh), _i(gw), _i(out.shape[1]),
+                                                                                 _i(out.shape[2]), _i(Cc), C.c_float(eps), _i(dtype_code(x.dtype)), _stream(x)),
+                                                 "pp_layernorm_grid"))
     return out
 
 
