@@ -214,6 +214,14 @@ int pp_img_prop_step(const void* x_prop, const void* m_prop, const void* x_cur, 
  * non-zero pixel lies within L1 distance k, else 0 (k = 0: plain binarisation).  out must not alias mask. */
 int pp_binary_dilate(const void* mask, void* out, int N, int H, int W, int iterations, void* stream);
 
+/* Ordered uint8 composite of one generator window (inference_propainter.py:435-450) in one launch: for local frame i (clip frame
+ * frame_ids[i], HOST array of n <= 32 ids)  img = uint8(((pred + 1) / 2) * 255) with every operation rounded in pred's dtype and the
+ * final truncation of .astype(np.uint8);  cur = mask ? img : original;  comp = (blend_bits >> i) & 1 ? uint8(0.5f * comp + 0.5f * cur) :
+ * cur.  pred planar [n,3,H,W] (dtype); mask uint8, element (frame, pixel) at (frame * H * W + pixel) * mask_stride, non-zero = hole;
+ * original / comp uint8 [L,H,W,3].  Order dependent: windows must be composited in increasing position. */
+int pp_composite_window(const void* pred, int dtype, const void* mask, int mask_stride, const void* original, void* comp,
+                        const int32_t* frame_ids, uint32_t blend_bits, int n, int H, int W, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * RAFT correlation (RAFT/corr.py:13-60, RAFT/utils/utils.py:57-71, RAFT/raft.py:73-84)
  * ---------------------------------------------------------------------------------------------- */

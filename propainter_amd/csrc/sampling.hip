@@ -179,9 +179,63 @@ __global__ void binary_dilate_kernel(const unsigned char* __restrict__ in, unsig
   }
 }
 
+// Ordered uint8 composite of one generator window (inference_propainter.py:435-450), all its local frames in ONE launch.
+//   img  = uint8( ((pred + 1) / 2) * 255 )      every operation rounded in pred's own dtype like the reference's tensor / numpy ops,
+//                                                then truncated towards zero (.astype(np.uint8))
+//   cur  = mask ? img : original
+//   comp = blend ? uint8(0.5f * comp + 0.5f * cur) : cur          (the frame already carries an earlier window's result)
+// pred planar [n, 3, H, W]; mask [L, H, W] (non-zero = hole), original / comp [L, H, W, 3] uint8; frame i of the window is clip frame
+// ids[i]; bit i of blend_bits says whether that frame was composited before.  One thread per pixel (3 bytes).
+struct CompositeIds { int ids[32]; };
+template <typename T>
+__global__ void composite_window_kernel(const T* __restrict__ pred, const unsigned char* __restrict__ mask, int mask_stride,
+                                        const unsigned char* __restrict__ ori, unsigned char* __restrict__ comp, const CompositeIds fr,
+                                        unsigned blend_bits, int n, int HW) {
+  const long long total = (long long)n * HW;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int f = (int)(i / HW), px = (int)(i - (long long)f * HW);
+    const long long g = (long long)fr.ids[f] * HW + px;          // pixel of the clip frame
+    const bool hole = mask[g * mask_stride] != 0;
+    const bool blend = (blend_bits >> f) & 1u;
+    unsigned char* cp = comp + g * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      unsigned char cur = ori[g * 3 + c];
+      if (hole) {
+        const T one = from_f32<T>(1.f), two = from_f32<T>(2.f), s255 = from_f32<T>(255.f);
+        T v = pred[((long long)f * 3 + c) * HW + px];
+        v = v + one;             // one rounding per operation in T (fp16: v_add_f16 / v_mul_f16; the build uses -ffp-contract=off)
+        v = v / two;
+        v = v * s255;
+        cur = (unsigned char)to_f32(v);
+      }
+      if (blend) cur = (unsigned char)((float)cp[c] * 0.5f + (float)cur * 0.5f);
+      cp[c] = cur;
+    }
+  }
+}
+
 }  // namespace pp
 
 using namespace pp;
+
+extern "C" int pp_composite_window(const void* pred, int dtype, const void* mask, int mask_stride, const void* original, void* comp,
+                                   const int32_t* frame_ids, uint32_t blend_bits, int n, int H, int W, void* stream) {
+  PP_REQUIRE(pred && mask && original && comp && frame_ids && n > 0 && n <= 32 && H > 0 && W > 0 && mask_stride >= 1, PP_ERR_ARG,
+             "pp_composite_window: bad arguments (n = %d local frames, at most 32)", n);
+  PP_REQUIRE(dtype == PP_F32 || dtype == PP_F16, PP_ERR_DTYPE, "pp_composite_window: dtype %d", dtype);
+  CompositeIds fr;
+  for (int i = 0; i < 32; ++i) fr.ids[i] = i < n ? frame_ids[i] : 0;
+  for (int i = 0; i < n; ++i) PP_REQUIRE(fr.ids[i] >= 0, PP_ERR_ARG, "pp_composite_window: negative frame id");
+  const int g = grid_for((long long)n * H * W);
+  if (dtype == PP_F16)
+    hipLaunchKernelGGL((composite_window_kernel<_Float16>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const _Float16*)pred,
+                       (const unsigned char*)mask, mask_stride, (const unsigned char*)original, (unsigned char*)comp, fr, blend_bits, n, H * W);
+  else
+    hipLaunchKernelGGL((composite_window_kernel<float>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)pred,
+                       (const unsigned char*)mask, mask_stride, (const unsigned char*)original, (unsigned char*)comp, fr, blend_bits, n, H * W);
+  return launch_status("pp_composite_window");
+}
 
 extern "C" int pp_flow_warp(const void* x, int x_cstride, int x_choff, const void* flow, int fl_cstride, int fl_choff,
                             void* out, int out_cstride, int out_choff, int N, int H, int W, int C, int mode, int dtype,

@@ -367,6 +367,20 @@ def binary_dilate(mask_u8, iterations):
     return out
 
 
+def composite_window(pred, mask_u8, ori_u8, comp_u8, frame_ids, blend_flags):
+    """pred [n,3,H,W] in [-1,1] (fp32 / fp16); mask_u8 [L,H,W(,1)] uint8 (non-zero = hole); ori_u8 / comp_u8 uint8 [L,H,W,3]; frame_ids: the clip
+    frames of the n local frames; blend_flags[i]: frame i was composited before (0.5 / 0.5 blend).  Updates comp_u8 in place."""
+    n, c3, H, W = pred.shape
+    assert c3 == 3 and n <= 32 and pred.is_contiguous() and mask_u8.is_contiguous() and ori_u8.is_contiguous() and comp_u8.is_contiguous()
+    assert mask_u8.dtype == ori_u8.dtype == comp_u8.dtype == torch.uint8 and len(frame_ids) == n == len(blend_flags)
+    ids = (C.c_int32 * n)(*[int(i) for i in frame_ids])
+    bits = sum(1 << i for i, b in enumerate(blend_flags) if b)
+    timed("composite_window", 0, _nbytes(pred) + n * H * W * 10,
+          lambda: _check(lib().pp_composite_window(_p(pred), _i(dtype_code(pred.dtype)), _p(mask_u8), _i(1), _p(ori_u8), _p(comp_u8), ids, C.c_uint32(bits),
+                                                   _i(n), _i(H), _i(W), _stream(pred)), "pp_composite_window"))
+    return comp_u8
+
+
 def corr_avgpool(x, M, H, W):
     out = torch.empty((M, H // 2, W // 2), dtype=torch.float32, device=x.device)
     timed("corr_avgpool", 0, _nbytes(out) * 5, lambda: _check(lib().pp_corr_avgpool(_p(x), _p(out), C.c_int64(M), _i(H), _i(W), _stream(x)),

@@ -118,6 +118,7 @@ class _GenEngine:
                 fc1=mk(*tap_major(*g(t + "mlp.fc1.0"), 40)),
                 fc2=mk(sd[t + "mlp.fc2.1.weight"].view(HIDDEN, 40, 7, 7), sd[t + "mlp.fc2.1.bias"], stride=3, padding=3)))
         self._win_cache = {}
+        self._tind_cache = {}
 
     # ------------------------------------------------------------------ encoder / decoder
     def encode(self, x):
@@ -139,46 +140,55 @@ class _GenEngine:
         return hip.nhwc_to_nchw(x, 3)
 
     # ------------------------------------------------------------------ feature propagation (:104-190, learnable)
-    def feature_propagation(self, x, flows_f, flows_b, mask2, interpolation="bilinear"):
-        """x [t,h,w,128]; flows_* [t-1,h,w,2] NHWC (1/4-res, already /4); mask2 [t,h,w,2] -> fused [t,h,w,128]."""
+    def propagation_rows(self, flows_f, flows_b, mask2):
+        """The per-pair side inputs of the propagation steps: flows_* [n-1,h,w,2] NHWC (1/4-res, already /4), mask2 [n,h,w,2] ->
+        (aux_b, aux_f, mk8).  aux_b[j] = [flow_f[j] | valid(flow_f[j], flow_b[j]) | mask2[j] | 0 0 0] is what the BACKWARD pass needs when
+        it moves from frame j + 1 to frame j, aux_f[j] = [flow_b[j] | valid(flow_b[j], flow_f[j]) | mask2[j + 1] | 0 0 0] what the forward
+        pass needs from frame j to j + 1 (model/propainter.py:137-160); mk8 = mask2 padded to 8 channels.  All forward-backward
+        checks of a direction run as one launch."""
+        n, h, w, _ = mask2.shape
+        dev, dt = mask2.device, self.dtype
+        mk8 = torch.zeros((n, h, w, 8), dtype=dt, device=dev)
+        mk8[..., :2] = mask2
+        aux_b = torch.zeros((max(n - 1, 0), h, w, 8), dtype=dt, device=dev)
+        aux_f = torch.zeros_like(aux_b)
+        if n > 1:
+            aux_b[..., :2] = flows_f
+            aux_b[..., 3:5] = mask2[:n - 1]
+            hip.fb_check(aux_b, flows_b.contiguous(), out=aux_b, out_choff=2)
+            aux_f[..., :2] = flows_b
+            aux_f[..., 3:5] = mask2[1:]
+            hip.fb_check(aux_f, flows_f.contiguous(), out=aux_f, out_choff=2)
+        return aux_b, aux_f, mk8
+
+    def feature_propagation(self, x, flows_f, flows_b, mask2, interpolation="bilinear", rows=None, out=None):
+        """x [t,h,w,128]; flows_* [t-1,h,w,2] NHWC (1/4-res, already /4); mask2 [t,h,w,2] -> fused [t,h,w,128] (written to `out`
+        when given).  rows = propagation_rows(...) of these frames when the caller has them already (per-clip cache)."""
         t, h, w, c = x.shape
         dev, dt = x.device, self.dtype
-        mk8 = torch.zeros((t, h, w, 8), dtype=dt, device=dev)
-        mk8[..., :2] = mask2
+        aux_b, aux_f, mk8 = rows if rows is not None else self.propagation_rows(flows_f, flows_b, mask2)
         feats = {"input": x}
         prev_name = "input"
         for name in ("backward_1", "forward_1"):
             L = self.prop[name]
+            # step i >= 1 of the backward pass moves from frame idx + 1 to idx = t - 1 - i with the rows of pair idx; the forward pass
+            # moves from frame i - 1 to i with the rows of pair i - 1 (plain slices: the whole window is capturable in a hipGraph)
             if name == "backward_1":
                 order = list(range(t - 1, -1, -1))
-                fidx = order                               # flow index of step i (i >= 1) is order[i]
-                f_prop, f_chk = flows_f, flows_b
+                aux, pair = aux_b, (lambda i, idx: idx)
             else:
                 order = list(range(t))
-                fidx = [None] + list(range(0, t - 1))
-                f_prop, f_chk = flows_b, flows_f
+                aux, pair = aux_f, (lambda i, idx: i - 1)
             cur_all = feats[prev_name]
             outs = torch.empty((t, h, w, c), dtype=dt, device=dev)
-            if t > 1:
-                # aux[i-1] = [flow_prop(2) | valid(1) | mask_cur(2) | 0 0 0] for step i; all fb checks in one launch
-                # (step i >= 1 uses flow fidx[i] and the mask of frame order[i]: a reversed / shifted slice -- no index
-                # tensors, so the whole window is capturable in a hipGraph)
-                if name == "backward_1":
-                    fp_sel, fc_sel, m_sel = f_prop[:t - 1].flip(0), f_chk[:t - 1].flip(0), mask2[:t - 1].flip(0)
-                else:
-                    fp_sel, fc_sel, m_sel = f_prop[:t - 1], f_chk[:t - 1], mask2[1:]
-                aux = torch.zeros((t - 1, h, w, 8), dtype=dt, device=dev)
-                aux[..., :2] = fp_sel
-                aux[..., 3:5] = m_sel
-                chk = fc_sel.contiguous()
-                hip.fb_check(aux, chk, out=aux, out_choff=2)
             prop = None
             for i, idx in enumerate(order):
                 cur = cur_all[idx:idx + 1]
                 if i == 0:
                     prop = cur
                 else:
-                    ax = aux[i - 1:i]
+                    j = pair(i, idx)
+                    ax = aux[j:j + 1]
                     warped = hip.flow_warp(prop, ax, mode=interpolation)
                     o = L["off0"]([cur, warped, ax], act="lrelu", act_param=0.1)
                     o = L["off2"]([o], act="lrelu", act_param=0.1)
@@ -191,7 +201,7 @@ class _GenEngine:
             feats[name] = outs
             prev_name = name
         y = self.fuse0([feats["backward_1"], feats["forward_1"], mk8], act="lrelu", act_param=0.2)
-        return self.fuse2([y], residual=x)
+        return self.fuse2([y], residual=x, out=out)
 
     # ------------------------------------------------------------------ transformer
     def _window_tables(self, Hp, Wp):
@@ -212,25 +222,27 @@ class _GenEngine:
         mpad = torch.zeros((1, token_mask.shape[0], Hp, Wp), dtype=dt, device=dev)
         mpad[0, :, :fh, :fw] = token_mask
         wmask = hip.window_mask(mpad, *WIN)
-        tinds = [torch.arange(i, t, t_dilation, dtype=torch.int32, device=dev) for i in range(t_dilation)]
+        tkey = (t, t_dilation, str(dev))
+        if tkey not in self._tind_cache:
+            self._tind_cache[tkey] = [torch.arange(i, t, t_dilation, dtype=torch.int32, device=dev) for i in range(t_dilation)]
+        tinds = self._tind_cache[tkey]
         ypad = torch.zeros((t, Hp, Wp, c), dtype=dt, device=dev) if padded else None
         x = tok
         n_tok = t * fh * fw
         for i, B in enumerate(self.blocks):
-            y = hip.layernorm(x, *B["n1"])
-            if padded:
-                ypad[:, :fh, :fw] = y          # zero pad AFTER LayerNorm (:169-171): pad tokens' q/k/v = bias
-                y = ypad
+            if padded:       # zero pad AFTER LayerNorm (:169-171; pad tokens' q/k/v = bias): LayerNorm writes into the padded grid, whose
+                y = hip.layernorm_grid(x, *B["n1"], out=ypad)     # padding tokens were zero-filled once and are never written
+            else:
+                y = hip.layernorm(x, *B["n1"])
             qkv = B["qkv"]([y.view(1, 1, t * Hp * Wp, c)]).view(1, t, Hp, Wp, 3 * c)
             pooled = hip.depthwise_pool(y, B["pool_w"], B["pool_b"], 4)
             P = pooled.shape[1] * pooled.shape[2]
             pkv = B["kv"]([pooled.view(1, 1, t * P, c)]).view(1, t, P, 2 * c)
             att = hip.sparse_window_attention(
                 qkv, qkv[..., c:], qkv[..., 2 * c:], pkv, pkv[..., c:], own, rolled, tinds[i % t_dilation], wmask,
-                heads=HEADS, wh=WIN[0], ww=WIN[1], qkv_cstride=3 * c, pkv_cstride=2 * c, C_=c)
+                heads=HEADS, wh=WIN[0], ww=WIN[1], qkv_cstride=3 * c, pkv_cstride=2 * c, C_=c,
+                out_hw=(fh, fw) if padded else None)      # the crop of :276-277 happens in the kernel's store
             att = att[0]
-            if padded:
-                att = att[:, :fh, :fw].contiguous()
             x = B["proj"]([att.view(1, 1, n_tok, c)], residual=x.view(1, 1, n_tok, c)).view(t, fh, fw, c)
             y = hip.layernorm(x, *B["n2"])
             hid = B["fc1"]([y.view(1, 1, n_tok, c)])                      # [1,1,n_tok,1960]
@@ -278,16 +290,55 @@ class _GenEngine:
         token_mask = F.max_pool2d(dm_in, 7, 3, 3)[:, 0]                               # [l_t,fh,fw]
         if interpolation not in ("bilinear", "nearest"):
             raise ValueError(f"interpolation {interpolation!r}: 'bilinear' or 'nearest' (model/propainter.py:148)")
-        local = self.feature_propagation(enc[:l_t].contiguous(), dsf, dsb, mask2, interpolation)
-        enc = torch.cat([local, enc[l_t:]], 0) if t > l_t else local
-        tok = self.ss([enc])                                               # SoftSplit as one convolution
+        encw = torch.empty((t, h, w, 128), dtype=dt, device=dev)          # [propagated local frames | reference frames]
+        self.feature_propagation(enc[:l_t], dsf, dsb, mask2, interpolation, out=encw[:l_t])
+        if t > l_t:
+            encw[l_t:] = enc[l_t:]
+        return self._window_tail(encw, l_t, token_mask, t_dilation, H, W)
+
+    def _window_tail(self, encw, l_t, token_mask, t_dilation, H, W):
+        """SoftSplit -> transformer -> SoftComp -> decoder of one window (:351-372); encw [t,h,w,128]."""
+        t, h, w, _ = encw.shape
+        tok = self.ss([encw])                                              # SoftSplit as one convolution
         tok = self.transformer(tok, (h, w), token_mask, t_dilation)
         fh, fw = tok.shape[1], tok.shape[2]
         emb = self.sc_embed([tok.view(1, 1, t * fh * fw, HIDDEN)])          # [1,1,n,6272]
         folded = hip.fold_tokens(emb.view(t, fh * fw, 128 * 49), t, fh, fw, 128, h, w, normalize=False)
-        enc2 = self.sc_bias([folded], residual=enc)                        # bias_conv + (enc_feat + trans_feat)
-        out = self.decode(enc2[:l_t].contiguous())
+        enc2 = self.sc_bias([folded], residual=encw)                       # bias_conv + (enc_feat + trans_feat)
+        out = self.decode(enc2[:l_t])
         return out.view(1, l_t, 3, H, W)
+
+    # ------------------------------------------------------------------ per-clip cache (engine extension used by pipeline.run_clip)
+    def prepare_clip(self, frames, flows_bi, masks_in, masks_updated, interpolation="bilinear"):
+        """Everything the generator windows of ONE clip need that depends on a frame or a flow pair only -- encoder features, 1/4
+        resolution flows and masks, token masks, the per-pair rows of the propagation steps -- computed once per clip instead of once
+        per window (a frame sits in 2-3 windows as a local frame and in several more as a reference).  frames [1,L,3,H,W], flows
+        2 x [1,L-1,2,H,W], masks [1,L,1,H,W].  Same arithmetic on the same values as forward(): results are identical."""
+        b, L, _, H, W = frames.shape
+        assert b == 1
+        dt = self.dtype
+        enc = self.encode_frames(frames, masks_in, masks_updated)
+        dsf = (F.interpolate(flows_bi[0][0], scale_factor=1 / 4, mode="bilinear", align_corners=False) / 4.0).permute(0, 2, 3, 1).contiguous()
+        dsb = (F.interpolate(flows_bi[1][0], scale_factor=1 / 4, mode="bilinear", align_corners=False) / 4.0).permute(0, 2, 3, 1).contiguous()
+        dm_in = masks_in[0, :, :, ::4, ::4]
+        mask2 = torch.cat([dm_in, masks_updated[0, :, :, ::4, ::4]], 1).permute(0, 2, 3, 1).contiguous()        # [L,h,w,2]
+        aux_b, aux_f, mk8 = self.propagation_rows(dsf, dsb, mask2)
+        return dict(enc=enc, aux_b=aux_b, aux_f=aux_f, mk8=mk8, token_mask=F.max_pool2d(dm_in, 7, 3, 3)[:, 0].contiguous(),
+                    H=H, W=W, L=L, interpolation=interpolation)
+
+    def forward_window(self, clip, first, l_t, ref_index, t_dilation=2):
+        """The generator call of the window whose local frames are clip frames [first, first + l_t) and whose reference frames are
+        ref_index (int64 device tensor, may be empty) -> [1,l_t,3,H,W]; == forward() on the gathered inputs."""
+        enc = clip["enc"]
+        h, w = enc.shape[1], enc.shape[2]
+        n_ref = int(ref_index.numel())
+        encw = torch.empty((l_t + n_ref, h, w, 128), dtype=self.dtype, device=enc.device)
+        a, b = first, first + l_t
+        self.feature_propagation(enc[a:b], None, None, None, clip["interpolation"],
+                                 rows=(clip["aux_b"][a:b - 1], clip["aux_f"][a:b - 1], clip["mk8"][a:b]), out=encw[:l_t])
+        if n_ref:
+            torch.index_select(enc, 0, ref_index, out=encw[l_t:])
+        return self._window_tail(encw, l_t, clip["token_mask"][a:b], t_dilation, clip["H"], clip["W"])
 
     # ------------------------------------------------------------------ image propagation (:104-190, non-learnable)
     def img_propagation(self, frames, flows_f, flows_b, masks, interpolation):
@@ -383,6 +434,31 @@ class InpaintGenerator(nn.Module):
         dt = masked_frames.dtype
         eng = self._get_engine(dt, masked_frames.device)
         return eng.encode_frames(masked_frames, masks_in.to(dt), masks_updated.to(dt))
+
+    @hip.on_input_device
+    @torch.no_grad()
+    def prepare_clip(self, frames, completed_flows, masks_in, masks_updated, interpolation='bilinear'):
+        """Engine extension (not in the reference API): the per-clip cache of ``forward_window`` -- encoder features, 1/4-resolution
+        flows / masks, token masks and the propagation side inputs of EVERY frame / flow pair of a clip, computed once.
+        frames [1,L,3,H,W] (the updated frames), completed_flows 2 x [1,L-1,2,H,W], masks [1,L,1,H,W]."""
+        hip.require_gpu(frames, "InpaintGenerator")
+        if interpolation not in ("bilinear", "nearest"):
+            raise ValueError(f"interpolation {interpolation!r}: 'bilinear' or 'nearest' (model/propainter.py:148)")
+        dt = frames.dtype
+        if frames.shape[0] != 1 or frames.shape[3] % 8 or frames.shape[4] % 8:
+            raise ValueError(f"prepare_clip takes one clip [1,L,3,H,W] with H, W multiples of 8 (got {tuple(frames.shape)})")
+        eng = self._get_engine(dt, frames.device)
+        return eng.prepare_clip(frames, (completed_flows[0].to(dt), completed_flows[1].to(dt)), masks_in.to(dt), masks_updated.to(dt),
+                                interpolation)
+
+    @hip.on_input_device
+    @torch.no_grad()
+    def forward_window(self, clip, first, num_local_frames, ref_index, t_dilation=2):
+        """``forward`` of the window with local frames [first, first + num_local_frames) and reference frames ``ref_index`` (int64 device
+        tensor) of a clip prepared by ``prepare_clip``; returns [1,l_t,3,H,W] -- identical to ``forward`` on the gathered tensors."""
+        assert DEPTH % t_dilation == 0, 'wrong t_dilation input.'
+        enc = clip["enc"]
+        return self._get_engine(enc.dtype, enc.device).forward_window(clip, int(first), int(num_local_frames), ref_index, t_dilation)
 
     @hip.on_input_device
     @torch.no_grad()

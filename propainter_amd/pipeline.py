@@ -146,6 +146,12 @@ class Compositor:
         per operation, exactly like the reference (``(pred_img + 1) / 2`` on the device, ``* 255`` on a float16 / float32
         numpy array, truncation to uint8: inference_propainter.py:437-438,443) -- so the bytes equal the reference's
         for identical predictions in either precision (tests/test_host_logic_cpu.py::test_compositor_*)."""
+        if pred_img.is_cuda:      # one launch per window (pp_composite_window: same roundings, same bytes) instead of ~8 per frame
+            flags = [self.done[idx] for idx in neighbor_ids]
+            hip.composite_window(pred_img.contiguous(), self.bin, self.ori, self.comp, neighbor_ids, flags)
+            for idx in neighbor_ids:
+                self.done[idx] = True
+            return
         img = (pred_img + 1) / 2
         img = img.permute(0, 2, 3, 1) * 255
         img = img.to(torch.uint8)
@@ -230,9 +236,16 @@ def run_clip(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg: InferenceC
     updated_frames, updated_masks = propagate_images(model, frames, masks_dilated, pred_flows_bi, cfg.subvideo_length)
     mark('image_propagation')
     comp = Compositor(fr_u8, masks_dilated)
-    # engine extension: encode every frame once (the encoder is per-frame), windows take slices -- same results
-    enc_all = model.encode_frames(updated_frames, masks_dilated, updated_masks) if hasattr(model, "encode_frames") else None
+    # engine extension: everything of the generator windows that depends on a frame / flow pair only (encoder features, 1/4-resolution
+    # flows and masks, propagation side inputs) once per clip; a window then reads slices of it -- same results
+    clip_cache = model.prepare_clip(updated_frames, pred_flows_bi, masks_dilated, updated_masks) if hasattr(model, "prepare_clip") else None
+    enc_all = (model.encode_frames(updated_frames, masks_dilated, updated_masks)
+               if clip_cache is None and hasattr(model, "encode_frames") else None)
+    empty_ref = torch.zeros((0,), dtype=torch.long, device=device)
+
     def window(nb, ref):
+        if clip_cache is not None:                # (nb is a contiguous range of clip frames)
+            return model.forward_window(clip_cache, nb[0], len(nb), _dev_index(ref, device) if ref else empty_ref)
         ids = _dev_index(nb + ref, device)        # cached device index: no host->device copy per window (graph-safe)
         kw = {} if enc_all is None else {"enc_feat": enc_all.index_select(0, ids)}
         fl = slice(nb[0], nb[-1])                 # flows of the local pairs (nb is a contiguous range)

@@ -231,11 +231,13 @@ def _window_mask(mask, wh=5, ww=9):
 
 
 def _attention(q, k, v, pk, pv, own, rolled, tind, wmask, heads=4, wh=5, ww=9, qkv_cstride=None, pkv_cstride=None,
-               C_=None, impl=0):
+               C_=None, impl=0, out_hw=None):
     from tests.test_ops_gpu import _attention_reference
     C_ = q.shape[-1] if C_ is None else C_
     out = _attention_reference(q[..., :C_].float(), k[..., :C_].float(), v[..., :C_].float(), pk[..., :C_].float(),
                                pv[..., :C_].float(), own.long(), rolled.long(), tind.long(), wmask, heads)
+    if out_hw is not None:
+        out = out[:, :, :out_hw[0], :out_hw[1]].contiguous()
     return out.to(q.dtype)
 
 
@@ -250,6 +252,11 @@ def _fold_tokens(tokens, BT, fh, fw, Cc, H, W, normalize=False, act=hip.ACT_NONE
 
 def _layernorm(x, gamma, beta, eps=1e-5):
     return F.layer_norm(x.float(), (x.shape[-1],), gamma, beta, eps).to(x.dtype)
+
+
+def _layernorm_grid(x, gamma, beta, out, eps=1e-5):
+    out[:, :x.shape[1], :x.shape[2]] = F.layer_norm(x.float(), (x.shape[-1],), gamma, beta, eps).to(x.dtype)
+    return out
 
 
 def _depthwise_pool(x, weight, bias, k=4):
@@ -335,7 +342,7 @@ def emulated_device_ops():
         "sparse_window_attention": _attention, "fold_tokens": _fold_tokens, "layernorm": _layernorm,
         "depthwise_pool": _depthwise_pool, "instance_norm": _instance_norm, "upsample2x": _upsample2x,
         "dcn_offset_mask_act": _dcn_act, "gru_gate": _gru_gate, "nchw_to_nhwc": _nchw_to_nhwc, "nhwc_to_nchw": _nhwc_to_nchw,
-        "instance_norm_split": _instance_norm_split,
+        "instance_norm_split": _instance_norm_split, "layernorm_grid": _layernorm_grid,
     }
     patches["require_gpu"] = lambda t, who: None
     saved = {k: getattr(hip, k) for k in patches}

@@ -561,3 +561,27 @@ print('RCCL_SELF_OK', stats)
     r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
     out = r.stdout.decode(errors="replace")
     assert r.returncode == 0 and "RCCL_SELF_OK" in out, out[-3000:]
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16], ids=["f32", "f16"])
+def test_forward_window_of_a_prepared_clip_equals_forward(models, dt):
+    """InpaintGenerator.prepare_clip + forward_window (per-clip cache of encoder features, 1/4-resolution flows / masks and propagation
+    rows; what pipeline.run_clip uses) is the same arithmetic on the same values as forward() on the gathered window tensors: bit-identical,
+    incl. a padded token grid (64x104 -> 22x35 tokens, 25x36 padded) and a window without reference frames."""
+    gen = models[2]
+    gq = torch.Generator().manual_seed(31)
+    L, H, W = 7, 64, 104
+    fr = (torch.rand(1, L, 3, H, W, generator=gq) * 2 - 1).cuda().to(dt)
+    mk = torch.zeros(1, L, 1, H, W)
+    mk[:, :, :, 16:48, 24:80] = 1
+    mu = torch.zeros(1, L, 1, H, W)
+    mu[:, :, :, 24:40, 40:64] = 1
+    mk, mu = mk.cuda().to(dt), mu.cuda().to(dt)
+    fl = tuple((torch.randn(1, L - 1, 2, H, W, generator=gq) * 2).cuda().to(dt) for _ in range(2))
+    clip = gen.prepare_clip(fr * (1 - mk), fl, mk, mu)
+    for first, lt, ref in ((2, 4, [0, 6]), (0, 5, []), (3, 4, [0])):
+        ids = torch.tensor(list(range(first, first + lt)) + ref, device="cuda")
+        want = gen((fr * (1 - mk))[:, ids], (fl[0][:, first:first + lt - 1], fl[1][:, first:first + lt - 1]), mk[:, ids], mu[:, ids], lt)
+        got = gen.forward_window(clip, first, lt, torch.tensor(ref, dtype=torch.long, device="cuda"))
+        torch.cuda.synchronize()
+        assert got.shape == want.shape == (1, lt, 3, H, W) and torch.equal(got, want), (first, lt, ref, (got.float() - want.float()).abs().max().item())
