@@ -415,8 +415,12 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnParams p) {
 
 // Persistent launch for the masked windows (the long key lists: ~all of the attention time).  With the grid-mapped
 // launch the working blocks (25 % of the grid at the benchmark mask) land unevenly on the CUs and the slowest CU runs 3
-// rounds where 2 would do.  Here a compacted list of masked windows (attn_compact_kernel) is walked by 2 blocks per CU with a
-// fixed stride; consecutive items are the query blocks of one (window, head), so they share their K/V rows in L2.
+// rounds where 2 would do.  Here a compacted list of masked windows (attn_compact_kernel) is walked by 2 blocks per CU.
+// Items are ordered (window, head, query block): the ~7 query blocks of one (window, head) read the SAME K / V rows, neighbouring
+// windows share their 148 rolled rows.  Consecutive block ids sit on different XCDs (id mod 8), each with its own L2, so every XCD
+// gets one CONTIGUOUS eighth of the item list and its blocks walk it with a stride of blocks-per-XCD: at any moment an XCD works on
+// ~64 consecutive items = ~9 (window, head) groups, whose rows are fetched into that L2 once (round 2's flat stride spread the
+// query blocks of a group over 7 XCDs: PMC fabric traffic 2.05x the algorithmic bytes, profiles/r2v_hbm_traffic_720p.json).
 template <int QT, bool PROF = false>
 __global__ __launch_bounds__(256, 2) void attn_mfma_persistent_kernel(const AttnParams p, const int gy) {
   __shared__ __attribute__((aligned(16))) _Float16 Ks[KT * KS_LD];
@@ -425,7 +429,11 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_persistent_kernel(const Attn
   __shared__ int tind_lds[64];
   __shared__ int koff_lds[256];
   const int total = p.work[0] * p.heads * gy;
-  for (int item = blockIdx.x; item < total; item += gridDim.x) {
+  const int nxb = gridDim.x >> 3, xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;     // (gridDim.x is a multiple of 8)
+  const int chunk = (total + 7) >> 3;
+  for (int it = loc; it < chunk; it += nxb) {
+    const int item = xcd * chunk + it;
+    if (item >= total) break;
     const int yb = item % gy;
     const int wh = item / gy;
     const int head = wh % p.heads;
@@ -571,8 +579,8 @@ extern "C" int pp_sparse_window_attention(const pp_attn_args_t* a, void* stream)
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
         if (n_cu <= 0) n_cu = 256;
       }
-      if (a->impl == 5) hipLaunchKernelGGL((attn_mfma_persistent_kernel<2, true>), dim3(2 * n_cu), dim3(256), 0, st, p, (int)gy_m);
-      else hipLaunchKernelGGL((attn_mfma_persistent_kernel<2>), dim3(2 * n_cu), dim3(256), 0, st, p, (int)gy_m);
+      if (a->impl == 5) hipLaunchKernelGGL((attn_mfma_persistent_kernel<2, true>), dim3((2 * n_cu + 7) / 8 * 8), dim3(256), 0, st, p, (int)gy_m);
+      else hipLaunchKernelGGL((attn_mfma_persistent_kernel<2>), dim3((2 * n_cu + 7) / 8 * 8), dim3(256), 0, st, p, (int)gy_m);
     } else {
       hipLaunchKernelGGL((attn_mfma_kernel<2, true>), dim3(gx, gy_m), dim3(256), 0, st, p);
     }
