@@ -164,7 +164,12 @@ __global__ __launch_bounds__(256, 2) void conv_dcn_patch_kernel(const ConvParams
       shift_x = (int)red[9];
     }
     // ---- stage the 32-channel patch: rows [py0, py0 + PH), columns [px0, px0 + PW); 16-byte slot c of patch pixel i is
-    //      stored at slot (c + (i >> 2)) & 3 (16 consecutive positions x one slot = 16 distinct banks groups)
+    //      stored at slot (c + 2 * (i >> 2)) & 3.  A corner read is a ds_read_b128 by lane (pixel l15, channel slot l4); the hardware
+    //      serves it in the lane groups {0-3, 12-15, 20-27}, ... = pixels {0-3, 12-15} of slot l4 = 0 with pixels {4-11} of slot 1: for a
+    //      smooth offset field the 16 lanes hit 16 consecutive patch pixels, whose (pixel & 3, physical slot) pairs must all differ.
+    //      With the rotation (c + (i >> 2)) the pixels 12-15 of slot 0 and 8-11 of slot 1 met in the same banks (2-way conflict on
+    //      half of the lanes: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.50, profiles/r2p_lds_conflicts.txt); 2 * (i >> 2) separates
+    //      them for every alignment of the 16 pixels (tools/lds_swizzle_check.py, tests/test_host_logic_cpu.py).
     const int py0 = ty0 - 1 - DCN_R0 + 1 + shift_y - 0, px0 = tx0 - 1 - DCN_R0 + 1 + shift_x - 0;   // = tile origin - 6 + shift
     if (!(dbg & 2)) {
       constexpr int NC = DCN_PH * DCN_PW * 4, ITER = (NC + 255) / 256, BATCH = 5;
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void conv_dcn_patch_kernel(const ConvParams
         for (int k = 0; k < BATCH; ++k) {
           const int i = tid + (k0 + k) * 256;
           const int pi = i >> 2, c = i & 3;
-          if (i < NC) *reinterpret_cast<u32x4*>(patch + pi * 64 + (((c + (pi >> 2)) & 3) << 4)) = vp[k];
+          if (i < NC) *reinterpret_cast<u32x4*>(patch + pi * 64 + (((c + 2 * (pi >> 2)) & 3) << 4)) = vp[k];
         }
       }
     }
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(256, 2) void conv_dcn_patch_kernel(const ConvParams
             for (int c = 0; c < 4; ++c) {
               const int pi = pi0 + (c >> 1) * DCN_PW + (c & 1);
               const u32x4 raw = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(
-                  (const __attribute__((address_space(3))) char*)patch + pi * 64 + (((l4 + (pi >> 2)) & 3) << 4));
+                  (const __attribute__((address_space(3))) char*)patch + pi * 64 + (((l4 + 2 * (pi >> 2)) & 3) << 4));
               const h2* hv = reinterpret_cast<const h2*>(&raw);
               const h2 wv = h2{hw[c], hw[c]};
 #pragma unroll

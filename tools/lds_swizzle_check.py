@@ -36,6 +36,10 @@ CASES = [
     ("halo patch, 128-B rows, slot ^ (row & 7)         [shipped]", lambda r, kk, s: r * 128 + (((kk * 4 + s) ^ (r & 7)) << 4), range(64), (0, 1)),
     ("weight tile, 128-B rows, slot ^ ((row >> 1) & 7), 16-aligned", lambda r, kk, s: r * 128 + (((kk * 4 + s) ^ ((r >> 1) & 7)) << 4), range(0, 64, 16), (0, 1)),
     ("64-B rows (32-channel blocks), slot ^ ((row >> 1) & 2)", lambda r, kk, s: r * 64 + ((s ^ ((r >> 1) & 2)) << 4), range(64), (0,)),
+    # deformable-conv patch (conv_dcn.hip): 64-B pixel rows, a corner read = pixel r (16 consecutive patch pixels when the offsets of a
+    # tile row move together), channel slot s
+    ("dcn patch, 64-B rows, (slot + (pixel >> 2)) & 3      [round 2]", lambda r, kk, s: r * 64 + (((s + (r >> 2)) & 3) << 4), range(64), (0,)),
+    ("dcn patch, 64-B rows, (slot + 2 * (pixel >> 2)) & 3  [shipped dcn]", lambda r, kk, s: r * 64 + (((s + 2 * (r >> 2)) & 3) << 4), range(64), (0,)),
 ]
 
 if __name__ == "__main__":
