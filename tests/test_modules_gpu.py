@@ -32,6 +32,7 @@ def check(name, got, ref, rtol, atol=0.0):
     assert got.shape == ref.shape, (name, got.shape, ref.shape)
     err = (got - ref).abs().max().item()
     lim = rtol * ref.abs().max().item() + atol
+    print(f"MODULE_PARITY {name} [{str(got.dtype).replace('torch.', '')}]: max|d| {err:.3e} = {err / max(ref.abs().max().item(), 1e-12):.2e} of range (limit {rtol:.0e})")
     assert math.isfinite(err) and err <= lim, report(name, got, ref) + f" limit {lim:.3e}"
 
 
@@ -105,7 +106,8 @@ def test_image_propagation_is_bit_exact_fp32(models):
 
 
 def test_generator_vs_oracle_odd_sizes_fp32(models, sds):
-    """Token grid 17x27 -> padded to 20x27 windows (pad_b > 0), t even/odd T_ind split, all-masked local frame."""
+    """H = 64, W = 104 -> token grid 22x35, padded to 25x36 windows (pad_b = 3, pad_r = 1: both pads exercised), t even/odd T_ind
+    split, masked and unmasked windows."""
     gen = models[2]
     gq = torch.Generator().manual_seed(31)
     H, W, t, lt = 64, 104, 4, 2
@@ -119,7 +121,7 @@ def test_generator_vs_oracle_odd_sizes_fp32(models, sds):
     check("generator_odd", out, ref, 1e-3)
 
 
-# end-to-end PSNR floors (dB, composited uint8 frames vs the REAL reference's golden): (stages fp16?, RAFT precision)
+# end-to-end PSNR floors (dB, composited uint8 frames vs the golden of the oracle's restated driver, see the test's docstring): (stages fp16?, RAFT precision)
 # -> floor = 3 dB under the value measured on MI355X (profiles/r2_parity_e2e.json); fp32 measures > 90 dB.
 # measured: f32/f32 94.0, f32/f16x3 92.8, f16 stages 67.3 with any RAFT precision (max |d| = 1 byte in every configuration)
 E2E_PSNR_FLOOR = {(False, "f32"): 91.0, (False, "f16x3"): 89.8, (True, "f32"): 64.3, (True, "f16x3"): 64.3, (True, "f16"): 64.3}
@@ -128,8 +130,10 @@ E2E_PSNR_FLOOR = {(False, "f32"): 91.0, (False, "f16x3"): 89.8, (True, "f32"): 6
 @pytest.mark.parametrize("fp16,raft_prec", sorted(E2E_PSNR_FLOOR), ids=lambda v: str(v))
 def test_end_to_end_clip_vs_golden(models, fp16, raft_prec):
     """Whole path (RAFT -> completion -> image propagation -> windows -> blend) at 128x192x10 with sub-video
-    chunking active, at every precision configuration the CLI / bench can run -- incl. the headline one (fp16 stages,
-    fp16 RAFT) -- compared with the REAL reference driver's composited uint8 frames by PSNR."""
+    chunking active, at every precision configuration the CLI / bench can run -- incl. the headline one (fp16 stages, split-plane
+    f16x3 RAFT) -- compared by PSNR with the composited uint8 frames of the ORACLE'S restated driver (oracle.inpaint_video, the
+    statement-by-statement restatement of inference_propainter.py:298-452, run on the stage functions that are pinned to the REAL
+    reference's goldens; the reference's own driver cannot be imported here: top-level cv2 / imageio -- oracle/make_golden.py:80-90)."""
     from propainter_amd.pipeline import InferenceConfig, run_clip
     g = load_golden("e2e_128x192.npz")
     cfg = InferenceConfig(raft_iter=int(g["raft_iter"]), subvideo_length=int(g["subvideo_length"]),
