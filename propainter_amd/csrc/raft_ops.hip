@@ -17,64 +17,95 @@ __global__ void corr_avgpool_kernel(const float* __restrict__ in, float* __restr
   }
 }
 
-// One 256-thread block per source pixel, one wave per pyramid level.  The wave stages the 10x10 patch
-// around (x/2^l, y/2^l) in LDS (zeros outside the map), then 81 lanes-outputs blend 4 neighbours with the
-// common fractional weights.  Output channel l*81 + a*9 + b <- sample (x + a - 4, y + b - 4).
-// SPLIT (TO = _Float16): split-plane output -- hi = fp16(v) at channel i, lo = fp16(v - hi) at channel i + ocs / 2 (PP_F16S)
+// One WAVE per source pixel, pixels walked with a grid stride by long-lived blocks (round 2: one 256-thread block per pixel, one
+// wave per level, a block barrier between staging and blending -- 504 000 four-wave blocks per launch of the 720p chunk, each wave
+// with two dependent 4-byte loads in flight: 0.87 ms per launch = 1.5 TB/s of algorithmic bytes).  Per pixel the wave issues the eight
+// load rounds of all four levels (10 x 10 positions each, lanes along the rows: 40-byte row segments) back to back, parks them in a
+// wave-private LDS patch (zeros outside the map), then blends its 324 outputs -- 4 neighbours with the reference's per-tap coordinate
+// round trip (bilinear_sampler's 2c / (W - 1) - 1 normalisation, RAFT/utils/utils.py:61-65) -- and stores them as full rows.
+// Output channel l*81 + a*9 + b <- sample (x / 2^l + a - 4, y / 2^l + b - 4): a moves x (RAFT/corr.py:36-43).
+// SPLIT (TO = _Float16): split-plane output -- hi = fp16(v) at channel i, lo = fp16(v - hi) at channel i + ocs / 2 (PP_F16S).
 template <typename TO, bool SPLIT = false>
 __global__ __launch_bounds__(256) void corr_lookup_kernel(const float* __restrict__ l0, const float* __restrict__ l1,
                                                           const float* __restrict__ l2, const float* __restrict__ l3,
                                                           const float* __restrict__ coords, TO* __restrict__ out,
-                                                          int ocs, int ocpad, int h, int w) {
-  __shared__ float patch[4][10][11];
-  const long long pix = blockIdx.x;
-  const int lvl = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const float* base = lvl == 0 ? l0 : lvl == 1 ? l1 : lvl == 2 ? l2 : l3;
-  const int Hl = h >> lvl, Wl = w >> lvl;
-  const float* map = base + pix * (long long)Hl * Wl;
-  const float scale = 1.f / (float)(1 << lvl);
-  // bilinear_sampler normalises with 2c/(W-1)-1 and grid_sample maps back (RAFT/utils/utils.py:61-65)
-  const float cx = coords[pix * 2] * scale, cy = coords[pix * 2 + 1] * scale;
-  // all 81 taps share the fractional part when computed on the un-shifted centre; to stay faithful to
-  // the reference's per-tap round trip we evaluate the round trip per tap below, but stage the patch from
-  // the floor of the centre (taps are centre + integer, so floor(tap) = floor(centre) + integer up to
-  // 1-ulp effects that only move weight between two staged neighbours).
-  const int x0 = (int)floorf(cx) - 4, y0 = (int)floorf(cy) - 4;
-  for (int i = lane; i < 100; i += 64) {
-    const int r = i / 10, c = i % 10;
-    const int yy = y0 + r, xx = x0 + c;
-    patch[lvl][r][c] = (yy >= 0 && yy < Hl && xx >= 0 && xx < Wl) ? map[(long long)yy * Wl + xx] : 0.f;
-  }
-  __syncthreads();
-  TO* op = out + pix * ocs + lvl * 81;
-  for (int i = lane; i < 81; i += 64) {
-    const int a = i / 9, b = i % 9;           // a moves x, b moves y
-    const float px = grid_roundtrip(cx + (float)(a - 4), Wl);
-    const float py = grid_roundtrip(cy + (float)(b - 4), Hl);
-    const float fx = floorf(px), fy = floorf(py);
-    const float lx = px - fx, ly = py - fy;
-    int c0 = (int)fx - x0, r0 = (int)fy - y0;  // position inside the staged patch
-    float v = 0.f;
+                                                          int ocs, int ocpad, int h, int w, long long npix) {
+  __shared__ float patch_all[4][4][10][11];                    // [wave][level][row][col]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float (*patch)[10][11] = patch_all[wave];
+  for (long long pix = (long long)blockIdx.x * 4 + wave; pix < npix; pix += (long long)gridDim.x * 4) {
+    const float cx0 = coords[pix * 2], cy0 = coords[pix * 2 + 1];
+    // ---- stage: all loads of the pixel first (one exposed latency), then the LDS writes
+    float v[4][2];
+    int x0s[4], y0s[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int rr = r0 + (k >> 1), cc = c0 + (k & 1);
-      const float wgt = ((k & 1) ? lx : 1.f - lx) * ((k >> 1) ? ly : 1.f - ly);
-      float s = 0.f;
-      if (rr >= 0 && rr < 10 && cc >= 0 && cc < 10) s = patch[lvl][rr][cc];
-      else {
-        const int yy = y0 + rr, xx = x0 + cc;   // 1-ulp spill outside the staged window: read directly
-        if (yy >= 0 && yy < Hl && xx >= 0 && xx < Wl) s = map[(long long)yy * Wl + xx];
+    for (int lvl = 0; lvl < 4; ++lvl) {
+      const float* base = lvl == 0 ? l0 : lvl == 1 ? l1 : lvl == 2 ? l2 : l3;
+      const int Hl = h >> lvl, Wl = w >> lvl;
+      const float* map = base + pix * (long long)Hl * Wl;
+      const float scale = 1.f / (float)(1 << lvl);
+      // all 81 taps share the fractional part when computed on the un-shifted centre; to stay faithful to the reference's per-tap
+      // round trip it is evaluated per tap below, the patch is staged from the floor of the centre (taps are centre + integer, so
+      // floor(tap) = floor(centre) + integer up to 1-ulp effects that only move weight between two staged neighbours)
+      const int x0 = (int)floorf(cx0 * scale) - 4, y0 = (int)floorf(cy0 * scale) - 4;
+      x0s[lvl] = x0; y0s[lvl] = y0;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int i = lane + 64 * k;
+        const int r = i / 10, c = i - r * 10;
+        const int yy = y0 + r, xx = x0 + c;
+        v[lvl][k] = (i < 100 && yy >= 0 && yy < Hl && xx >= 0 && xx < Wl) ? map[(long long)yy * Wl + xx] : 0.f;
       }
-      v += wgt * s;
     }
-    op[i] = from_f32<TO>(v);
-    if constexpr (SPLIT) op[i + ocs / 2] = from_f32<TO>(v - to_f32(from_f32<TO>(v)));
-  }
-  if (lvl == 3)
+#pragma unroll
+    for (int lvl = 0; lvl < 4; ++lvl)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int i = lane + 64 * k;
+        if (i < 100) patch[lvl][i / 10][i % 10] = v[lvl][k];
+      }
+    // (the patch is wave-private and LDS operations of one wave execute in order: no barrier)
+    TO* op = out + pix * ocs;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int i = lane + 64 * k;                 // output channel
+      if (i >= 324) break;
+      const int lvl = i / 81, j = i - lvl * 81;
+      const int a = j / 9, b = j - a * 9;          // a moves x, b moves y
+      const int Hl = h >> lvl, Wl = w >> lvl;
+      const float scale = 1.f / (float)(1 << lvl);
+      const float cx = cx0 * scale, cy = cy0 * scale;
+      const float px = grid_roundtrip(cx + (float)(a - 4), Wl);
+      const float py = grid_roundtrip(cy + (float)(b - 4), Hl);
+      const float fx = floorf(px), fy = floorf(py);
+      const float lx = px - fx, ly = py - fy;
+      const int x0 = lvl == 0 ? x0s[0] : lvl == 1 ? x0s[1] : lvl == 2 ? x0s[2] : x0s[3];
+      const int y0 = lvl == 0 ? y0s[0] : lvl == 1 ? y0s[1] : lvl == 2 ? y0s[2] : y0s[3];
+      const int c0 = (int)fx - x0, r0 = (int)fy - y0;  // position inside the staged patch
+      float acc = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int rr = r0 + (q >> 1), cc = c0 + (q & 1);
+        const float wgt = ((q & 1) ? lx : 1.f - lx) * ((q >> 1) ? ly : 1.f - ly);
+        float s = 0.f;
+        if (rr >= 0 && rr < 10 && cc >= 0 && cc < 10) s = patch[lvl][rr][cc];
+        else {
+          const int yy = y0 + rr, xx = x0 + cc;   // 1-ulp spill outside the staged window: read directly
+          if (yy >= 0 && yy < Hl && xx >= 0 && xx < Wl) {
+            const float* base = lvl == 0 ? l0 : lvl == 1 ? l1 : lvl == 2 ? l2 : l3;
+            s = base[pix * (long long)Hl * Wl + (long long)yy * Wl + xx];
+          }
+        }
+        acc += wgt * s;
+      }
+      op[i] = from_f32<TO>(acc);
+      if constexpr (SPLIT) op[i + ocs / 2] = from_f32<TO>(acc - to_f32(from_f32<TO>(acc)));
+    }
     for (int i = 324 + lane; i < ocpad; i += 64) {
-      out[pix * ocs + i] = from_f32<TO>(0.f);
-      if constexpr (SPLIT) out[pix * ocs + ocs / 2 + i] = from_f32<TO>(0.f);
+      op[i] = from_f32<TO>(0.f);
+      if constexpr (SPLIT) op[ocs / 2 + i] = from_f32<TO>(0.f);
     }
+  }
 }
 
 // One thread per fine output pixel pair (both flow channels): softmax over the 9 mask logits of its
@@ -137,15 +168,18 @@ extern "C" int pp_corr_lookup(const float* lvl0, const float* lvl1, const float*
              "pp_corr_lookup: split-plane output needs an even cstride with cstride / 2 >= out_cpad");
   const long long npix = (long long)B * h * w;
   hipStream_t st = (hipStream_t)stream;
+  // one wave per pixel, 4 waves per block, blocks walk the pixels with a grid stride: enough blocks to fill every CU eight times
+  const long long want = (npix + 3) / 4;
+  const unsigned lk_grid = (unsigned)(want < 256 * 8 ? want : 256 * 8);
   if (out_dtype == PP_F16S)
-    hipLaunchKernelGGL((corr_lookup_kernel<_Float16, true>), dim3((unsigned)npix), dim3(256), 0, st, lvl0, lvl1, lvl2, lvl3, coords,
-                       (_Float16*)out, out_cstride, out_cpad, h, w);
+    hipLaunchKernelGGL((corr_lookup_kernel<_Float16, true>), dim3(lk_grid), dim3(256), 0, st, lvl0, lvl1, lvl2, lvl3, coords,
+                       (_Float16*)out, out_cstride, out_cpad, h, w, npix);
   else if (out_dtype == PP_F16)
-    hipLaunchKernelGGL((corr_lookup_kernel<_Float16>), dim3((unsigned)npix), dim3(256), 0, st, lvl0, lvl1, lvl2, lvl3, coords,
-                       (_Float16*)out, out_cstride, out_cpad, h, w);
+    hipLaunchKernelGGL((corr_lookup_kernel<_Float16>), dim3(lk_grid), dim3(256), 0, st, lvl0, lvl1, lvl2, lvl3, coords,
+                       (_Float16*)out, out_cstride, out_cpad, h, w, npix);
   else
-    hipLaunchKernelGGL((corr_lookup_kernel<float>), dim3((unsigned)npix), dim3(256), 0, st, lvl0, lvl1, lvl2, lvl3, coords,
-                       (float*)out, out_cstride, out_cpad, h, w);
+    hipLaunchKernelGGL((corr_lookup_kernel<float>), dim3(lk_grid), dim3(256), 0, st, lvl0, lvl1, lvl2, lvl3, coords,
+                       (float*)out, out_cstride, out_cpad, h, w, npix);
   return launch_status("pp_corr_lookup");
 }
 
