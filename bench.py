@@ -391,10 +391,15 @@ def main():
     if rank == 0 and not args.no_profile and not use_ranks:
         marks = []
 
+        stage_peaks = {}
+
         def hook(name):
             e = torch.cuda.Event(enable_timing=True)
             e.record()
             marks.append((name, e, time.perf_counter()))
+            # peak of live device memory inside the stage that just ended (caching-allocator statistics: no synchronisation)
+            stage_peaks[name] = torch.cuda.max_memory_allocated(dev) / 1e9
+            torch.cuda.reset_peak_memory_stats(dev)
         with hip.KernelProfiler(detail=args.detail) as kp:
             t1 = time.perf_counter()
             # windows serialised on one stream here: a launch's event pair then brackets that launch alone (with
@@ -432,6 +437,7 @@ def main():
         else:
             roof = dict(common, bound="hbm", achieved=v["gbs"], peak=PEAK_HBM_GBS, unit="GB/s", frac=v["gbs"] / PEAK_HBM_GBS)
         stages["instrumented_step_wall_ms"] = prof_wall * 1e3
+        stages["peak_allocated_GB_by_stage"] = {k: v for k, v in stage_peaks.items() if k != "start"}
 
     # ---- the pass at the other RAFT precisions, submitted the same way as the headline (own hipGraph, mean of 2 replays
     # after one untimed replay); the reference's own RAFT arithmetic is fp32

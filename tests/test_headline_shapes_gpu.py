@@ -19,9 +19,10 @@ from tests.helpers import report, seeded_models, seeded_sds
 
 pytestmark = pytest.mark.gpu
 
-# (rtol of the output range).  fp32: north_star's bar.  fp16: the stated fp16 tolerance of the feed-forward stages; the values
-# measured on MI355X are printed by every run (HEADLINE_PARITY lines) and recorded in profiles/r3_parity_headline_shapes.txt
-RTOL = {torch.float32: 1e-3, torch.float16: 3e-2}
+# (rtol of the output range).  fp32: north_star's bar (measured on MI355X: 2.6e-6 flow completion, 1.4e-5 / 2.5e-5 generator at 720p /
+# 1080p).  fp16: the stated fp16 tolerance = twice the largest value measured for the stage (flow completion 1.7e-3 / 1.9e-3, generator
+# 8.6e-3 / 9.4e-3 at 720p / 1080p); every run prints its own values (HEADLINE_PARITY lines; profiles/r3_parity_headline_shapes.txt)
+RTOL = {torch.float32: {"fc": 1e-3, "gen": 1e-3}, torch.float16: {"fc": 4e-3, "gen": 2e-2}}
 
 
 @pytest.fixture(scope="module")
@@ -92,8 +93,8 @@ def test_flow_completion_chunk_720p_vs_oracle(models, sds, dt):
     (pf, pb), _ = models[1].forward_bidirect_flow((fl[0].cuda().to(dt), fl[1].cuda().to(dt)), m.cuda().to(dt))
     torch.cuda.synchronize()
     name = "f32" if dt == torch.float32 else "f16"
-    rel_check(f"fc720_{name}_fwd", pf, ref[0], RTOL[dt])
-    rel_check(f"fc720_{name}_bwd", pb, ref[1], RTOL[dt])
+    rel_check(f"fc720_{name}_fwd", pf, ref[0], RTOL[dt]["fc"])
+    rel_check(f"fc720_{name}_bwd", pb, ref[1], RTOL[dt]["fc"])
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.float16], ids=["f32", "f16"])
@@ -104,7 +105,7 @@ def test_generator_window_720p_vs_oracle(models, sds, dt):
     out = models[2]((fr * (1 - mk)).cuda().to(dt), (gfl[0].cuda().to(dt), gfl[1].cuda().to(dt)), mk.cuda().to(dt), mu.cuda().to(dt), lt)
     torch.cuda.synchronize()
     assert out.shape == ref.shape == (1, lt, 3, 720, 1280)
-    rel_check(f"gen720_{'f32' if dt == torch.float32 else 'f16'}", out, ref, RTOL[dt])
+    rel_check(f"gen720_{'f32' if dt == torch.float32 else 'f16'}", out, ref, RTOL[dt]["gen"])
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.float16], ids=["f32", "f16"])
@@ -115,7 +116,7 @@ def test_generator_window_1080p_vs_oracle(models, sds, dt):
     out = models[2]((fr * (1 - mk)).cuda().to(dt), (gfl[0].cuda().to(dt), gfl[1].cuda().to(dt)), mk.cuda().to(dt), mu.cuda().to(dt), lt)
     torch.cuda.synchronize()
     assert out.shape == ref.shape == (1, lt, 3, 1080, 1920)
-    rel_check(f"gen1080_{'f32' if dt == torch.float32 else 'f16'}", out, ref, RTOL[dt])
+    rel_check(f"gen1080_{'f32' if dt == torch.float32 else 'f16'}", out, ref, RTOL[dt]["gen"])
 
 
 def test_flow_completion_chunk_1080p_vs_oracle(models, sds):
@@ -123,5 +124,5 @@ def test_flow_completion_chunk_1080p_vs_oracle(models, sds):
     fl, m, ref = _fc_case(sds, 1080, 1920)
     (pf, pb), _ = models[1].forward_bidirect_flow((fl[0].cuda().half(), fl[1].cuda().half()), m.cuda().half())
     torch.cuda.synchronize()
-    rel_check("fc1080_f16_fwd", pf, ref[0], RTOL[torch.float16])
-    rel_check("fc1080_f16_bwd", pb, ref[1], RTOL[torch.float16])
+    rel_check("fc1080_f16_fwd", pf, ref[0], RTOL[torch.float16]["fc"])
+    rel_check("fc1080_f16_bwd", pb, ref[1], RTOL[torch.float16]["fc"])

@@ -1,8 +1,12 @@
 """Stage-level parity on the GPU: our drop-in modules (HIP engine) against the golden vectors produced by the
 REAL reference (tests/golden/*.npz) and against the CPU oracle on fresh seeded inputs.
 
-Tolerances (stated per north_star): fp32 engine 1e-3 of the output range; fp16 engine (fp16 storage + MFMA, fp32
-accumulate) 3e-2 of the range for the feed-forward stages; RAFT in fp16 is judged by end-point error in pixels."""
+Tolerances: fp32 engine 1e-3 of the output range (north_star's bar; measured on MI355X: <= 2.5e-5 everywhere).  fp16 engine (fp16
+storage + MFMA, fp32 accumulate), the STATED fp16 tolerance = twice the largest value measured on MI355X for the stage (printed by every
+run as MODULE_PARITY / HEADLINE_PARITY lines, recorded in profiles/r3_parity_headline_shapes.txt): flow completion 4e-3 of the range
+(measured 1.4e-3 at 64x96 ... 1.9e-3 at 1080x1920), generator 2e-2 (measured 5.1e-3 at 64x96, 7.2e-3 at 240x432, 8.6e-3 at 720x1280,
+9.4e-3 at 1080x1920).  RAFT in fp16 is judged by end-point error in pixels."""
+FP16_RTOL = {"fc": 4e-3, "gen": 2e-2}
 import math
 import os
 
@@ -73,7 +77,7 @@ def test_flow_completion_matches_reference_golden(models, dt):
     cf, cb = fc.combine_flow(fl, (pf, pb), m)
     torch.cuda.synchronize()
     assert edges == [None, None] and pf.dtype == dt
-    rt = 1e-3 if dt == torch.float32 else 3e-2
+    rt = 1e-3 if dt == torch.float32 else FP16_RTOL["fc"]
     check("fc_pred_f", pf, torch.from_numpy(g["pred_f"]), rt)
     check("fc_pred_b", pb, torch.from_numpy(g["pred_b"]), rt)
     check("fc_comb_f", cf, torch.from_numpy(g["comb_f"]), rt)
@@ -88,7 +92,7 @@ def test_generator_matches_reference_golden(models, dt):
     out = gen(fr * (1 - mk), fl, mk, mu, int(g["lt"]))
     torch.cuda.synchronize()
     assert out.shape == (1, 3, 3, 64, 96) and out.dtype == dt
-    check("generator", out, torch.from_numpy(g["out"]), 1e-3 if dt == torch.float32 else 3e-2)
+    check("generator", out, torch.from_numpy(g["out"]), 1e-3 if dt == torch.float32 else FP16_RTOL["gen"])
 
 
 def test_image_propagation_is_bit_exact_fp32(models):
@@ -214,7 +218,7 @@ def test_stages_at_432x240_vs_oracle(models, sds, dt):
     ref_p = O.fc_forward_bidirect(sds["fc"], fl, m)
     (pf, pb), _ = fc.forward_bidirect_flow((fl[0].cuda().to(dt), fl[1].cuda().to(dt)), m.cuda().to(dt))
     torch.cuda.synchronize()
-    rt = 1e-3 if dt == torch.float32 else 3e-2
+    rt = 1e-3 if dt == torch.float32 else FP16_RTOL["fc"]
     check("fc240_f", pf, ref_p[0], rt)
     check("fc240_b", pb, ref_p[1], rt)
     tt, lt = 7, 5
@@ -227,7 +231,7 @@ def test_stages_at_432x240_vs_oracle(models, sds, dt):
     ref = O.generator_forward(sds["gen"], fr * (1 - mk), gfl, mk, mu, lt)
     out = gen((fr * (1 - mk)).cuda().to(dt), (gfl[0].cuda().to(dt), gfl[1].cuda().to(dt)), mk.cuda().to(dt), mu.cuda().to(dt), lt)
     torch.cuda.synchronize()
-    check("gen240", out, ref, rt)
+    check("gen240", out, ref, 1e-3 if dt == torch.float32 else FP16_RTOL["gen"])
 
 
 @pytest.mark.parametrize("fp16", [False, True], ids=["f32", "f16"])
