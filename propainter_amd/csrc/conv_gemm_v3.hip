@@ -21,8 +21,31 @@
 //        keeps ((row >> 1) & 7): its fragments start at multiples of 16 rows.
 //   4 waves (2 x 2), wave tile 64 px x BN/2 couts, v_mfma_f32_16x16x32_f16, fp32 accumulate.  Epilogue as in v2.
 #include "conv_halo.h"
+#include <stdlib.h>
 
 namespace pp {
+
+// 64-cout tiles run with wave-private weight stages (conv_halo.h, PRIVB: no block barrier inside a channel block) unless
+// PP_HALO_SHARED_WEIGHTS=1 asks for the shared-stage form (A/B runs); 128-cout tiles always share their stages.
+static bool halo_shared_weights() {
+  static const bool v = getenv("PP_HALO_SHARED_WEIGHTS") != nullptr && getenv("PP_HALO_SHARED_WEIGHTS")[0] == '1';
+  return v;
+}
+template <int TH, int TW, int KH, int KW>
+static int launch_plain_k(const ConvParams& p, bool n64, hipStream_t stream) {
+  if (!n64) return launch_v3<TH, TW, KH, KW, 128>(p, stream);
+  return halo_shared_weights() ? launch_v3<TH, TW, KH, KW, 64>(p, stream) : launch_v3<TH, TW, KH, KW, 64, false, 0, 64, false, true>(p, stream);
+}
+static int launch_plain(const ConvParams& p, int kh, int kw, bool n64, hipStream_t stream) {
+  if (kh == 3 && kw == 3) return launch_plain_k<8, 16, 3, 3>(p, n64, stream);
+  if (kh == 1 && kw == 5) return launch_plain_k<8, 16, 1, 5>(p, n64, stream);
+  if (kh == 5 && kw == 1) return launch_plain_k<16, 8, 5, 1>(p, n64, stream);
+  return -1000;
+}
+template <int TH, int TW, int KH, int KW>
+static int launch_tiny(const ConvParams& p, hipStream_t stream) {     // 16-cout tiles (flow head, RGB decoder)
+  return halo_shared_weights() ? launch_v3<TH, TW, KH, KW, 16>(p, stream) : launch_v3<TH, TW, KH, KW, 16, false, 0, 64, false, true>(p, stream);
+}
 
 // Returns -1000 when the shape is outside the halo-tile family (caller falls back to v2).
 // cfg: 0 = auto, 70 = force (BN by cout), 71 = BN 128, 72 = BN 64.
@@ -43,9 +66,9 @@ int conv_v3_dispatch(const ConvParams& p, int cfg, hipStream_t stream) {
   const bool n64 = cfg == 72 || (cfg != 71 && (p.cout_g <= 64 || (p.cout_g <= 192 && p.cout_g % 128 != 0 && p.cout_g % 128 <= 64) ||
                                                (blk128 <= 256 && p.cout_g % 64 == 0)));
   if (cfg == 73 || (cfg == 0 && p.cout_g <= 16)) {   // tiny cout (flow head, RGB decoder): A-bandwidth bound, halo tiles cut the gather 6x
-    if (kh == 3 && kw == 3) return launch_v3<8, 16, 3, 3, 16>(p, stream);
-    if (kh == 1 && kw == 5) return launch_v3<8, 16, 1, 5, 16>(p, stream);
-    if (kh == 5 && kw == 1) return launch_v3<16, 8, 5, 1, 16>(p, stream);
+    if (kh == 3 && kw == 3) return launch_tiny<8, 16, 3, 3>(p, stream);
+    if (kh == 1 && kw == 5) return launch_tiny<8, 16, 1, 5>(p, stream);
+    if (kh == 5 && kw == 1) return launch_tiny<16, 8, 5, 1>(p, stream);
     return -1000;
   }
 #if defined(PP_DIAG)      // tuning / diagnostic variants (tools/kbench, PP_DIAG=1 builds only; measured in profiles/r2_conv_epilogue_ab.txt)
@@ -127,14 +150,9 @@ int conv_v3_dispatch(const ConvParams& p, int cfg, hipStream_t stream) {
     ConvParams q = p;
     q.preadd = p.residual; q.preadd_cstride = p.res_cstride; q.preadd_choff = p.res_choff;
     q.residual = nullptr; q.act = p.act2; q.act_param = 0.f; q.act2 = PP_ACT_NONE;
-    if (kh == 3 && kw == 3) return n64 ? launch_v3<8, 16, 3, 3, 64>(q, stream) : launch_v3<8, 16, 3, 3, 128>(q, stream);
-    if (kh == 1 && kw == 5) return n64 ? launch_v3<8, 16, 1, 5, 64>(q, stream) : launch_v3<8, 16, 1, 5, 128>(q, stream);
-    if (kh == 5 && kw == 1) return n64 ? launch_v3<16, 8, 5, 1, 64>(q, stream) : launch_v3<16, 8, 5, 1, 128>(q, stream);
+    return launch_plain(q, kh, kw, n64, stream);
   }
-  if (kh == 3 && kw == 3) return n64 ? launch_v3<8, 16, 3, 3, 64>(p, stream) : launch_v3<8, 16, 3, 3, 128>(p, stream);
-  if (kh == 1 && kw == 5) return n64 ? launch_v3<8, 16, 1, 5, 64>(p, stream) : launch_v3<8, 16, 1, 5, 128>(p, stream);
-  if (kh == 5 && kw == 1) return n64 ? launch_v3<16, 8, 5, 1, 64>(p, stream) : launch_v3<16, 8, 5, 1, 128>(p, stream);
-  return -1000;
+  return launch_plain(p, kh, kw, n64, stream);
 }
 
 }  // namespace pp

@@ -34,7 +34,12 @@ static __device__ unsigned long long g_v3_prof[12];     // (per translation unit
 // W_hi x A_hi + W_hi x A_lo + W_lo x A_hi: 48 MFMAs per 16 fragment reads, one weight stage and one barrier (the plain fp16 step:
 // 32 MFMAs per 16 reads; walking a block three times through the plain kernel: 48 MFMAs per 24 reads, 1.5 stages, 1.5 barriers).
 // The epilogue reads its operands (preadd, residual, h, z) as hi + lo and writes two planes (conv_epilogue.h).
-template <int TH, int TW, int KH, int KW, int BN, bool PROF = false, int STAGGER = 0, int WMT = 64, bool SPLIT = false>
+// PRIVB (BN <= 64): WAVE-PRIVATE weight stages.  A wave needs only the WN couts of its own column of the tile: with tiles of at most 64
+// couts a private copy of that slice per wave (2 stages x WN x 128 B: 4 KB / 2 KB per stage for BN 64 / 16) fits next to the patches in
+// the 80 KB of a block, every wave DMAs its own slice, and the tap steps of a channel block need NO block barrier -- only a counted
+// s_waitcnt on the wave's own DMA; the barrier remains once per channel block (the patch is shared).  MFMAs per barrier: x KH*KW.
+// (128-cout tiles would need 64 KB of private stages: one block per CU.)
+template <int TH, int TW, int KH, int KW, int BN, bool PROF = false, int STAGGER = 0, int WMT = 64, bool SPLIT = false, bool PRIVB = false>
 __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : (SPLIT && BN == 128 ? 2 : 1)) void conv_halo_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef _Float16 T;
@@ -48,11 +53,13 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : (SPLIT && BN =
   constexpr int PIECES = (P + 8 * NW - 1) / (8 * NW) * NW;     // LDS-DMA instructions per patch (8 rows each)
   constexpr int PPW = PIECES / NW;                              // ... per wave
   constexpr int PATCH_BYTES = PIECES * 1024;
-  constexpr int BSTAGE = BN * 128;
-  constexpr int B_INST = BN / 8;                               // weight-tile DMA instructions per stage (8 rows each)
-  constexpr int B_PER_WAVE = (B_INST + NW - 1) / NW;
-  constexpr bool B_RAGGED = (B_INST % NW) != 0;                 // BN 16: only waves 0..B_INST-1 fetch weights
-  constexpr int PIPE_BYTES = 2 * PATCH_BYTES + 2 * BSTAGE;
+  static_assert(!PRIVB || (BN <= 64 && STAGGER == 0 && WMT == 64), "private weight stages: tiles of at most 64 couts");
+  constexpr int BW_ROWS = PRIVB ? WN : BN;                     // weight rows of one stage buffer (the wave's own couts when private)
+  constexpr int BSTAGE = BW_ROWS * 128;
+  constexpr int B_INST = BW_ROWS / 8;                          // weight-tile DMA instructions per stage (8 rows each)
+  constexpr int B_PER_WAVE = PRIVB ? B_INST : (B_INST + NW - 1) / NW;
+  constexpr bool B_RAGGED = !PRIVB && (B_INST % NW) != 0;      // BN 16, shared stages: only waves 0..B_INST-1 fetch weights
+  constexpr int PIPE_BYTES = 2 * PATCH_BYTES + (PRIVB ? 2 * NW : 2) * BSTAGE;
   constexpr int EPI_WN = WN > 64 ? 64 : WN;                    // the epilogue stages at most 64 couts of the wave tile at a time
   constexpr int EPI_LD = EPI_WN + 4;
   constexpr int EPI_BYTES = NW * WM * EPI_LD * 4;
@@ -105,9 +112,12 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : (SPLIT && BN =
   int wvoff[B_PER_WAVE];
 #pragma unroll
   for (int j = 0; j < B_PER_WAVE; ++j) {
-    int row = n0 + (j * NW + wave) * 8 + rin;
+    // shared stages: instruction j of the wave covers tile rows (j * NW + wave) * 8 ..; private stages: rows j * 8 .. of the wave's own
+    // WN couts.  Weight rows are swizzled by slot ^ ((row >> 1) & 7) with the row counted inside the stage buffer.
+    int row = PRIVB ? n0 + wn * WN + j * 8 + rin : n0 + (j * NW + wave) * 8 + rin;
     if (row >= p.cout_pad) row = p.cout_pad - 1;          // clamped rows feed accumulators that are never stored
-    wvoff[j] = row * p.kchunks * 16 + lc * 16;
+    const int lcj = PRIVB ? (slot ^ ((4 * (j & 1) + (rin >> 1)) & 7)) : lc;
+    wvoff[j] = row * p.kchunks * 16 + lcj * 16;
   }
   const int nrec = p.N * p.H * p.W;
   // (individual scalars, not arrays: a dynamically indexed private array would live in scratch, and scratch loads share
@@ -134,7 +144,7 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : (SPLIT && BN =
   do {                                                                                                          \
     _Pragma("unroll") for (int j_ = 0; j_ < B_PER_WAVE; ++j_)                                                   \
       if (!B_RAGGED || j_ * NW + wave < B_INST)                                                                 \
-        v3_dma16(rw, bst0 + (par_) * BSTAGE + (j_ * NW + wave) * 1024, wvoff[j_], (ks_) * 128);                 \
+        v3_dma16(rw, bst0 + (PRIVB ? wave * 2 + (par_) : (par_)) * BSTAGE + (PRIVB ? j_ : j_ * NW + wave) * 1024, wvoff[j_], (ks_) * 128); \
   } while (0)
 
   f32x4 acc[TN][TM];
@@ -150,7 +160,7 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : (SPLIT && BN =
     const int m = wm * WM + t * 16 + l15;
     pp0[t] = (m / TW) * PW + (m % TW);
   }
-  const int b_off = (wn * WN + l15) * 128;
+  const int b_off = (PRIVB ? l15 : wn * WN + l15) * 128;
   const int bswz = (l15 >> 1) & 7;
 
   const int nblocks = p.kchunks / (8 * NTAPS);
@@ -211,9 +221,21 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : (SPLIT && BN =
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if constexpr (PRIVB) {
+        // the wave's own weight stage of this step was requested one step ago, BEFORE that step's patch pieces: at most PCP younger
+        // requests (pieces of the next block's patch) may stay in flight.  Only the first tap of a channel block needs the block: the
+        // patch arrived from all four waves.
+        const int tp = (t + NTAPS - 1) % NTAPS;                                              // tap of the previous step (folds after unrolling)
+        const int pcp = PPW > tp ? (PPW - tp + NTAPS - 1) / NTAPS : 0;                       // pieces a step issues at tap tp
+        if (t == 0 || !have_next || pcp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (pcp == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else if (pcp == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       if constexpr (PROF) { pf_b = __builtin_readcyclecounter(); pf_vm += pf_b - pf_a; }
-      __builtin_amdgcn_s_barrier();          // weights of step ks (and, at t == 0, the whole patch of this block) are in LDS
+      if (!PRIVB || t == 0) __builtin_amdgcn_s_barrier();          // weights of step ks (and, at t == 0, the whole patch of this block) are in LDS
       if constexpr (PROF) { pf_c = __builtin_readcyclecounter(); pf_wait += pf_c - pf_b; }
       if (t == 0 && have_next) {
         v3_entry_ready(en);
@@ -228,7 +250,7 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : (SPLIT && BN =
         }
       }
       if constexpr (PROF) { pf_a = __builtin_readcyclecounter(); pf_issue += pf_a - pf_c; }
-      const char* sb = bst0 + par * BSTAGE;
+      const char* sb = bst0 + (PRIVB ? wave * 2 + par : par) * BSTAGE;
       if constexpr (SPLIT) {
         // tri-product step: fragments of both planes (kk 0 = hi / W_hi, kk 1 = lo / W_lo), then the three products with the
         // accumulators interleaved (an accumulator is revisited every 16 MFMAs; small terms first)
@@ -392,13 +414,13 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : (SPLIT && BN =
 #endif
 }
 
-template <int TH, int TW, int KH, int KW, int BN, bool PROF = false, int STAGGER = 0, int WMT = 64, bool SPLIT = false>
+template <int TH, int TW, int KH, int KW, int BN, bool PROF = false, int STAGGER = 0, int WMT = 64, bool SPLIT = false, bool PRIVB = false>
 static int launch_v3(ConvParams p, hipStream_t stream) {
   p.tiles_n = (p.cout_g + BN - 1) / BN;
   const long long tiles = (long long)p.N * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
   const long long nblk = tiles * p.tiles_n;
   if (nblk >= (1ll << 31)) return -1000;
-  hipLaunchKernelGGL((conv_halo_kernel<TH, TW, KH, KW, BN, PROF, STAGGER, WMT, SPLIT>), dim3((unsigned)nblk), dim3(TH * TW * 128 / WMT), 0, stream, p);
+  hipLaunchKernelGGL((conv_halo_kernel<TH, TW, KH, KW, BN, PROF, STAGGER, WMT, SPLIT, PRIVB>), dim3((unsigned)nblk), dim3(TH * TW * 128 / WMT), 0, stream, p);
   return launch_status("pp_conv2d(v3)");
 }
 
