@@ -25,10 +25,12 @@
 
 namespace pp {
 
-// 64-cout tiles run with wave-private weight stages (conv_halo.h, PRIVB: no block barrier inside a channel block) unless
-// PP_HALO_SHARED_WEIGHTS=1 asks for the shared-stage form (A/B runs); 128-cout tiles always share their stages.
+// Tiles of at most 64 couts can run with wave-private weight stages (conv_halo.h, PRIVB: no block barrier inside a channel block).
+// MEASURED (profiles/r3h_halo_private_weights_ab.txt, four interleaved bench runs on one box): no difference -- 1 551 / 1 556 ms per clip
+// with shared stages, 1 560 / 1 557 with private ones; the per-tap barrier is not what the step waits for.  Shipped default: shared
+// stages (one more block per CU for the 16-cout tiles); PP_HALO_PRIVATE_WEIGHTS=1 selects the private form.
 static bool halo_shared_weights() {
-  static const bool v = getenv("PP_HALO_SHARED_WEIGHTS") != nullptr && getenv("PP_HALO_SHARED_WEIGHTS")[0] == '1';
+  static const bool v = !(getenv("PP_HALO_PRIVATE_WEIGHTS") != nullptr && getenv("PP_HALO_PRIVATE_WEIGHTS")[0] == '1');
   return v;
 }
 template <int TH, int TW, int KH, int KW>

@@ -13,8 +13,8 @@ namespace pp {
 template <int KH, int KW>
 static int launch_v3s(const ConvParams& p, int bn, bool shared_w, hipStream_t stream) {
   constexpr int TH = KW == 1 ? 16 : 8, TW = KW == 1 ? 8 : 16;
-  // tiles of at most 64 couts: wave-private weight stages, no block barrier inside a channel block (conv_halo.h, PRIVB); shared_w keeps
-  // the shared-stage form selectable (PP_HALO_SHARED_WEIGHTS=1: A/B runs)
+  // tiles of at most 64 couts: optional wave-private weight stages, no block barrier inside a channel block (conv_halo.h, PRIVB;
+  // PP_HALO_PRIVATE_WEIGHTS=1) -- measured neutral (conv_gemm_v3.hip), the shared-stage form ships
   if (bn == 16) return shared_w ? launch_v3<TH, TW, KH, KW, 16, false, 0, 64, true>(p, stream) : launch_v3<TH, TW, KH, KW, 16, false, 0, 64, true, true>(p, stream);
   if (bn == 64) return shared_w ? launch_v3<TH, TW, KH, KW, 64, false, 0, 64, true>(p, stream) : launch_v3<TH, TW, KH, KW, 64, false, 0, 64, true, true>(p, stream);
   return launch_v3<TH, TW, KH, KW, 128, false, 0, 64, true>(p, stream);
@@ -43,7 +43,7 @@ int conv_v3s_dispatch(const ConvParams& p, int cfg, hipStream_t stream) {
     q.preadd = p.residual; q.preadd_cstride = p.res_cstride; q.preadd_choff = p.res_choff; q.preadd_lo = p.res_lo;
     q.residual = nullptr; q.act = p.act2; q.act_param = 0.f; q.act2 = PP_ACT_NONE;
   }
-  static const bool shared_w = getenv("PP_HALO_SHARED_WEIGHTS") != nullptr && getenv("PP_HALO_SHARED_WEIGHTS")[0] == '1';
+  static const bool shared_w = !(getenv("PP_HALO_PRIVATE_WEIGHTS") != nullptr && getenv("PP_HALO_PRIVATE_WEIGHTS")[0] == '1');
   if (kh == 3) return launch_v3s<3, 3>(q, bn, shared_w, stream);
   if (kh == 1) return launch_v3s<1, 5>(q, bn, shared_w, stream);
   return launch_v3s<5, 1>(q, bn, shared_w, stream);
