@@ -335,7 +335,25 @@ def main():
     exchange_stats.clear()
     graph = None
     capture_s = None
-    if not args.eager and not use_ranks:      # (the sharded pass interleaves RCCL exchanges with the stages: eager submission)
+    sgraph = None
+    if not args.eager and use_ranks:
+        # sub-video shards: the compute segments between the four halo exchanges as hipGraphs, the exchanges stay eager RCCL
+        # point-to-point ops (sharding.ShardedClipGraph); falls back to eager submission if the capture is refused
+        from propainter_amd.sharding import ShardedClipGraph, dist_exchanger
+        t_c = time.perf_counter()
+        try:
+            sgraph = ShardedClipGraph(models, L, H, W, cfg, dev, rank, world)
+            sgraph.load(clip_pin, masks_pin, masks_pin)
+            sgraph.capture(dist_exchanger(dev, None, None))
+        except Exception as e:
+            sys.stderr.write(f"[bench] sharded hipGraph capture failed on rank {rank} ({type(e).__name__}: {e}); eager launches\n")
+            sgraph = None
+        capture_s = time.perf_counter() - t_c
+        ok = torch.tensor([1 if sgraph is not None else 0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)        # all ranks or none: the exchange pattern must match
+        if int(ok.item()) == 0:
+            sgraph = None
+    if not args.eager and not use_ranks:      # one clip per rank: the whole pass as ONE hipGraph
         from propainter_amd.pipeline import ClipGraph
         t_c = time.perf_counter()
         try:
@@ -347,7 +365,18 @@ def main():
             torch.cuda.synchronize()
         capture_s = time.perf_counter() - t_c
 
+    sgraph_x = None
+    if sgraph is not None:
+        from propainter_amd.sharding import dist_exchanger
+        sgraph_x = dist_exchanger(dev, None, exchange_stats)
+
     def step(stage_hook=None):
+        if sgraph is not None and stage_hook is None:
+            sgraph.load(clip_pin, masks_pin, masks_pin)       # every rank uploads the slice of the raw input it needs inside the step
+            lo_, comp = sgraph.replay(sgraph_x)
+            if comp.shape[0]:
+                host_out[:comp.shape[0]].copy_(comp, non_blocking=True)
+            return
         if graph is None or stage_hook is not None:
             return eager_step(stage_hook)
         host_out.copy_(graph.replay(), non_blocking=True)
@@ -443,7 +472,8 @@ def main():
     # after one untimed replay); the reference's own RAFT arithmetic is fp32
     raft_precisions = None
     raft = models[0]
-    submission = "eager (Python launches)" if graph is None else "hipGraph replay of the whole pass (pipeline.ClipGraph)"
+    submission = ("hipGraph replays of the compute segments between the halo exchanges (sharding.ShardedClipGraph)" if sgraph is not None else
+                  "eager (Python launches)" if graph is None else "hipGraph replay of the whole pass (pipeline.ClipGraph)")
     if rank == 0 and world == 1 and not args.no_precisions and not sharded:
         raft_precisions = {args.raft_dtype: {"value": fps, "ms_per_step": ms_per_step, "timed": "headline (see value)"}}
         had_graph = graph is not None

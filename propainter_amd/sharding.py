@@ -307,10 +307,11 @@ def can_shard(L, cfg, world):
     return world > 1 and cfg.subvideo_length <= 100 and L - 1 > cfg.subvideo_length
 
 
-def _dist_exchange(ex, device, group=None, stats=None):
+def _dist_exchange(ex, device, group=None, stats=None, bufs=None):
     """Answers one Exchange with torch.distributed point-to-point ops (RCCL send/recv between the two GPUs' xGMI link;
     gloo stages through host memory).  ``stats`` (optional dict) accumulates per exchange tag the bytes sent / received
-    by this rank and the wall time of the exchange (device-synchronised on both sides when the backend is RCCL)."""
+    by this rank and the wall time of the exchange (device-synchronised on both sides when the backend is RCCL).
+    ``bufs`` (optional {q: tensor}): receive into these preallocated device tensors (ShardedClipGraph: the captured graphs read them)."""
     import time
     import torch.distributed as dist
     via_host = dist.get_backend(group) == "gloo"
@@ -318,9 +319,9 @@ def _dist_exchange(ex, device, group=None, stats=None):
         if not via_host:
             torch.cuda.synchronize(device)
         t0 = time.perf_counter()
-    bufs, ops, keep = {}, [], []
+    static, bufs, ops, keep = bufs, {}, [], []
     for q, (shape, dtype) in sorted(ex.recv.items()):
-        bufs[q] = torch.empty(shape, dtype=dtype, device="cpu" if via_host else device)
+        bufs[q] = static[q] if (static is not None and not via_host) else torch.empty(shape, dtype=dtype, device="cpu" if via_host else device)
         ops.append(dist.P2POp(dist.irecv, bufs[q], q, group))
     for q, t in sorted(ex.send.items()):
         t = t.cpu() if via_host else t.contiguous()
@@ -329,6 +330,10 @@ def _dist_exchange(ex, device, group=None, stats=None):
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
+    if static is not None and via_host:
+        for q, b in bufs.items():
+            static[q].copy_(b)
+        bufs = static
     out = {q: b.to(device) for q, b in bufs.items()}
     if stats is not None:
         if not via_host:
@@ -353,6 +358,123 @@ def run_clip_sharded(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg, de
             ex = gen.send(_dist_exchange(ex, device, group, stats))
     except StopIteration as stop:
         return stop.value
+
+
+class _RawSlice:
+    """Stands for a whole-clip input array of which one rank reads exactly the slice [r0, r1): sharded_clip_steps only asks for the
+    length, the frame shape and that slice."""
+
+    def __init__(self, t, r0, total):
+        self.t, self.r0, self.total = t, r0, total
+        self.shape = (total,) + tuple(t.shape[1:])
+
+    def __len__(self):
+        return self.total
+
+    def __getitem__(self, sl):
+        assert isinstance(sl, slice) and sl.start == self.r0 and sl.stop == self.r0 + self.t.shape[0], (sl, self.r0, self.t.shape)
+        return self.t
+
+
+class ShardedClipGraph:
+    """One rank's part of the sharded pass over clips of ONE shape as hipGraphs (the sharded counterpart of pipeline.ClipGraph).
+
+    The eager sharded pass issues ~10 k launches per rank from Python (~170 us of host time each): with one sub-video per GPU the
+    ranks are host-bound.  The pass has no data-dependent host control flow between two halo exchanges, so the generator
+    ``sharded_clip_steps`` is run ONCE under hipGraph capture from one exchange request to the next -- one graph per compute segment
+    (5 segments: the 4 exchanges of RAFT flows, completed flows, updated frames, boundary composites).  A replay is graph_0, exchange_0,
+    graph_1, ... : the exchanges stay eager point-to-point ops (RCCL send / recv) on the send tensors the previous graph wrote and into
+    receive buffers the next graph reads -- all at fixed addresses.  Same kernels, same order: bit-identical to the eager pass.
+
+        g = ShardedClipGraph(models, L, H, W, cfg, device, rank, world)
+        g.load(frames_u8, flow_masks_u8, masks_dilated_u8)          # whole-clip host arrays; the rank's slice is uploaded
+        g.capture(exchange)                                          # exchange(ex, bufs): answers one Exchange into bufs
+        lo, comp = g.replay(exchange)                                # (after another load(): the next clip)
+    """
+
+    def __init__(self, models, L, H, W, cfg, device, rank, world):
+        self.models, self.cfg, self.device, self.rank, self.world, self.L = models, cfg, torch.device(device), rank, world, L
+        self.r0, self.r1 = ShardPlan(L, cfg, world).need_raw(rank)
+        n = max(0, self.r1 - self.r0)
+        self.frames = torch.zeros((n, H, W, 3), dtype=torch.uint8, device=device)
+        self.flow_masks = torch.zeros((n, H, W), dtype=torch.uint8, device=device)
+        self.masks_dilated = torch.zeros((n, H, W), dtype=torch.uint8, device=device)
+        self.segments = []          # [(graph, Exchange or None, {q: receive buffer})]
+        self.result = None
+        self._gen = None
+        self._pinned = []
+
+    def load(self, frames_u8, flow_masks_u8, masks_dilated_u8):
+        to_t = lambda a: a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))
+        for dst, src in ((self.frames, frames_u8), (self.flow_masks, flow_masks_u8), (self.masks_dilated, masks_dilated_u8)):
+            if dst.shape[0]:
+                dst.copy_(to_t(src[self.r0:self.r1]), non_blocking=True)
+
+    def _inputs(self):
+        return tuple(_RawSlice(t, self.r0, self.L) for t in (self.frames, self.flow_masks, self.masks_dilated))
+
+    def eager(self, exchange):
+        """One eager pass on the static inputs (builds engines, tables and cached index tensors; must precede capture())."""
+        gen = sharded_clip_steps(self.models, *self._inputs(), self.cfg, self.device, self.rank, self.world)
+        try:
+            ex = next(gen)
+            while True:
+                bufs = {q: torch.empty(shape, dtype=dtype, device=self.device) for q, (shape, dtype) in ex.recv.items()}
+                exchange(ex, bufs)
+                ex = gen.send(bufs)
+        except StopIteration as stop:
+            return stop.value
+
+    def capture_next(self, got):
+        """Captures the next compute segment (from the answer `got` of the previous exchange -- None for the first -- to the next
+        exchange request).  Returns that request with freshly allocated receive buffers, or (None, None) after the last segment."""
+        from . import pipeline
+        if self._gen is None:
+            self._gen = sharded_clip_steps(self.models, *self._inputs(), self.cfg, self.device, self.rank, self.world)
+        g = torch.cuda.CUDAGraph()
+        pool = self.segments[0][0].pool() if self.segments else None
+        prev, pipeline._index_recorder = pipeline._index_recorder, self._pinned      # the graphs own the cached index tensors they read
+        ex, done = None, False
+        try:
+            with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+                try:
+                    ex = next(self._gen) if got is None and not self.segments else self._gen.send(got)
+                except StopIteration as stop:
+                    self.result, done = stop.value, True
+        finally:
+            pipeline._index_recorder = prev
+        if done:
+            self.segments.append((g, None, None))
+            return None, None
+        bufs = {q: torch.empty(shape, dtype=dtype, device=self.device) for q, (shape, dtype) in ex.recv.items()}
+        self.segments.append((g, ex, bufs))
+        return ex, bufs
+
+    def capture(self, exchange):
+        """Eager warm-up pass, then the capture pass (its exchanges are executed for real: the peers capture in lockstep)."""
+        self.eager(exchange)
+        torch.cuda.synchronize(self.device)
+        got = None
+        while True:
+            ex, bufs = self.capture_next(got)
+            if ex is None:
+                break
+            exchange(ex, bufs)
+            got = bufs
+        torch.cuda.synchronize(self.device)
+        return self
+
+    def replay(self, exchange):
+        for g, ex, bufs in self.segments:
+            g.replay()
+            if ex is not None:
+                exchange(ex, bufs)
+        return self.result
+
+
+def dist_exchanger(device, group=None, stats=None):
+    """exchange(ex, bufs) over torch.distributed for ShardedClipGraph (receives into the static buffers)."""
+    return lambda ex, bufs: _dist_exchange(ex, device, group, stats, bufs=bufs)
 
 
 def gather_frames(lo, comp, total, dst=0, group=None):
@@ -409,3 +531,50 @@ def run_logical_shards(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg, 
     for lo, comp in results:
         out[lo:lo + comp.shape[0]] = comp
     return out
+
+
+def _copy_exchange(reqs):
+    """In-process answer of one SPMD exchange step: reqs[r] = (Exchange or None, {q: receive buffer}) of logical rank r."""
+    for r, (ex, bufs) in enumerate(reqs):
+        if ex is None:
+            continue
+        for q, (shape, dtype) in ex.recv.items():
+            t = reqs[q][0].send[r]
+            assert tuple(t.shape) == tuple(shape) and t.dtype == dtype, (ex.tag, r, q, t.shape, shape)
+            bufs[q].copy_(t)
+
+
+def run_logical_shards_graphed(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg, device, world, replays=2, clips=None):
+    """`world` logical ranks in ONE process, each as a ShardedClipGraph (captured in lockstep, exchanged tensors copied between the
+    ranks' static buffers): validates the graph form of the sharded pass where only one GPU is available.  Returns the uint8
+    [L,H,W,3] result of the LAST replay; `clips` (optional list of (frames, flow_masks, masks_dilated)) are loaded before the replays
+    in turn (same shape), the default replays the clip that was captured."""
+    L, H, W = len(frames_u8), frames_u8.shape[1], frames_u8.shape[2]
+    graphs = [ShardedClipGraph(models, L, H, W, cfg, device, r, world) for r in range(world)]
+    for g in graphs:
+        g.load(frames_u8, flow_masks_u8, masks_dilated_u8)
+    run_logical_shards(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg, device, world)      # eager warm-up of every rank's engines / tables
+    torch.cuda.synchronize(device)
+    got = [None] * world
+    while True:
+        reqs = [g.capture_next(got[r]) for r, g in enumerate(graphs)]
+        assert len({ex.tag if ex is not None else None for ex, _ in reqs}) == 1, "ranks must stop at the same exchange"
+        if reqs[0][0] is None:
+            break
+        _copy_exchange(reqs)
+        got = [b for _, b in reqs]
+    nseg = len(graphs[0].segments)
+    assert all(len(g.segments) == nseg for g in graphs)
+    for i in range(replays):
+        if clips:
+            for g in graphs:
+                g.load(*clips[i % len(clips)])
+        for s_ in range(nseg):
+            for g in graphs:
+                g.segments[s_][0].replay()
+            _copy_exchange([(g.segments[s_][1], g.segments[s_][2]) for g in graphs])
+    out = torch.zeros((L, H, W, 3), dtype=torch.uint8, device=device)
+    for g in graphs:
+        lo, comp = g.result
+        out[lo:lo + comp.shape[0]] = comp
+    return out, nseg

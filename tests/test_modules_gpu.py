@@ -353,6 +353,33 @@ def test_logical_shards_on_one_gpu_match_the_unsharded_pass(models, fp16):
     assert torch.equal(out, ref), f"sharded pass differs in {(out != ref).float().mean().item():.3e} of bytes"
 
 
+def test_sharded_pass_as_hipgraphs_matches_the_unsharded_pass(models):
+    """sharding.ShardedClipGraph: the compute segments between the four halo exchanges captured as hipGraphs (one set per logical rank,
+    captured in lockstep on one GPU, exchanges copied between the ranks' static buffers) and replayed -- also after ANOTHER clip of the same
+    shape was loaded into the static inputs -- must reproduce run_clip bit for bit (headline precision: fp16 stages, split-plane RAFT)."""
+    from propainter_amd.pipeline import InferenceConfig, run_clip
+    from propainter_amd.sharding import run_logical_shards_graphed
+    from propainter_amd.synthetic import synthetic_clip, synthetic_mask
+    import scipy.ndimage
+    L, H, W = 26, 128, 192
+    m = scipy.ndimage.binary_dilation(synthetic_mask(H, W), iterations=4).astype(np.uint8) * 255
+    masks = np.repeat(m[None], L, 0)
+    clip_a, clip_b = synthetic_clip(L, H, W, seed=9), synthetic_clip(L, H, W, seed=10)
+    dev = torch.device("cuda")
+    cfg = InferenceConfig(raft_iter=3, subvideo_length=10, neighbor_length=4, ref_stride=3, fp16=True)
+    raft = models[0]
+    raft.precision = "f16x3"
+    try:
+        ref_b = run_clip(models, clip_b, masks, masks, cfg, dev)
+        out, nseg = run_logical_shards_graphed(models, clip_a, masks, masks, cfg, dev, 3, replays=2,
+                                               clips=[(clip_a, masks, masks), (clip_b, masks, masks)])      # last replay: clip b
+    finally:
+        raft.precision = None
+    torch.cuda.synchronize()
+    assert nseg == 5, nseg                      # 4 exchanges (gt flows, completed flows, updated frames, boundary composites) -> 5 segments
+    assert torch.equal(out, ref_b), f"graphed sharded pass differs in {(out != ref_b).float().mean().item():.3e} of bytes"
+
+
 def test_generator_nearest_interpolation_and_batch_of_two(models, sds):
     """InpaintGenerator.forward(interpolation='nearest') (model/propainter.py:148,319) and b = 2 against the oracle."""
     gen = models[2]
