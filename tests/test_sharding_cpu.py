@@ -149,9 +149,18 @@ def _worker(rank, world, port, L, S, q):
         cfg = InferenceConfig(raft_iter=20, subvideo_length=S, neighbor_length=10, ref_stride=10)
         lo, comp = run_clip_sharded(MODELS, clip, m, m, cfg, torch.device("cpu"))
         full = gather_frames(lo, comp, L, dst=0)
+        # the host side of ShardedClipGraph (static raw-slice inputs, receives into preallocated buffers): its eager driver over the
+        # same process group must give the same frames (the hipGraph capture itself is covered by the GPU test with logical ranks)
+        from propainter_amd.sharding import ShardedClipGraph, dist_exchanger
+        sg = ShardedClipGraph(MODELS, L, clip.shape[1], clip.shape[2], cfg, torch.device("cpu"), rank, world)
+        sg.load(clip, m, m)
+        lo2, comp2 = sg.eager(dist_exchanger(torch.device("cpu")))
+        flag = torch.tensor([1 if (lo2 == lo and torch.equal(comp2, comp)) else 0])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)                   # every rank's frames must match
+        same = bool(flag.item())
         if rank == 0:
             ref = run_clip(MODELS, clip, m, m, cfg, torch.device("cpu"))
-            q.put((bool(torch.equal(full, ref)), int(lo), int(comp.shape[0])))
+            q.put((bool(torch.equal(full, ref)) and same, int(lo), int(comp.shape[0])))
     finally:
         dist.destroy_process_group()
 
