@@ -70,7 +70,7 @@ typedef struct {
   int32_t cstride;  /* elements per pixel                                */
   int32_t choff;    /* first channel used (for group 0)                  */
   int32_t cgroup;   /* channel advance per group (0 when groups == 1)    */
-  int32_t pad_;
+  int32_t lo_off;   /* split-plane source (pp_conv_args_t.split == 2): element offset of its lo plane, else 0 */
 } pp_conv_src_t;
 
 typedef struct {

@@ -71,15 +71,18 @@ def tri_ktable(taps, src_cpad, src_lo):
     planes of one source; per tap 8 chunks -- 4 of the hi plane, then the same 4 channel chunks of the lo plane (flags PLANE_LO |
     WEIGHT_LO: the packed weight row holds [32 ch W_hi | 32 ch W_lo] per tap).  The kernel multiplies the four fragment sets of a
     tap step as W_hi x A_hi + W_hi x A_lo + W_lo x A_hi, so -- unlike split_ktable's -- this table is NOT a plain K walk: only the
-    halo-tile kernel (and the CPU emulation's matching branch) may consume it.  Returns int32 [chunks + 1, 4]."""
+    tri-product kernels (halo-tile kernel, v2 kernel with TRI; the CPU emulation's matching branch) may consume it.  Works for any tap
+    list; a source that is no multiple of 32 channels gets a ragged last block padded with zero chunks.  Returns int32 [chunks + 1, 4]."""
     rows = []
     for s, (c, lo) in enumerate(zip(src_cpad, src_lo)):
-        assert c % 32 == 0 and lo % 8 == 0 and lo >= c
+        assert c % 8 == 0 and lo % 8 == 0 and lo >= c
         for cb in range(0, c, 32):
-            for t, (dy, dx) in enumerate(taps):
+            n = min(4, (c - cb) // 8)          # chunks of this block (the last block of a source that is no multiple of 32 is ragged:
+            for t, (dy, dx) in enumerate(taps):       # zero chunks -- source id 255 -- fill both halves of the step)
                 for plane in (0, 1):
+                    fl = (KT_PLANE_LO | KT_WEIGHT_LO) if plane else 0
                     for j in range(4):
-                        rows.append([dy, dx, s | (t << 16) | ((KT_PLANE_LO | KT_WEIGHT_LO) if plane else 0), cb + 8 * j + (lo if plane else 0)])
+                        rows.append([dy, dx, s | (t << 16) | fl, cb + 8 * j + (lo if plane else 0)] if j < n else [0, 0, 255 | fl, 0])
     rows.append([0, 0, 0, 0])
     return np.ascontiguousarray(np.asarray(rows, dtype=np.int32))
 
@@ -166,10 +169,14 @@ class ConvLayer:
             # tri-product format (halo-tile kernel: 48 MFMAs per 16 fragment reads) for the stride-1 "same" 3x3 / 1x5 / 5x1 layers
             # over 32-channel-multiple sources; every other layer walks its blocks three times through the LDS-DMA (v2) kernel
             pad_same = self.padding == ((kh - 1) // 2, (kw - 1) // 2) and self.stride == (1, 1)
-            self.tri = (self.tap_hw in ((3, 3), (1, 5), (5, 1)) and pad_same and all(c % 32 == 0 for c in self.src_cpad) and
-                        not (16 < cout < 48) and self.pad_mode == 0)
-            if tri is not None:      # (tests: tri=False walks a halo-eligible layer through the v2 kernel's plain format)
-                assert self.tri or not tri, "layer outside the halo-tile family"
+            halo = (self.tap_hw in ((3, 3), (1, 5), (5, 1)) and pad_same and all(c % 32 == 0 for c in self.src_cpad) and
+                    not (16 < cout < 48) and self.pad_mode == 0)
+            # ... and, through the v2 kernel's tri step (64-wide K steps: couts > 32), every other layer whose 32-channel blocks are
+            # (nearly) full: 1x1 over 324 / 128 / 256 channels, strided 3x3 (a 7x7 over 8 or a 7x1 over 16 channels would be 2-4x zeros)
+            full = sum((c + 31) // 32 * 32 for c in self.src_cpad) <= 1.1 * sum(self.src_cpad)
+            self.tri = halo or (full and cout > 32)
+            if tri is not None:      # (tests: tri=False walks a layer through the v2 kernel's plain format)
+                assert self.tri or not tri or cout > 32, "tri-product format: halo family, or more than 32 couts (v2 kernel, 64-wide K steps)"
                 self.tri = bool(tri)
             kt = tri_ktable(taps, self.src_cpad, self.src_lo) if self.tri else split_ktable(kt, self.src_lo)
         packed, K, cout_g = pack_weight(weight, self.src_channels, groups, ktable=kt,     # K order = the table's order
@@ -185,8 +192,8 @@ class ConvLayer:
         self.dcn = dcn_groups > 0
         # K steps of 4 / 8 chunks are (tap, source)-uniform when every source is a multiple of 32 / 64 channels
         self.ktable_uniform = (4 if all(c % 32 == 0 for c in self.src_cpad) else 0) | (8 if all(c % 64 == 0 for c in self.src_cpad) else 0)
-        if self.split and self.tri:
-            self.ktable_uniform = 8      # every run of 8 chunks is one (tap, source) [4 hi + 4 lo chunks]: what the halo kernel needs
+        if self.split and self.tri:      # every run of 8 chunks is one (tap, source) [4 hi + 4 lo chunks] when no block is ragged
+            self.ktable_uniform = 8 if all(c % 32 == 0 for c in self.src_cpad) else 0
         self.impl = 0            # pp_conv_args_t.impl: 0 auto, 1 register-staged kernel, >= 10 a specific LDS-DMA tile
         # fp32 tensors, products on the fp16 matrix cores as hi*hi + hi*lo + lo*hi (fp32 accumulate): ~2^-21 per
         # product instead of fp32's 2^-24, 5x the rate of the exact fp32 MFMA (pp_conv_args_t.impl 3)
@@ -235,6 +242,7 @@ class ConvLayer:
             a.src[i].cstride = t.shape[-1]
             a.src[i].choff = choff
             a.src[i].cgroup = self.src_channels[i] if self.groups > 1 else 0
+            a.src[i].lo_off = self.src_lo[i] if self.split else 0
         a.ktable = self.ktable.data_ptr()
         a.weight = self.weight.data_ptr()
         a.weight_gstride = self.cout_pad * self.K
@@ -305,8 +313,8 @@ _split_gemm_tables = {}
 def batched_gemm_nt_split(a, b, out_scale=1.0):
     """Split-plane ("f16x3") batched GEMM: a, b fp16 [B, M | N, 2K] = hi | lo planes of fp32 operands;
     out[b, m, n] = out_scale * sum_k a[b, m, k] * b[b, n, k] as hi*hi + lo*hi + hi*lo on the fp16 matrix cores, fp32 output.
-    The A side needs no copy (its K table walks hi, lo, hi of every 64-channel block); the B side is the kernel's dense
-    "weight" operand, so its rows are gathered once into that K order (hi, hi, lo per block).
+    Tri-product K format: the A side needs no copy (its K table lists 4 hi + 4 lo chunks per 32-channel block); the B side is the
+    kernel's dense "weight" operand, so its rows are gathered once into that K order ([32 ch hi | 32 ch lo] per block).
     RAFT all-pairs correlation volume at reference precision (RAFT/corr.py:52-60)."""
     B, M, K2 = a.shape
     Bb, Nn, K2b = b.shape
@@ -314,7 +322,7 @@ def batched_gemm_nt_split(a, b, out_scale=1.0):
     assert B == Bb and K2 == K2b and K % 64 == 0 and a.dtype == b.dtype == torch.float16 and a.is_contiguous() and b.is_contiguous()
     key = (K, str(a.device))
     if key not in _split_gemm_tables:
-        kt = split_ktable(hip.build_ktable([(0, 0)], [K]), [K])
+        kt = tri_ktable([(0, 0)], [K], [K])            # per 32-channel block: 4 hi chunks, then the same 4 chunks of the lo plane
         code = kt[:-1, 2].astype(np.int64)
         plane = np.where(code & KT_WEIGHT_LO, 1, 0)                                  # B-side plane of every chunk
         cols = (plane * K + kt[:-1, 3] % K)[:, None] + np.arange(8)[None, :]         # [chunks, 8] columns of b's rows (lo-plane A chunks: c + K -> c)
@@ -329,13 +337,15 @@ def batched_gemm_nt_split(a, b, out_scale=1.0):
     g.stride_h = g.stride_w = 1
     g.groups, g.cout_g, g.cout_pad, g.kchunks, g.nsrc = B, Nn, Nn, kchunks, 1
     g.src[0].ptr, g.src[0].cstride, g.src[0].choff, g.src[0].cgroup = a.data_ptr(), K2, 0, 0
+    g.src[0].lo_off = K
     g.ktable, g.weight, g.weight_gstride = kt.data_ptr(), bt.data_ptr(), Nn * kchunks * 8
     g.act, g.out_scale, g.act2 = hip.ACT_NONE, float(out_scale), hip.ACT_NONE
     g.out_dtype = hip.PP_F32
-    g.ktable_uniform = 12
+    g.split = 2                    # tri-product K step (plain fp32 output: no split-plane epilogue operands)
+    g.ktable_uniform = 8
     g.out, g.out_cstride, g.out_choff, g.out_cgroup = out.data_ptr(), Nn, 0, 0
     g.src_gstride, g.out_gstride = M * K2, M * Nn
-    hip.conv2d_raw(g, cin_read=K * B, on=a, split_k=3)
+    hip.conv2d_raw(g, cin_read=K * B, on=a, split_k=2)
     del bt
     return out
 

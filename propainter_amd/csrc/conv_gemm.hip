@@ -514,7 +514,7 @@ extern "C" int pp_conv2d(const pp_conv_args_t* a, void* stream) {
   for (int s = 0; s < PP_CONV_MAX_SRC; ++s) {
     const int ss = s < a->nsrc ? s : 0;
     p.src[s].ptr = (const char*)a->src[ss].ptr; p.src[s].cstride = a->src[ss].cstride;
-    p.src[s].choff = a->src[ss].choff; p.src[s].cgroup = a->src[ss].cgroup;
+    p.src[s].choff = a->src[ss].choff; p.src[s].cgroup = a->src[ss].cgroup; p.src[s].lo = a->src[ss].lo_off;
   }
   p.ktable = (const int4*)a->ktable; p.weight = (const char*)a->weight; p.weight_gstride = a->weight_gstride;
   p.bias = a->bias; p.act = a->act; p.act_param = a->act_param; p.out_scale = a->out_scale;
@@ -560,8 +560,10 @@ extern "C" int pp_conv2d(const pp_conv_args_t* a, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (a->split) {
     // split-plane ("f16x3") layer: the LDS-DMA kernels with the split epilogue only -- there is no register-staged fallback
-    PP_REQUIRE((a->split == 1 || a->split == 2) && a->dtype == PP_F16 && !deform && a->groups == 1 && a->fuse != PP_FUSE_DCN_OFFMASK, PP_ERR_ARG,
-               "pp_conv2d: split-plane layers (split 1 / 2) need dtype PP_F16, groups == 1, no deformable sampling, no PP_FUSE_DCN_OFFMASK");
+    PP_REQUIRE((a->split == 1 || a->split == 2) && a->dtype == PP_F16 && !deform && a->fuse != PP_FUSE_DCN_OFFMASK, PP_ERR_ARG,
+               "pp_conv2d: split-plane layers (split 1 / 2) need dtype PP_F16, no deformable sampling, no PP_FUSE_DCN_OFFMASK");
+    PP_REQUIRE(a->groups == 1 || (a->out_dtype == PP_F32 && a->residual == nullptr && a->preadd == nullptr && a->fuse == PP_FUSE_NONE), PP_ERR_ARG,
+               "pp_conv2d: grouped / batched split-plane layers write plain fp32 and take no epilogue operands (the volume GEMM)");
     PP_REQUIRE(((a->out_lo | a->out2_lo | a->preadd_lo | a->res_lo | a->fuse_a_lo | a->fuse_b_lo) & 7) == 0 && a->out_lo >= 0 &&
                    a->out2_lo >= 0 && a->preadd_lo >= 0 && a->res_lo >= 0 && a->fuse_a_lo >= 0 && a->fuse_b_lo >= 0,
                PP_ERR_ALIGN, "pp_conv2d: split-plane lo offsets must be non-negative multiples of 8 elements");
@@ -574,8 +576,11 @@ extern "C" int pp_conv2d(const pp_conv_args_t* a, void* stream) {
                PP_ERR_ARG, "pp_conv2d: split-plane epilogue operands need their lo offsets");
     // split == 2: TRI-PRODUCT K format (per tap 4 hi + 4 lo chunks of 32 channels, weights [W_hi | W_lo]): the halo-tile kernel only;
     // split == 1: every block walked three times by a plain K loop: the LDS-DMA (v2) kernel
-    const int rc = a->split == 2 ? conv_v3s_dispatch(p, a->impl == 71 || a->impl == 72 ? a->impl : 0, st)
-                                 : conv_v2s_dispatch(p, (a->impl >= 10 && a->impl < 70) || a->impl >= 110 ? a->impl : 0, st);
+    // ... or, outside the halo family (1x1, strided, batched GEMM, sources that are no multiples of 32 channels), the v2 kernel's tri step
+    const int v2cfg = (a->impl >= 10 && a->impl < 70) || a->impl >= 110 ? a->impl : 0;
+    int rc = -1000;
+    if (a->split == 2 && v2cfg == 0) rc = conv_v3s_dispatch(p, a->impl == 71 || a->impl == 72 ? a->impl : 0, st);
+    if (rc == -1000) rc = conv_v2s_dispatch(p, v2cfg, st);
     PP_REQUIRE(rc != -1000, PP_ERR_ARG, "pp_conv2d: no split-plane kernel for this layer (split %d, kchunks %d, %dx%d taps, impl %d)", a->split,
                a->kchunks, a->tap_h, a->tap_w, a->impl);
     return rc;

@@ -5,7 +5,7 @@
 namespace pp {
 
 int conv_v2s_dispatch(const ConvParams& p, int cfg, hipStream_t stream) {
-  if (p.kchunks % 8 != 0 || p.M >= (1ll << 31) || (long long)p.N * p.H * p.W >= (1ll << 31) || p.groups != 1) return -1000;
+  if (p.kchunks % 8 != 0 || p.M >= (1ll << 31) || (long long)p.N * p.H * p.W >= (1ll << 31)) return -1000;
   bool uni = p.ktable_uniform != 0 && p.pad_mode == 0 && (long long)p.cout_pad * p.kchunks * 16 < (1ll << 31);
   for (int i = 0; i < p.nsrc; ++i) uni = uni && (long long)p.N * p.H * p.W * p.src[i].cstride * 2 < (1ll << 31);
   if (cfg >= 100) { uni = false; cfg -= 100; }
@@ -15,6 +15,14 @@ int conv_v2s_dispatch(const ConvParams& p, int cfg, hipStream_t stream) {
     else if (p.cout_g > 32) cfg = 22;
     else if (p.cout_g > 16) cfg = 32;
     else cfg = 42;
+  }
+  if (p.split == 2) {      // tri-product K format: 64-wide K steps only
+    switch (cfg) {
+      case 12: return launch_v2<128, 128, 64, 2, 2, 2, 0, true, true>(p, uni, stream);
+      case 13: return launch_v2<256, 128, 64, 4, 2, 3, 0, true, true>(p, uni, stream);
+      case 22: return launch_v2<256, 64, 64, 4, 1, 2, 0, true, true>(p, uni, stream);
+      default: return -1000;
+    }
   }
   switch (cfg) {
     case 12: return launch_v2<128, 128, 64, 2, 2, 2, 0, true>(p, uni, stream);

@@ -8,6 +8,7 @@ namespace pp {
 struct ConvSrc {
   const char* ptr;
   int cstride, choff, cgroup;
+  int lo;                         // split-plane source: element offset of its lo plane (pp_conv_src_t.lo_off; tri-product layers)
 };
 
 struct ConvParams {

@@ -21,8 +21,11 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// SPLIT: split-plane ("f16x3") epilogue operands (pp_conv_args_t.split; see conv_epilogue.h).  The K loop is unchanged.
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int S, bool UNI, int SCHED = 0, bool SPLIT = false>
+// SPLIT: split-plane ("f16x3") epilogue operands (pp_conv_args_t.split; see conv_epilogue.h).
+// TRI (with SPLIT, BK 64): TRI-PRODUCT K step (pp_conv_args_t.split == 2, conv.tri_ktable): the 8 chunks of a step are 4 chunks of the hi
+// plane and the same 4 channel chunks of the lo plane (the LDS row of a pixel = [32 ch hi | 32 ch lo], of a cout = [W_hi | W_lo]) and
+// the step issues W_hi x A_hi + W_hi x A_lo + W_lo x A_hi: 48 MFMAs per 16 fragment reads and per stage instead of 32 (see conv_halo.h).
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int S, bool UNI, int SCHED = 0, bool SPLIT = false, bool TRI = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N <= 4 && BM * BN <= 128 * 128) ? 2 : 1) void conv_gemm_v2_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the body uses device-only types (__amdgpu_buffer_rsrc_t): the host pass only needs the stub
   typedef _Float16 T;
@@ -206,7 +209,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N <= 4 && 
     const int rowbytes = s == 1 ? srowb[1] : s == 2 ? srowb[2] : s == 3 ? srowb[3] : srowb[0];
     const bool live = s != 255;
     const int tapoff = dy * p.W + dx;
-    const int coff = e[3] * 2 + lc * 16;
+    // (TRI: logical chunks 0..3 = 32 channels of the hi plane, 4..7 = the same channels of the source's lo plane)
+    const int lob = TRI ? (s == 1 ? p.src[1].lo : s == 2 ? p.src[2].lo : s == 3 ? p.src[3].lo : p.src[0].lo) * 2 : 0;
+    const int coff = TRI ? e[3] * 2 + (lc & 3) * 16 + ((lc & 4) ? lob : 0) : e[3] * 2 + lc * 16;
     char* abase = lds + buf * STAGE;
 #pragma unroll
     for (int j = 0; j < A_PER_WAVE; ++j) {
@@ -292,6 +297,38 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N <= 4 && 
           for (int b = 0; b < TM; ++b)
             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[a], af[b], acc[a][b], 0, 0, 0);
       }
+    } else if constexpr (SCHED == 0 && TRI) {
+      static_assert(!TRI || (SPLIT && BK == 64), "tri-product step: split-plane layers, 64-wide K steps");
+      if (more) {
+        if constexpr (UNI) {
+          entry_ready(e1);
+          issue_uni(ks + S - 1, nbuf, e1);
+        } else {
+          entries_ready(E);
+          issue(ks + S - 1, nbuf, E);
+        }
+      }
+      f16x8 af[2][TM], bf[2][TN];          // kk 0 = hi plane / W_hi, kk 1 = lo plane / W_lo
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int so = ((kk * 4 + (lane >> 4)) ^ fswz) * 16;
+#pragma unroll
+        for (int t = 0; t < TM; ++t) af[kk][t] = *reinterpret_cast<const f16x8*>(sb + a_off + t * 16 * ROWB + so);
+#pragma unroll
+        for (int t = 0; t < TN; ++t) bf[kk][t] = *reinterpret_cast<const f16x8*>(sb + b_off + t * 16 * ROWB + so);
+      }
+#pragma unroll
+      for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[0][a], af[1][b], acc[a][b], 0, 0, 0);   // W_hi x A_lo
+#pragma unroll
+      for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[1][a], af[0][b], acc[a][b], 0, 0, 0);   // W_lo x A_hi
+#pragma unroll
+      for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[0][a], af[0][b], acc[a][b], 0, 0, 0);   // W_hi x A_hi
     } else if constexpr (SCHED == 0) {
       if (more) {
         if constexpr (UNI) {
@@ -431,7 +468,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N <= 4 && 
 #endif
 }
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int S, int SCHED = 0, bool SPLIT = false>
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int S, int SCHED = 0, bool SPLIT = false, bool TRI = false>
 static int launch_v2(ConvParams p, bool uni, hipStream_t stream) {
   p.tiles_m = (int)((p.M + BM - 1) / BM);
   p.tiles_n = (p.cout_g + BN - 1) / BN;
@@ -439,9 +476,9 @@ static int launch_v2(ConvParams p, bool uni, hipStream_t stream) {
   const dim3 grid((unsigned)nblk), block(64 * WAVES_M * WAVES_N);
   // the uniform-step fast path needs uniform steps at this BK (flag bit = chunks per step) -- see conv_v2_dispatch
   if (uni && (p.ktable_uniform & (BK / 8)))
-    hipLaunchKernelGGL((conv_gemm_v2_kernel<BM, BN, BK, WAVES_M, WAVES_N, S, true, SCHED, SPLIT>), grid, block, 0, stream, p);
+    hipLaunchKernelGGL((conv_gemm_v2_kernel<BM, BN, BK, WAVES_M, WAVES_N, S, true, SCHED, SPLIT, TRI>), grid, block, 0, stream, p);
   else
-    hipLaunchKernelGGL((conv_gemm_v2_kernel<BM, BN, BK, WAVES_M, WAVES_N, S, false, SCHED, SPLIT>), grid, block, 0, stream, p);
+    hipLaunchKernelGGL((conv_gemm_v2_kernel<BM, BN, BK, WAVES_M, WAVES_N, S, false, SCHED, SPLIT, TRI>), grid, block, 0, stream, p);
   return launch_status("pp_conv2d(v2)");
 }
 

@@ -20,7 +20,7 @@ FUSE_NONE, FUSE_GRU_ZR, FUSE_GRU_H, FUSE_DCN_OFFMASK = 0, 1, 2, 3
 
 class ConvSrc(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("cstride", C.c_int32), ("choff", C.c_int32), ("cgroup", C.c_int32),
-                ("pad_", C.c_int32)]
+                ("lo_off", C.c_int32)]
 
 
 class ConvArgs(C.Structure):

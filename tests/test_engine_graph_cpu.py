@@ -139,7 +139,9 @@ def test_raft_split_plane_engine_graph(models):
             eng = raft._get_engine("f16x3", torch.device("cpu"))
             assert eng.split and not eng.corr_otf
             assert eng.convc2.tri and eng.convc2.kchunks == 2 * 9 * 32           # halo-tile layer: tri-product format (both planes per K block)
-            assert eng.convc1.split and not eng.convc1.tri and eng.convc1.kchunks == 128      # 1x1 over 328 channels: blocks walked three times
+            assert eng.convc1.tri and eng.convc1.kchunks == 11 * 8 and eng.convc1.ktable_uniform == 0   # 1x1 over 328 channels: 10 full blocks + a ragged one
+            assert eng.convf1.split and not eng.convf1.tri and eng.convf1.kchunks == 48            # 7x1 over 16 channels: blocks walked three times (7 x 2 x 3 -> 48)
+            assert eng.fnet["conv1"].split and not eng.fnet["conv1"].tri                            # 7x7 over the 8-channel image: plain
             ff, fb = raft(fr, iters=int(g["iters"]))
         finally:
             raft.precision = None
@@ -188,3 +190,15 @@ def test_split_ktable_and_weight_packing():
     ref2 = torch.relu(torch.nn.functional.conv2d(torch.cat([x0, x1], -1).permute(0, 3, 1, 2).double(), w2.double(), b2.double(), padding=1))
     err2 = (merge_planes(y2).double() - ref2.permute(0, 2, 3, 1)).abs().max() / ref2.abs().max()
     assert err2 < 2e-6, err2
+    # a strided 3x3 over a 72-channel source (ragged last block: 8 channels + zero chunks in both halves of its steps): v2 tri step
+    w3, b3 = torch.randn(96, 72, 3, 3, generator=g) * 0.1, torch.randn(96, generator=g)
+    x3 = torch.randn(1, 9, 11, 72, generator=g)
+    with emulated_device_ops():
+        l3 = pconv.ConvLayer(w3, b3, stride=2, padding=1, src_channels=[72], dtype=torch.float16, device="cpu", split=True, tri=True)
+        assert l3.tri and l3.kchunks == 3 * 9 * 8 and l3.ktable_uniform == 0
+        k3 = l3.ktable.numpy()
+        assert (k3[16 * 9 + 1, 2] & 0xff) == 255 and (k3[16 * 9 + 5, 2] & 0xff) == 255 and (k3[16 * 9 + 5, 2] & pconv.KT_PLANE_LO)
+        y3 = l3([split_planes(x3)], act="relu")
+    ref3 = torch.relu(torch.nn.functional.conv2d(x3.permute(0, 3, 1, 2).double(), w3.double(), b3.double(), stride=2, padding=1))
+    err3 = (merge_planes(y3).double() - ref3.permute(0, 2, 3, 1)).abs().max() / ref3.abs().max()
+    assert err3 < 2e-6, err3

@@ -52,16 +52,20 @@ CASES = [
     dict(name="halo3x3_linear_residual", cin=[128], cout=128, k=(3, 3), pad=1, residual=True, act2="relu"),
     dict(name="halo3x3_preadd", cin=[128], cout=128, k=(3, 3), pad=1, act="tanh", preadd=True),
     # v2 LDS-DMA kernel: strided 7x7 over the 3-channel image, 96-channel layers, 1x1 over the 324-channel lookup, wide fp32 output
-    dict(name="v2_7x7s2_c3", cin=[3], cout=64, k=(7, 7), stride=2, pad=3, out_f32=True),
+    dict(name="v2_7x7s2_c3", cin=[3], cout=64, k=(7, 7), stride=2, pad=3, out_f32=True, exp_tri=False),            # 8-channel source: plain three-walk format
     dict(name="v2_3x3s2_c96", cin=[64], cout=96, k=(3, 3), stride=2, pad=1, act="relu"),
-    dict(name="v2_3x3_c96_residual", cin=[96], cout=96, k=(3, 3), pad=1, act="relu", residual=True, act2="relu", tri=False),
+    dict(name="v2_3x3_c96_residual", cin=[96], cout=96, k=(3, 3), pad=1, act="relu", residual=True, act2="relu", tri=False, exp_tri=False),
     dict(name="v2_1x1_c324", cin=[324], cout=256, k=(1, 1), pad=0, act="relu"),
     dict(name="v2_1x1_576_f32out", cin=[256], cout=576, k=(1, 1), pad=0, out_f32=True, out_scale=0.25),
-    dict(name="v2_7x1_c16", cin=[16], cout=128, k=(7, 1), pad=(3, 0), act="relu"),
+    dict(name="v2_7x1_c16", cin=[16], cout=128, k=(7, 1), pad=(3, 0), act="relu", exp_tri=False),
     dict(name="v2_1x1_linear_residual_c128", cin=[128], cout=128, k=(1, 1), pad=0, residual=True),
     # halo-eligible layers forced through the v2 kernel's plain split format (every block walked three times)
-    dict(name="v2_plain_3x3_c128_preadd", cin=[128], cout=128, k=(3, 3), pad=1, act="tanh", preadd=True, tri=False),
-    dict(name="v2_plain_3x3_c64_two_src", cin=[192, 64], cout=64, k=(3, 3), pad=1, act="relu", tri=False),
+    dict(name="v2_plain_3x3_c128_preadd", cin=[128], cout=128, k=(3, 3), pad=1, act="tanh", preadd=True, tri=False, exp_tri=False),
+    dict(name="v2_plain_3x3_c64_two_src", cin=[192, 64], cout=64, k=(3, 3), pad=1, act="relu", tri=False, exp_tri=False),
+    dict(name="v2_plain_1x1_c324", cin=[324], cout=256, k=(1, 1), pad=0, act="relu", tri=False, exp_tri=False),
+    # (the other v2_* cases above -- strided 3x3, 1x1 over 324 / 256 / 128 channels -- take the v2 kernel's TRI step; the 324-channel source
+    #  has a ragged last block: zero chunks in both halves of its steps, generic per-chunk gather)
+    dict(name="v2_tri_3x3s2_c72_ragged", cin=[72], cout=96, k=(3, 3), stride=2, pad=1, act="relu", tri=True),
     # tri-product format over a 96-channel source (32-channel blocks) and 32 + 64 channel sources
     dict(name="halo3x3_c96_src96", cin=[96], cout=96, k=(3, 3), pad=1, act="relu", residual=True, act2="relu"),
     dict(name="halo5x1_c64_src32_64", cin=[32, 64], cout=64, k=(5, 1), pad=(2, 0), act="relu"),
@@ -79,7 +83,7 @@ def test_split_plane_conv(dev, case):
     w = torch.randn(cout, sum(cin), *k, generator=g) / math.sqrt(sum(cin) * k[0] * k[1])
     b = torch.randn(cout, generator=g) * 0.3
     layer = ConvLayer(w, b, stride=stride, padding=pad, src_channels=cin, dtype=torch.float16, device=dev, split=True, tri=case.get("tri"))
-    assert layer.kchunks % 8 == 0 and layer.split and layer.tri == case.get("fmt_tri", case["name"].startswith("halo"))
+    assert layer.kchunks % 8 == 0 and layer.split and layer.tri == case.get("exp_tri", True), (layer.tri, case)
     # the weights the kernel multiplies with: W_hi + W_lo (22 bits of w)
     w_eff = (w.half().double() + (w - w.half().float()).half().double())
     ref = F.conv2d(torch.cat(vals, 1), w_eff, b.double(), stride, pad) * case.get("out_scale", 1.0)
