@@ -299,7 +299,9 @@ class ConvLayer:
         a.impl = 3 if self.split3 else self.impl
         a.ktable_uniform = self.ktable_uniform
         a.tap_h, a.tap_w = self.tap_hw
-        self._keep = (srcs, out, residual, dcn_offmask, preadd, fuse)
+        # (no references are kept past the launch: the caching allocator is stream-ordered, so the operands may be released as soon as the
+        #  kernel is enqueued -- round 2 parked (srcs, out, ...) of the LAST call on every layer, which kept ~70 GB of dead activations of
+        #  the flow-completion / RAFT layers alive through the rest of a 720p pass)
         hip.conv2d_raw(a, cin_read=sum(self.src_cpad) * self.groups, on=x0, split_k=(2 if self.tri else 3) if self.split else 0)
         return out
 

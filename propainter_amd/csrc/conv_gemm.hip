@@ -577,9 +577,10 @@ extern "C" int pp_conv2d(const pp_conv_args_t* a, void* stream) {
     // split == 2: TRI-PRODUCT K format (per tap 4 hi + 4 lo chunks of 32 channels, weights [W_hi | W_lo]): the halo-tile kernel only;
     // split == 1: every block walked three times by a plain K loop: the LDS-DMA (v2) kernel
     // ... or, outside the halo family (1x1, strided, batched GEMM, sources that are no multiples of 32 channels), the v2 kernel's tri step
-    const int v2cfg = (a->impl >= 10 && a->impl < 70) || a->impl >= 110 ? a->impl : 0;
+    const int v2cfg = (a->impl >= 10 && a->impl < 70) || a->impl > 110 ? a->impl : 0;
     int rc = -1000;
-    if (a->split == 2 && a->impl == 0) rc = conv_head_dispatch(p, st);          // 3x3 heads with <= 4 couts: streaming dot products
+    if (a->split == 2 && (a->impl == 0 || a->impl == 110)) rc = conv_head_dispatch(p, st, a->impl == 110);   // 3x3 heads with <= 4 couts (opt-in)
+    PP_REQUIRE(a->impl != 110 || rc != -1000, PP_ERR_ARG, "pp_conv2d: impl 110 (streaming head kernel) not available for this layer");
     if (rc == -1000 && a->split == 2 && v2cfg == 0) rc = conv_v3s_dispatch(p, a->impl == 71 || a->impl == 72 ? a->impl : 0, st);
     if (rc == -1000) rc = conv_v2s_dispatch(p, v2cfg, st);
     PP_REQUIRE(rc != -1000, PP_ERR_ARG, "pp_conv2d: no split-plane kernel for this layer (split %d, kchunks %d, %dx%d taps, impl %d)", a->split,
@@ -595,8 +596,9 @@ extern "C" int pp_conv2d(const pp_conv_args_t* a, void* stream) {
     PP_REQUIRE(a->impl == 0, PP_ERR_ARG, "pp_conv2d: impl 80 (A-stationary GEMM) not available for this shape");
   }
   if (a->dtype == PP_F16 && !deform && (a->impl == 0 || a->impl == 110)) {
-    // 3x3 heads with at most 4 couts (flow / RGB heads): HBM-bound dot products on the VALU instead of a 16-cout MFMA tile
-    const int rc = conv_head_dispatch(p, st);
+    // 3x3 heads with at most 4 couts (flow / RGB heads) as VALU dot products instead of a 16-cout MFMA tile: measured neutral, opt-in
+    // (PP_HEAD_KERNEL=1 / impl 110; conv_head.hip)
+    const int rc = conv_head_dispatch(p, st, a->impl == 110);
     if (rc != -1000) return rc;
     PP_REQUIRE(a->impl == 0, PP_ERR_ARG, "pp_conv2d: impl 110 (streaming head kernel) not available for this layer");
   }

@@ -136,9 +136,11 @@ __global__ __launch_bounds__(256) void conv_head_kernel(const ConvParams p) {
 }
 
 // Returns -1000 when the layer is outside this kernel's family.
-int conv_head_dispatch(const ConvParams& p, hipStream_t stream) {
-  static const bool off = getenv("PP_NO_HEAD_KERNEL") != nullptr && getenv("PP_NO_HEAD_KERNEL")[0] == '1';      // (A/B runs)
-  if (off) return -1000;
+int conv_head_dispatch(const ConvParams& p, hipStream_t stream, bool force) {
+  // MEASURED (profiles/r3l_head_kernel_ab.txt, four interleaved bench runs on one box): no gain over the 16-cout MFMA tiles -- 1 516 / 1 522 ms
+  // per clip without, 1 523 / 1 526 with this kernel.  Not dispatched by default; PP_HEAD_KERNEL=1 (or impl 110 for fp16 layers) selects it.
+  static const bool on = getenv("PP_HEAD_KERNEL") != nullptr && getenv("PP_HEAD_KERNEL")[0] == '1';
+  if (!on && !force) return -1000;
   if (p.cout_g > 4 || p.tap_h != 3 || p.tap_w != 3 || p.sh != 1 || p.sw != 1 || p.ph != 1 || p.pw != 1 || p.OH != p.H || p.OW != p.W) return -1000;
   if (p.nsrc != 1 || p.groups != 1 || p.pad_mode != 0 || p.residual != nullptr || p.preadd != nullptr || p.fuse != PP_FUSE_NONE ||
       p.act2 != PP_ACT_NONE || p.dcn != nullptr)

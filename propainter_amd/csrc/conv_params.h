@@ -67,7 +67,7 @@ int conv_v4_dispatch(const ConvParams& p, int cfg, hipStream_t stream);
 // conv_dcn.hip (patch-staged modulated deformable 3x3 convolution, fp16); returns -1000 when the layer is outside that family
 int conv_dcn_dispatch(const ConvParams& p, hipStream_t stream, int dbg = 0);
 // conv_head.hip (streaming 3x3 convolution with at most 4 couts, VALU dot products); -1000 outside that family
-int conv_head_dispatch(const ConvParams& p, hipStream_t stream);
+int conv_head_dispatch(const ConvParams& p, hipStream_t stream, bool force = false);
 // conv_gemm_ast.hip (A-stationary short-K GEMM); returns -1000 when the layer is outside that family
 int conv_ast_dispatch(const ConvParams& p, int cfg, hipStream_t stream);
 

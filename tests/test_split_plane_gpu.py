@@ -238,3 +238,38 @@ def test_split_plane_raft_matches_reference_golden():
     eb = (fb[0].cpu() - torch.from_numpy(g["flows_b"])).pow(2).sum(1).sqrt()
     print(f"SPLIT_PARITY raft golden EPE: fw mean {ef.mean():.2e} max {ef.max():.2e}, bw mean {eb.mean():.2e} max {eb.max():.2e}")
     assert ef.mean() < 5e-5 and ef.max() < 2e-3 and eb.mean() < 5e-5 and eb.max() < 2e-3
+
+
+@pytest.mark.parametrize("split", [False, True], ids=["f16", "split"])
+@pytest.mark.parametrize("cin,cout,act,out_f32", [(256, 2, None, True), (64, 3, "tanh", False)], ids=["flow_head", "rgb_head"])
+def test_streaming_head_kernel(dev, cin, cout, act, out_f32, split):
+    """conv_head.hip (impl 110; opt-in: measured neutral against the 16-cout MFMA tiles, profiles/r3l_head_kernel_ab.txt): 3x3 heads with
+    <= 4 couts as v_dot2 dot products over an LDS halo patch, plain fp16 and split-plane tri-product form, ragged tiles (37 x 45 map)."""
+    from propainter_amd.conv import ConvLayer, pad8
+    if split and not out_f32:
+        pytest.skip("split-plane heads write plain fp32")
+    g = torch.Generator().manual_seed(21)
+    N, H, W = 2, 37, 45
+    x = torch.randn(N, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g) * 0.3
+    fn = {None: lambda v: v, "tanh": torch.tanh}[act]
+    if split:
+        xt, xv = planes(x)
+        w_eff = w.half().double() + (w - w.half().float()).half().double()
+        ref = fn(F.conv2d(xv, w_eff, b.double(), 1, 1))
+        layer = ConvLayer(w, b, padding=1, src_channels=[cin], dtype=torch.float16, device=dev, split=True)
+        tol = RTOL
+    else:
+        xt = x.permute(0, 2, 3, 1).contiguous().half().cuda()
+        ref = fn(F.conv2d(xt.float().cpu().permute(0, 3, 1, 2).double(), w.half().double(), b.double(), 1, 1))
+        layer = ConvLayer(w, b, padding=1, src_channels=[cin], dtype=torch.float16, device=dev)
+        tol = 2e-3
+    layer.impl = 110
+    out = layer([xt], act=act, out_dtype=torch.float32 if out_f32 else None)
+    layer.impl = 0
+    base = layer([xt], act=act, out_dtype=torch.float32 if out_f32 else None)
+    torch.cuda.synchronize()
+    assert out.shape[-1] == pad8(cout) and (out[..., cout:] == 0).all()
+    check(f"head_{cin}_{cout}", out[..., :cout].permute(0, 3, 1, 2), ref, tol)
+    check(f"head_vs_mfma_{cin}_{cout}", out[..., :cout].permute(0, 3, 1, 2), base[..., :cout].permute(0, 3, 1, 2), tol)
