@@ -332,6 +332,7 @@ def main():
     torch.cuda.synchronize()
     eager_ms = (time.perf_counter() - t_e) * 1e3
     peak_eager = torch.cuda.max_memory_allocated(dev)
+    peak_eager_reserved = torch.cuda.max_memory_reserved(dev)      # what the caching allocator holds from the driver (all stream pools)
     exchange_stats.clear()
     graph = None
     capture_s = None
@@ -562,10 +563,13 @@ def main():
                        "raft_dtype": args.raft_dtype, "stages_dtype": "f16" if fp16 else "f32", "parallelism": par,
                        "window_streams": args.window_streams, "raft_streams": args.raft_streams},
             "roofline": roof, "cpu_baseline": cpu, "parity": parity, "raft_precisions": raft_precisions,
-            "memory": {"peak_allocated_GB_eager_pass": peak_eager / 1e9, "peak_allocated_GB_process": peak_total / 1e9,
-                       "note": "torch.cuda.max_memory_allocated; the eager pass is what a one-shot CLI run needs, the process "
-                               "figure adds the hipGraph's private pool; reference README.md:192 quotes 25 GB fp16 at 720x1280x80 "
-                               "(it runs RAFT in 4-frame clips; this engine batches all 158 pair-directions)"},
+            "memory": {"peak_allocated_GB_eager_pass": peak_eager / 1e9, "peak_reserved_GB_eager_pass": peak_eager_reserved / 1e9,
+                       "peak_allocated_GB_process": peak_total / 1e9, "peak_reserved_GB_process": torch.cuda.max_memory_reserved(dev) / 1e9,
+                       "note": "allocated = live tensors (torch.cuda.max_memory_allocated), reserved = what the caching allocator holds "
+                               "from the driver over all stream pools (max_memory_reserved: the figure a device-memory monitor shows); the "
+                               "eager pass is what a one-shot CLI run needs, the process figures add the hipGraphs' private pools; "
+                               "reference README.md:192 quotes 25 GB fp16 at 720x1280x80 (it runs RAFT in 4-frame clips; this engine "
+                               "batches the pair-directions in chunks with a 40 GB budget for the fp32 correlation volumes in flight)"},
             "exchange": exch, "stages_ms": stages,
             "submission": submission,
             "eager_ms_per_step": eager_ms, "graph_capture_s": capture_s,
