@@ -10,6 +10,8 @@ Exact-math savings over the reference call pattern (results unchanged): the feat
 per frame instead of 3x per pair-direction; the convex-upsampling mask head runs only on the last iteration
 (RAFT/raft.py:143-144 discards the rest); all pair-directions of a clip advance through the GRU as one batch.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -323,6 +325,8 @@ class RAFT_bi(nn.Module):
         self.batch_invariant = True
         self.supports_streams = True          # forward(..., streams=n): encoders / pair groups on n HIP streams
         self.max_pairs = max_pairs
+        # fp32 all-pairs correlation volumes + pyramids of the pair-direction chunks in flight (volume modes "f32" / "f16x3")
+        self.volume_budget_bytes = float(os.environ.get("PP_RAFT_VOLUME_GB", "40")) * 1e9
         self._engines = {}
         self.to(device)
         self.eval()
@@ -381,7 +385,7 @@ class RAFT_bi(nn.Module):
         if eng.corr_otf:      # largest activation of the update block: the [P, h8, w8, 328] lookup tile, < 2 GiB (32-bit buffer offsets)
             chunk = self.max_pairs or max(1, ((1 << 31) - 1) // (n8 * 328 * 2))
         else:                 # fp32 all-pairs pyramid: 1.34 x n8^2 x 4 bytes per pair-direction, 40 GB over the chunks in flight
-            chunk = self.max_pairs or max(1, int(40e9 // lanes // (n8 * n8 * 4 * 1.34)))
+            chunk = self.max_pairs or max(1, int(self.volume_budget_bytes // lanes // (n8 * n8 * 4 * 1.34)))
             if eng.split:     # ... and the largest split-plane activation (the [P, h8, w8, 2 x 328] lookup tile) below 2 GiB
                 chunk = min(chunk, max(1, ((1 << 31) - 1) // (n8 * 656 * 2)))
         if lanes > 1:
