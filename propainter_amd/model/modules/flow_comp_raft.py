@@ -385,7 +385,10 @@ class RAFT_bi(nn.Module):
         if eng.corr_otf:      # largest activation of the update block: the [P, h8, w8, 328] lookup tile, < 2 GiB (32-bit buffer offsets)
             chunk = self.max_pairs or max(1, ((1 << 31) - 1) // (n8 * 328 * 2))
         else:                 # fp32 all-pairs pyramid: 1.34 x n8^2 x 4 bytes per pair-direction, 40 GB over the chunks in flight
-            chunk = self.max_pairs or max(1, int(self.volume_budget_bytes // lanes // (n8 * n8 * 4 * 1.34)))
+            per_pair = n8 * n8 * 4 * 1.34
+            # (at least 4 pair-directions per chunk: at 1080x1920 a pair's pyramid is 5.6 GB and 40 GB over 3 lanes would leave 2-pair
+            #  chunks -- convolution launches over 64 800 pixels that do not fill the chip)
+            chunk = self.max_pairs or max(min(4, -(-P // lanes)), int(self.volume_budget_bytes // lanes // per_pair))
             if eng.split:     # ... and the largest split-plane activation (the [P, h8, w8, 2 x 328] lookup tile) below 2 GiB
                 chunk = min(chunk, max(1, ((1 << 31) - 1) // (n8 * 656 * 2)))
         if lanes > 1:
