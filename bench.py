@@ -358,7 +358,10 @@ def main():
         from propainter_amd.pipeline import ClipGraph
         t_c = time.perf_counter()
         try:
-            graph = ClipGraph(models, L, H, W, cfg, dev, example=(frames_dev, masks_dev, masks_dev))
+            # the graph gets a private pool as large as the eager pass's: when the eager pools already hold more than a third of the
+            # device (long clips / 1080p), hand them back to the driver first
+            big = torch.cuda.memory_reserved(dev) > torch.cuda.get_device_properties(dev).total_memory // 3
+            graph = ClipGraph(models, L, H, W, cfg, dev, example=(frames_dev, masks_dev, masks_dev), release_eager_pool=big)
             torch.cuda.synchronize()
         except Exception as e:       # capture refused (driver / runtime state): measure the eager submission instead of dying
             sys.stderr.write(f"[bench] hipGraph capture failed on rank {rank} ({type(e).__name__}: {e}); falling back to eager launches\n")

@@ -204,6 +204,35 @@ def test_raft_720p_endpoint_error_vs_oracle(models):
     assert not bad, bad
 
 
+def test_raft_1080p_endpoint_error_vs_oracle(models):
+    """RAFT at BASELINE config 5's resolution (1080x1920: 135x240 maps at 1/8 resolution -- ragged 8x16 / 16x8 halo tiles, a 5.6 GB
+    correlation pyramid per pair-direction in the volume modes) against the fp32 CPU oracle, at the two precisions the configs run:
+    split-plane f16x3 and fp16 (limits: 1.5 x the 720p ones)."""
+    from propainter_amd.synthetic import synthetic_clip
+    H, W, iters = 1080, 1920, 20
+    fr = torch.from_numpy(synthetic_clip(2, H, W)).permute(0, 3, 1, 2).float().div(255)[None] * 2 - 1
+    raft = models[0]
+    sd = {k: v.float().cpu() for k, v in raft.fix_raft.state_dict().items()}
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    with torch.no_grad():
+        ref_f, ref_b = O.raft_bi(sd, fr, iters=iters)
+    msgs, bad = [], []
+    for prec in ("f16x3", "f16"):
+        lim_mean, lim_max = RAFT_720P_EPE_LIMIT[prec]
+        raft.precision = prec
+        try:
+            ff, fb = raft(fr.cuda(), iters=iters)
+            torch.cuda.synchronize()
+        finally:
+            raft.precision = None
+        epe = torch.cat([(ff.cpu() - ref_f).pow(2).sum(2).sqrt().flatten(), (fb.cpu() - ref_b).pow(2).sum(2).sqrt().flatten()])
+        msgs.append(f"RAFT_1080P_EPE {prec}: mean {epe.mean():.3e} max {epe.max():.3e} px (flow range {ref_f.abs().max():.1f} px)")
+        if not (epe.mean() < 1.5 * lim_mean and epe.max() < 1.5 * lim_max):
+            bad.append(msgs[-1])
+    print("\n".join(msgs))
+    assert not bad, bad
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.float16], ids=["f32", "f16"])
 def test_stages_at_432x240_vs_oracle(models, sds, dt):
     """Flow completion (t = 6) and one generator window (t = 7, l_t = 5) at BASELINE config-2 resolution against the CPU
