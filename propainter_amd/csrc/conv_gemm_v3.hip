@@ -86,6 +86,18 @@ int conv_v3_dispatch(const ConvParams& p, int cfg, hipStream_t stream) {
     if (kh == 1 && kw == 5) return launch_v3<16, 16, 1, 5, 128, false, 0, 128>(p, stream);
     return -1000;
   }
+  if (cfg == 112 || cfg == 113) {   // weight fragments straight from L2 into registers, one step ahead (DIRB); 113 = + phase timing
+    if (kh == 3 && kw == 3) return cfg == 112 ? launch_v3<8, 16, 3, 3, 128, false, 0, 64, false, false, true>(p, stream) : launch_v3<8, 16, 3, 3, 128, true, 0, 64, false, false, true>(p, stream);
+    if (kh == 1 && kw == 5) return cfg == 112 ? launch_v3<8, 16, 1, 5, 128, false, 0, 64, false, false, true>(p, stream) : launch_v3<8, 16, 1, 5, 128, true, 0, 64, false, false, true>(p, stream);
+    if (kh == 5 && kw == 1) return cfg == 112 ? launch_v3<16, 8, 5, 1, 128, false, 0, 64, false, false, true>(p, stream) : launch_v3<16, 8, 5, 1, 128, true, 0, 64, false, false, true>(p, stream);
+    return -1000;
+  }
+  if (cfg == 111) {   // weight pieces of a wave 4 KB apart, M0 rewritten per piece (the layout before the one-M0 / instruction-offset form)
+    if (kh == 3 && kw == 3) return launch_v3<8, 16, 3, 3, 128, false, 12>(p, stream);
+    if (kh == 1 && kw == 5) return launch_v3<8, 16, 1, 5, 128, false, 12>(p, stream);
+    if (kh == 5 && kw == 1) return launch_v3<16, 8, 5, 1, 128, false, 12>(p, stream);
+    return -1000;
+  }
   if (cfg == 109) {   // the pre-activation addend / residual read by the epilogue instead of going through the matrix cores (A/B)
     if (kh == 3 && kw == 3) return launch_v3<8, 16, 3, 3, 128, false, 11>(p, stream);
     if (kh == 1 && kw == 5) return launch_v3<8, 16, 1, 5, 128, false, 11>(p, stream);
@@ -160,9 +172,10 @@ int conv_v3_dispatch(const ConvParams& p, int cfg, hipStream_t stream) {
 }  // namespace pp
 
 // [diagnostic, not part of the public header] reads and clears the phase counters of the PROF build:
-// out[0..7] = {vmcnt wait, barrier wait, DMA issue, compute, main loop total, epilogue, waves, K steps} (cycles summed over waves)
+// out[0..7] = {vmcnt wait, barrier wait, DMA issue, compute, main loop total, epilogue, waves, K steps} (cycles summed over waves),
+// out[12] / out[13] = earliest block start / latest block end stamp since the last call (16 values)
 extern "C" int pp_debug_conv_prof(unsigned long long* out) {
-  unsigned long long zero[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long zero[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, ~0ull, 0, 0, 0};    // ([12] is a minimum)
   hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(pp::g_v3_prof), sizeof(zero));
   if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(pp::g_v3_prof), zero, sizeof(zero));
   return (int)e;

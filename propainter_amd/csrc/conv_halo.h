@@ -18,10 +18,23 @@ static __device__ __forceinline__ void v3_entry_ready(i32x4s& e) { asm volatile(
 static __device__ __forceinline__ void v3_dma16(__amdgpu_buffer_rsrc_t r, char* dst, int voff, int soff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lptr3_t)dst, 16, voff, soff, 0, 0);
 }
+// Several pieces into consecutive KBs of LDS from ONE M0 value: the 12-bit instruction offset IMM is added to the LDS address and to the
+// global address alike (MUBUF-to-LDS addressing), so the caller's `voff` carries the global offset MINUS IMM.
+template <int IMM>
+static __device__ __forceinline__ void v3_dma16_imm(__amdgpu_buffer_rsrc_t r, char* dst, int voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lptr3_t)dst, 16, voff, soff, IMM, 0);
+}
+template <int J, int N>
+struct V3WeightPieces {      // pieces J .. N-1 of a wave's weight stage: LDS dst + J KB, global voff[J] (compensated) + soff
+  static __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t r, char* dst, const int (&voff)[N], int soff) {
+    v3_dma16_imm<J * 1024>(r, dst, voff[J], soff);
+    if constexpr (J + 1 < N) V3WeightPieces<J + 1, N>::issue(r, dst, voff, soff);
+  }
+};
 #endif
 
 // PROF: diagnostic build that accumulates s_memtime deltas per phase into pp_debug_conv_prof() (see tools/bench_conv.py)
-static __device__ unsigned long long g_v3_prof[12];     // (per translation unit)
+static __device__ unsigned long long g_v3_prof[16];     // (per translation unit; [12] / [13] = earliest start / latest end stamp)
 
 // WMT: pixel rows of a wave tile.  64 (default): 64 x 64 wave tiles, 4 waves per 128 x 128 block tile, 2 waves per SIMD.
 // 32: 32 x 64 wave tiles, 8 waves per block tile, FOUR waves per SIMD at <= 128 registers -- more LDS fragment traffic per
@@ -39,8 +52,14 @@ static __device__ unsigned long long g_v3_prof[12];     // (per translation unit
 // the 80 KB of a block, every wave DMAs its own slice, and the tap steps of a channel block need NO block barrier -- only a counted
 // s_waitcnt on the wave's own DMA; the barrier remains once per channel block (the patch is shared).  MFMAs per barrier: x KH*KW.
 // (128-cout tiles would need 64 KB of private stages: one block per CU.)
-template <int TH, int TW, int KH, int KW, int BN, bool PROF = false, int STAGGER = 0, int WMT = 64, bool SPLIT = false, bool PRIVB = false>
-__global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : (SPLIT && BN == 128 ? 2 : 1)) void conv_halo_kernel(const ConvParams p) {
+// (two blocks of 128 pixels per CU: the allocator must stay within 256 registers -- the 5x1 128-cout tile took 259 and ran one wave per SIMD)
+#if defined(PP_HALO_LB_ROUND2)   // (A/B builds: the bound the fp16 instantiations had before)
+#define HALO_MIN_WAVES(th, tw, bn, wmt, split) ((split) && (bn) == 128 ? 2 : 1)
+#else
+#define HALO_MIN_WAVES(th, tw, bn, wmt, split) ((th) * (tw) == 128 && (wmt) == 64 && (bn) <= 128 ? 2 : 1)
+#endif
+template <int TH, int TW, int KH, int KW, int BN, bool PROF = false, int STAGGER = 0, int WMT = 64, bool SPLIT = false, bool PRIVB = false, bool DIRB = false>
+__global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : HALO_MIN_WAVES(TH, TW, BN, WMT, SPLIT)) void conv_halo_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef _Float16 T;
   constexpr int BM = TH * TW;                                   // 128 px (2 blocks/CU) or 256 px (8 waves, 1 block/CU)
@@ -54,17 +73,21 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : (SPLIT && BN =
   constexpr int PPW = PIECES / NW;                              // ... per wave
   constexpr int PATCH_BYTES = PIECES * 1024;
   static_assert(!PRIVB || (BN <= 64 && STAGGER == 0 && WMT == 64), "private weight stages: tiles of at most 64 couts");
+  static_assert(!DIRB || (!PRIVB && STAGGER == 0 && WMT == 64), "direct weight fragments: the plain schedule only");
   constexpr int BW_ROWS = PRIVB ? WN : BN;                     // weight rows of one stage buffer (the wave's own couts when private)
   constexpr int BSTAGE = BW_ROWS * 128;
   constexpr int B_INST = BW_ROWS / 8;                          // weight-tile DMA instructions per stage (8 rows each)
   constexpr int B_PER_WAVE = PRIVB ? B_INST : (B_INST + NW - 1) / NW;
   constexpr bool B_RAGGED = !PRIVB && (B_INST % NW) != 0;      // BN 16, shared stages: only waves 0..B_INST-1 fetch weights
-  constexpr int PIPE_BYTES = 2 * PATCH_BYTES + (PRIVB ? 2 * NW : 2) * BSTAGE;
+  // BCONTIG (shared stages): a wave's B_PER_WAVE weight pieces are CONSECUTIVE 8-row groups of the stage, so one M0 value + the
+  // instruction offset addresses all of them (an M0 rewrite between two LDS-DMA instructions serialises them)
+  constexpr bool BCONTIG = !PRIVB && STAGGER != 3 && STAGGER != 12 && B_PER_WAVE <= 4;
+  constexpr int PIPE_BYTES = 2 * PATCH_BYTES + (DIRB ? 0 : (PRIVB ? 2 * NW : 2) * BSTAGE);
   constexpr int EPI_WN = WN > 64 ? 64 : WN;                    // the epilogue stages at most 64 couts of the wave tile at a time
   constexpr int EPI_LD = EPI_WN + 4;
   constexpr int EPI_BYTES = NW * WM * EPI_LD * 4;
   constexpr int LDS_BYTES = PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES;
-  constexpr bool PRE_MFMA = STAGGER == 0 && BM == 128 && (BN == 128 || BN == 64) && WMT == 64 && PATCH_BYTES >= 16 * 1024;   // (STAGGER 11, impl 109: off, for A/B)
+  constexpr bool PRE_MFMA = (STAGGER == 0 || STAGGER == 12) && BM == 128 && (BN == 128 || BN == 64) && WMT == 64 && PATCH_BYTES >= 16 * 1024;   // (STAGGER 11, impl 109: off, for A/B)
   static_assert((BM == 128 || BM == 256) && (TW == 16 || TW == 8) && PPW <= 3 * NTAPS && (BN % 32 == 0 || BN == 16) &&
                     LDS_BYTES <= (BM == 128 ? 80 : 160) * 1024, "tile");
 
@@ -114,10 +137,10 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : (SPLIT && BN =
   for (int j = 0; j < B_PER_WAVE; ++j) {
     // shared stages: instruction j of the wave covers tile rows (j * NW + wave) * 8 ..; private stages: rows j * 8 .. of the wave's own
     // WN couts.  Weight rows are swizzled by slot ^ ((row >> 1) & 7) with the row counted inside the stage buffer.
-    int row = PRIVB ? n0 + wn * WN + j * 8 + rin : n0 + (j * NW + wave) * 8 + rin;
+    int row = PRIVB ? n0 + wn * WN + j * 8 + rin : (BCONTIG ? n0 + (wave * B_PER_WAVE + j) * 8 + rin : n0 + (j * NW + wave) * 8 + rin);
     if (row >= p.cout_pad) row = p.cout_pad - 1;          // clamped rows feed accumulators that are never stored
-    const int lcj = PRIVB ? (slot ^ ((4 * (j & 1) + (rin >> 1)) & 7)) : lc;
-    wvoff[j] = row * p.kchunks * 16 + lcj * 16;
+    const int lcj = PRIVB ? (slot ^ ((4 * (j & 1) + (rin >> 1)) & 7)) : (BCONTIG ? (slot ^ ((4 * ((wave * B_PER_WAVE + j) & 1) + (rin >> 1)) & 7)) : lc);
+    wvoff[j] = row * p.kchunks * 16 + lcj * 16 - (BCONTIG ? j * 1024 : 0);      // (BCONTIG: minus the instruction offset of piece j)
   }
   const int nrec = p.N * p.H * p.W;
   // (individual scalars, not arrays: a dynamically indexed private array would live in scratch, and scratch loads share
@@ -142,9 +165,18 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : (SPLIT && BN =
   } while (0)
 #define V3_ISSUE_B(ks_, par_)                                                                                   \
   do {                                                                                                          \
-    _Pragma("unroll") for (int j_ = 0; j_ < B_PER_WAVE; ++j_)                                                   \
-      if (!B_RAGGED || j_ * NW + wave < B_INST)                                                                 \
-        v3_dma16(rw, bst0 + (PRIVB ? wave * 2 + (par_) : (par_)) * BSTAGE + (PRIVB ? j_ : j_ * NW + wave) * 1024, wvoff[j_], (ks_) * 128); \
+    if constexpr (DIRB) {                                                                                       \
+      _Pragma("unroll") for (int kk_ = 0; kk_ < 2; ++kk_)                                                       \
+        _Pragma("unroll") for (int f_ = 0; f_ < TN; ++f_)                                                       \
+          bnxt[kk_][f_] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, bvo[f_], (ks_) * 128 + kk_ * 64, 0)); \
+    } else if constexpr (BCONTIG) {                                                                                    \
+      if (!B_RAGGED || wave < B_INST)                                                                           \
+        V3WeightPieces<0, B_PER_WAVE>::issue(rw, bst0 + (par_) * BSTAGE + wave * B_PER_WAVE * 1024, wvoff, (ks_) * 128); \
+    } else {                                                                                                    \
+      _Pragma("unroll") for (int j_ = 0; j_ < B_PER_WAVE; ++j_)                                                 \
+        if (!B_RAGGED || j_ * NW + wave < B_INST)                                                               \
+          v3_dma16(rw, bst0 + (PRIVB ? wave * 2 + (par_) : (par_)) * BSTAGE + (PRIVB ? j_ : j_ * NW + wave) * 1024, wvoff[j_], (ks_) * 128); \
+    }                                                                                                           \
   } while (0)
 
   f32x4 acc[TN][TM];
@@ -162,6 +194,16 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : (SPLIT && BN =
   }
   const int b_off = (PRIVB ? l15 : wn * WN + l15) * 128;
   const int bswz = (l15 >> 1) & 7;
+  // DIRB: the weight fragments never pass through LDS -- every lane fetches its own 16 bytes of the NEXT step's B fragments from L2
+  // (row = cout, 64 contiguous bytes per cout and K half; rows past cout_pad are out of the buffer's range and read as zero) one
+  // step ahead, straight into registers: no weight stages, no weight DMA issue, no B ds_reads, and the block barrier only when a new
+  // patch becomes current.  The two waves that share a cout half fetch the same lines (the second one hits the CU's L1).
+  int bvo[DIRB ? TN : 1];
+  f16x8 bcur[2][DIRB ? TN : 1], bnxt[2][DIRB ? TN : 1];
+  if constexpr (DIRB) {
+#pragma unroll
+    for (int f = 0; f < TN; ++f) bvo[f] = (n0 + wn * WN + f * 16 + l15) * (p.kchunks * 16) + l4 * 16;
+  }
 
   const int nblocks = p.kchunks / (8 * NTAPS);
   const int nk = nblocks * NTAPS;
@@ -235,7 +277,13 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : (SPLIT && BN =
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       if constexpr (PROF) { pf_b = __builtin_readcyclecounter(); pf_vm += pf_b - pf_a; }
-      if (!PRIVB || t == 0) __builtin_amdgcn_s_barrier();          // weights of step ks (and, at t == 0, the whole patch of this block) are in LDS
+      if constexpr (DIRB) {                                          // this step's fragments arrived with the wait above
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int f = 0; f < TN; ++f) bcur[kk][f] = bnxt[kk][f];
+      }
+      if ((!PRIVB && !DIRB) || t == 0) __builtin_amdgcn_s_barrier();          // weights of step ks (and, at t == 0, the whole patch of this block) are in LDS
       if constexpr (PROF) { pf_c = __builtin_readcyclecounter(); pf_wait += pf_c - pf_b; }
       if (t == 0 && have_next) {
         v3_entry_ready(en);
@@ -263,7 +311,10 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : (SPLIT && BN =
             af[kk][f] = *reinterpret_cast<const f16x8*>(pcur + row * 128 + (((kk * 4 + l4) ^ (row & 7)) << 4));
           }
 #pragma unroll
-          for (int f = 0; f < TN; ++f) bf[kk][f] = *reinterpret_cast<const f16x8*>(sb + b_off + f * 16 * 128 + (((kk * 4 + l4) ^ bswz) << 4));
+          for (int f = 0; f < TN; ++f) {
+            if constexpr (DIRB) bf[kk][f] = bcur[kk][f];
+            else bf[kk][f] = *reinterpret_cast<const f16x8*>(sb + b_off + f * 16 * 128 + (((kk * 4 + l4) ^ bswz) << 4));
+          }
         }
 #pragma unroll
         for (int a = 0; a < TN; ++a)
@@ -294,7 +345,8 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : (SPLIT && BN =
         }
 #pragma unroll
         for (int f = 0; f < TN; ++f) {
-          if constexpr (STAGGER == 8) bf[f] = f16x8{(_Float16)1, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)(float)f};
+          if constexpr (DIRB) bf[f] = bcur[kk][f];
+          else if constexpr (STAGGER == 8) bf[f] = f16x8{(_Float16)1, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)(float)f};
           else bf[f] = *reinterpret_cast<const f16x8*>(sb + b_off + f * 16 * 128 + (((kk * 4 + l4) ^ bswz) << 4));
         }
         if constexpr (STAGGER == 7) {               // [ablation] no MFMA: keep the fragments alive only
@@ -407,6 +459,7 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : (SPLIT && BN =
       atomicAdd(&g_v3_prof[8], pf_e1 - pf_b); atomicAdd(&g_v3_prof[9], pf_e2 - pf_e1); atomicAdd(&g_v3_prof[10], te - pf_e2);
       atomicAdd(&g_v3_prof[11], pf_t0 - pf_start);
       atomicAdd(&g_v3_prof[6], 1ull); atomicAdd(&g_v3_prof[7], (unsigned long long)nk);
+      atomicMin(&g_v3_prof[12], pf_start); atomicMax(&g_v3_prof[13], te);
     }
   }
 #undef V3_ISSUE_PIECE
@@ -414,13 +467,13 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : (SPLIT && BN =
 #endif
 }
 
-template <int TH, int TW, int KH, int KW, int BN, bool PROF = false, int STAGGER = 0, int WMT = 64, bool SPLIT = false, bool PRIVB = false>
+template <int TH, int TW, int KH, int KW, int BN, bool PROF = false, int STAGGER = 0, int WMT = 64, bool SPLIT = false, bool PRIVB = false, bool DIRB = false>
 static int launch_v3(ConvParams p, hipStream_t stream) {
   p.tiles_n = (p.cout_g + BN - 1) / BN;
   const long long tiles = (long long)p.N * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
   const long long nblk = tiles * p.tiles_n;
   if (nblk >= (1ll << 31)) return -1000;
-  hipLaunchKernelGGL((conv_halo_kernel<TH, TW, KH, KW, BN, PROF, STAGGER, WMT, SPLIT, PRIVB>), dim3((unsigned)nblk), dim3(TH * TW * 128 / WMT), 0, stream, p);
+  hipLaunchKernelGGL((conv_halo_kernel<TH, TW, KH, KW, BN, PROF, STAGGER, WMT, SPLIT, PRIVB, DIRB>), dim3((unsigned)nblk), dim3(TH * TW * 128 / WMT), 0, stream, p);
   return launch_status("pp_conv2d(v3)");
 }
 

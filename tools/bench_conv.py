@@ -125,7 +125,7 @@ def main():
             print(f"{name:24s} {impl:4d} {ms:9.3f} {flops / ms / 1e9:9.1f} {d:16.3e}", flush=True)
             if impl in (75, 77, 78):      # phase counters of the PROF build (cycles per wave)
                 import ctypes
-                buf = (ctypes.c_uint64 * 12)()
+                buf = (ctypes.c_uint64 * 16)()
                 hip.lib().pp_debug_conv_prof(buf)
                 w = max(1, buf[6])
                 print("    per wave: vmcnt-wait %.0f  barrier-wait %.0f  dma-issue %.0f  compute %.0f  | loop %.0f  epilogue %.0f  (K steps %.0f, waves %d)"

@@ -152,7 +152,7 @@ int main(int argc, char** argv) {
     for (int i = 0; i < 3 && rc == 0; ++i) rc = pp_conv2d(&a, st);
     if (rc != 0) { printf("  impl %3d: refused (%d) %s\n", impls[ii], rc, pp_last_error_string()); continue; }
     CK(hipStreamSynchronize(st));
-    unsigned long long pf[12];
+    unsigned long long pf[16];
     if (prof) pp_debug_conv_prof(pf);
     CK(hipEventRecord(e0, st));
     for (int i = 0; i < reps; ++i) pp_conv2d(&a, st);
@@ -176,10 +176,17 @@ int main(int argc, char** argv) {
     printf("\n");
     if (prof) {
       pp_debug_conv_prof(pf);
+      // blocks of the halo launch (128-pixel tiles; 128-cout tiles unless the layer has at most 64 couts)
+      const double nblk_print = (double)N * (KW == 1 ? ((H + 15) / 16) * ((W + 7) / 8) : ((H + 7) / 8) * ((W + 15) / 16)) * (COUT <= 64 ? 1 : (COUT + 127) / 128);
       if (pf[6]) {
         const double wv = (double)pf[6];
         printf("      prof/wave: vmwait %.0f barrier %.0f issue %.0f compute %.0f | loop %.0f epilogue %.0f (sync %.0f) prologue %.0f | steps %.1f | epi: phase1 %.0f rest %.0f\n",
                pf[0] / wv, pf[1] / wv, pf[2] / wv, pf[3] / wv, pf[4] / wv, pf[5] / wv, pf[8] / wv, pf[11] / wv, pf[7] / wv, pf[9] / wv, pf[10] / wv);
+        // stamp clock and average residency: (latest end - earliest start) spans the `reps` launches the events timed
+        const double span = (double)(pf[13] - pf[12]), tick_ghz = span / (us * reps) / 1e3;
+        const double life = (pf[4] + pf[5] + pf[11]) / wv;       // prologue + loop + epilogue per wave, in ticks
+        printf("      stamp clock %.3f GHz | block lifetime %.2f us | blocks %lld -> average resident blocks %.1f\n", tick_ghz, life / tick_ghz / 1e3,
+               (long long)nblk_print, nblk_print * (life / tick_ghz / 1e3) / us);
       }
     }
   }
