@@ -608,7 +608,7 @@ extern "C" int pp_conv2d(const pp_conv_args_t* a, void* stream) {
     if (rc != -1000) return rc;
     PP_REQUIRE(a->impl == 0, PP_ERR_ARG, "pp_conv2d: impl %d (wide halo tiles) not available for this shape", a->impl);
   }
-  if (a->dtype == PP_F16 && !deform && (a->impl == 0 || (a->impl >= 70 && a->impl < 80) || (a->impl >= 82 && a->impl <= 89) || a->impl == 106 || a->impl == 109 || (a->impl >= 111 && a->impl <= 113))) {
+  if (a->dtype == PP_F16 && !deform && (a->impl == 0 || (a->impl >= 70 && a->impl < 80) || (a->impl >= 82 && a->impl <= 89) || a->impl == 106 || a->impl == 109 || (a->impl >= 111 && a->impl <= 115))) {
     // halo-tile kernel family (stride-1 "same" 3x3 / 1x5 / 5x1 windows over 64-channel-multiple sources)
     const int rc = conv_v3_dispatch(p, a->impl, st);
     if (rc != -1000) return rc;

@@ -92,6 +92,12 @@ int conv_v3_dispatch(const ConvParams& p, int cfg, hipStream_t stream) {
     if (kh == 5 && kw == 1) return cfg == 112 ? launch_v3<16, 8, 5, 1, 128, false, 0, 64, false, false, true>(p, stream) : launch_v3<16, 8, 5, 1, 128, true, 0, 64, false, false, true>(p, stream);
     return -1000;
   }
+  if (cfg == 114 || cfg == 115) {   // all 16 fragment reads of a step ahead of its MFMAs; 115 = + phase timing
+    if (kh == 3 && kw == 3) return cfg == 114 ? launch_v3<8, 16, 3, 3, 128, false, 13>(p, stream) : launch_v3<8, 16, 3, 3, 128, true, 13>(p, stream);
+    if (kh == 1 && kw == 5) return cfg == 114 ? launch_v3<8, 16, 1, 5, 128, false, 13>(p, stream) : launch_v3<8, 16, 1, 5, 128, true, 13>(p, stream);
+    if (kh == 5 && kw == 1) return cfg == 114 ? launch_v3<16, 8, 5, 1, 128, false, 13>(p, stream) : launch_v3<16, 8, 5, 1, 128, true, 13>(p, stream);
+    return -1000;
+  }
   if (cfg == 111) {   // weight pieces of a wave 4 KB apart, M0 rewritten per piece (the layout before the one-M0 / instruction-offset form)
     if (kh == 3 && kw == 3) return launch_v3<8, 16, 3, 3, 128, false, 12>(p, stream);
     if (kh == 1 && kw == 5) return launch_v3<8, 16, 1, 5, 128, false, 12>(p, stream);

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : HALO_MIN_WAVES
   constexpr int EPI_LD = EPI_WN + 4;
   constexpr int EPI_BYTES = NW * WM * EPI_LD * 4;
   constexpr int LDS_BYTES = PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES;
-  constexpr bool PRE_MFMA = (STAGGER == 0 || STAGGER == 12) && BM == 128 && (BN == 128 || BN == 64) && WMT == 64 && PATCH_BYTES >= 16 * 1024;   // (STAGGER 11, impl 109: off, for A/B)
+  constexpr bool PRE_MFMA = (STAGGER == 0 || STAGGER == 12 || STAGGER == 13) && BM == 128 && (BN == 128 || BN == 64) && WMT == 64 && PATCH_BYTES >= 16 * 1024;   // (STAGGER 11, impl 109: off, for A/B)
   static_assert((BM == 128 || BM == 256) && (TW == 16 || TW == 8) && PPW <= 3 * NTAPS && (BN % 32 == 0 || BN == 16) &&
                     LDS_BYTES <= (BM == 128 ? 80 : 160) * 1024, "tile");
 
@@ -328,6 +328,29 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : HALO_MIN_WAVES
         for (int a = 0; a < TN; ++a)
 #pragma unroll
           for (int b = 0; b < TM; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[0][a], af[0][b], acc[a][b], 0, 0, 0);   // W_hi x A_hi
+      } else if constexpr ((STAGGER == 0 || STAGGER == 13) && BN == 128 && WMT == 64 && BM == 128 && !DIRB) {
+        // the fragments of BOTH K halves are requested before the first MFMA (32 more live fragment registers; 231 in all for 3x3): the
+        // reads of the second half complete under the 16 MFMAs of the first instead of being waited for in four small groups
+        // (+1.5 % on average over seven layer shapes, bit-identical: profiles/r3q_halo_kernel_phases.txt; impl 111 = the interleaved form)
+        f16x8 af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+          for (int f = 0; f < TN; ++f) bf[kk][f] = *reinterpret_cast<const f16x8*>(sb + b_off + f * 16 * 128 + (((kk * 4 + l4) ^ bswz) << 4));
+#pragma unroll
+          for (int f = 0; f < TM; ++f) {
+            const int row = pp0[f] + sh;
+            af[kk][f] = *reinterpret_cast<const f16x8*>(pcur + row * 128 + (((kk * 4 + l4) ^ (row & 7)) << 4));
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int a = 0; a < TN; ++a)
+#pragma unroll
+            for (int b = 0; b < TM; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[kk][a], af[kk][b], acc[a][b], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       } else {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
