@@ -52,10 +52,29 @@ FAMILIES = [   # (substring of the demangled OR mangled kernel name, family)
 ]
 
 
+def _template_args(name, kernel):
+    """Template arguments of `kernel` in a demangled ("kernel<a, b, ...>(") or Itanium-mangled ("kernelILi8ELb1E...E") name."""
+    i = name.find(kernel + "<")
+    if i >= 0:
+        j = name.find(">", i)
+        return [t.strip() for t in name[i + len(kernel) + 1:j].split(",")]
+    i = name.find(kernel + "I")
+    if i >= 0:
+        return ["true" if t == "b1" else "false" if t == "b0" else t[1:] for t in re.findall(r"L([ib]\d+)E", name[i:])]
+    return []
+
+
+# position of the SPLIT template argument (split-plane "f16x3" instantiations): conv_halo_kernel<TH, TW, KH, KW, BN, PROF, STAGGER, WMT,
+# SPLIT, PRIVB, DIRB>, conv_gemm_v2_kernel<BM, BN, BK, WM, WN, STAGES, UNI, CFG, SPLIT, TRI>
+_SPLIT_ARG = {"conv_halo_kernel": 8, "conv_gemm_v2_kernel": 8}
+
+
 def family(name):
-    # split-plane ("f16x3") instantiations: the LAST template argument (SPLIT) of conv_halo_kernel / conv_gemm_v2_kernel is true
-    if ("conv_halo_kernel" in name or "conv_gemm_v2_kernel" in name) and (re.search(r", true>\(", name + "(") or "Lb1EEEv" in name):
-        return SPLIT_FAMILY
+    for kernel, pos in _SPLIT_ARG.items():
+        if kernel in name:
+            args = _template_args(name, kernel)
+            if len(args) > pos and args[pos] == "true":
+                return SPLIT_FAMILY
     for pat, fam in FAMILIES:
         if pat in name:
             return fam
