@@ -343,6 +343,8 @@ def main():
         from propainter_amd.sharding import ShardedClipGraph, dist_exchanger
         t_c = time.perf_counter()
         try:
+            if torch.cuda.memory_reserved(dev) > torch.cuda.get_device_properties(dev).total_memory // 3:
+                torch.cuda.empty_cache()      # long clips / 1080p: the eager pools back to the driver before the graphs build their own
             sgraph = ShardedClipGraph(models, L, H, W, cfg, dev, rank, world)
             sgraph.load(clip_pin, masks_pin, masks_pin)
             sgraph.capture(dist_exchanger(dev, None, None))
