@@ -244,6 +244,11 @@ int pp_corr_lookup(const float* lvl0, const float* lvl1, const float* lvl2, cons
  *     fp16: channel l*81 + a*9 + b samples (x/2^l + a - 4, y/2^l + b - 4), scaled by 1/sqrt(256); channels
  *     [324, out_cpad) are zeroed.  coords fp32 [P,h,w,2] = (x, y).  Deterministic, batch-invariant. */
 int pp_corr_feature_pyramid(const void* f2, void* lvl1, void* lvl2, void* lvl3, int P, int h, int w, void* stream);
+/* The same pooling for split-plane ("f16x3") features: f2 and the levels are fp16 NHWC [P, h>>l, w>>l, 512] = 256 hi | 256 lo channels
+ * of fp32 values; the means are formed in fp32 and stored as hi = fp16(m), lo = fp16(m - hi).  The volume engine of the fp32-class RAFT
+ * builds levels 1..3 of the correlation pyramid (RAFT/corr.py:21-27) as GEMMs of f1 with these pooled features -- pooling is linear --
+ * instead of re-reading the level-0 volume (829 MB per pair-direction at 720x1280). */
+int pp_corr_feature_pyramid_split(const void* f2, void* lvl1, void* lvl2, void* lvl3, int P, int h, int w, void* stream);
 int pp_corr_lookup_otf(const void* f1, const void* f2_lvl0, const void* f2_lvl1, const void* f2_lvl2, const void* f2_lvl3,
                        const float* coords, void* out, int out_cstride, int out_cpad, int P, int h, int w, void* stream);
 

@@ -312,11 +312,12 @@ _gemm_tables = {}
 _split_gemm_tables = {}
 
 
-def batched_gemm_nt_split(a, b, out_scale=1.0):
+def batched_gemm_nt_split(a, b, out_scale=1.0, impl=0):
     """Split-plane ("f16x3") batched GEMM: a, b fp16 [B, M | N, 2K] = hi | lo planes of fp32 operands;
     out[b, m, n] = out_scale * sum_k a[b, m, k] * b[b, n, k] as hi*hi + lo*hi + hi*lo on the fp16 matrix cores, fp32 output.
     Tri-product K format: the A side needs no copy (its K table lists 4 hi + 4 lo chunks per 32-channel block); the B side is the
-    kernel's dense "weight" operand, so its rows are gathered once into that K order ([32 ch hi | 32 ch lo] per block).
+    kernel's dense "weight" operand, so its rows are gathered once into that K order ([32 ch hi | 32 ch lo] per block; N is padded
+    to a multiple of 16 rows with zeros -- the pooled levels of a pyramid have any size).  impl: tile configuration (0 = auto).
     RAFT all-pairs correlation volume at reference precision (RAFT/corr.py:52-60)."""
     B, M, K2 = a.shape
     Bb, Nn, K2b = b.shape
@@ -331,19 +332,25 @@ def batched_gemm_nt_split(a, b, out_scale=1.0):
         cols[(code & 0xff) == 255] = 0
         _split_gemm_tables[key] = (torch.from_numpy(kt).to(a.device), torch.from_numpy(cols.reshape(-1)).to(a.device), kt.shape[0] - 1)
     kt, cols, kchunks = _split_gemm_tables[key]
-    bt = b.index_select(2, cols)                                                        # [B, N, 3K] in K-table order
+    npad = (Nn + 15) // 16 * 16
+    if npad == Nn:
+        bt = b.index_select(2, cols)                                                    # [B, N, 2K] in K-table order
+    else:
+        bt = torch.zeros((B, npad, cols.numel()), dtype=b.dtype, device=b.device)
+        bt[:, :Nn] = b.index_select(2, cols)
     out = torch.empty((B, M, Nn), dtype=torch.float32, device=a.device)
     g = hip.ConvArgs()
     g.dtype = hip.PP_F16
     g.N, g.H, g.W, g.OH, g.OW = 1, 1, M, 1, M
     g.stride_h = g.stride_w = 1
-    g.groups, g.cout_g, g.cout_pad, g.kchunks, g.nsrc = B, Nn, Nn, kchunks, 1
+    g.groups, g.cout_g, g.cout_pad, g.kchunks, g.nsrc = B, Nn, npad, kchunks, 1
     g.src[0].ptr, g.src[0].cstride, g.src[0].choff, g.src[0].cgroup = a.data_ptr(), K2, 0, 0
     g.src[0].lo_off = K
-    g.ktable, g.weight, g.weight_gstride = kt.data_ptr(), bt.data_ptr(), Nn * kchunks * 8
+    g.ktable, g.weight, g.weight_gstride = kt.data_ptr(), bt.data_ptr(), npad * kchunks * 8
     g.act, g.out_scale, g.act2 = hip.ACT_NONE, float(out_scale), hip.ACT_NONE
     g.out_dtype = hip.PP_F32
     g.split = 2                    # tri-product K step (plain fp32 output: no split-plane epilogue operands)
+    g.impl = int(impl)
     g.ktable_uniform = 8
     g.out, g.out_cstride, g.out_choff, g.out_cgroup = out.data_ptr(), Nn, 0, 0
     g.src_gstride, g.out_gstride = M * K2, M * Nn

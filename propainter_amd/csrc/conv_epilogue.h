@@ -128,6 +128,30 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc_)
     }
     return;
   }
+  if (p.epi_direct && !p.out_f16 && !has_res && !late) {
+    // ---- plain fp32 output: accumulator layout straight to memory.  acc[a][b] of a lane = couts co_wave + a*16 + l4*4 .. +3 of pixel row
+    // b*16 + l15: one 16-byte store per tile, the four l4 groups of a pixel row cover 64 contiguous bytes, the TN tiles the row's WN couts
+    float* ob = reinterpret_cast<float*>(outp) + out_cbase;
+    const bool vec_ok = ((p.out_cstride | out_cbase) & 3) == 0 && ((unsigned long long)outp & 15) == 0;
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+      const long long m = rowmap(b * 16 + l15);
+      if (m < 0) continue;
+      float* orow = ob + m * p.out_cstride;
+#pragma unroll
+      for (int a = 0; a < TN; ++a) {
+        const int c0 = co_wave + a * 16 + l4 * 4;
+        const int nv = p.cout_g - c0;
+        if (nv >= 4 && vec_ok) *reinterpret_cast<f32x4*>(orow + c0) = acc_[A0 + a][b];
+        else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (r < nv) orow[c0 + r] = acc_[A0 + a][b][r];
+        }
+      }
+    }
+    return;
+  }
   // ---- fp32 staging (residual and / or fp32 output): row stride WN + 4 floats
   constexpr int LDF = WN + 4;
   float* et = reinterpret_cast<float*>(wave_lds);

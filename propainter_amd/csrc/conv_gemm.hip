@@ -14,6 +14,7 @@
 //   fp16: v_mfma_f32_16x16x32_f16 (8 k per lane);  fp32: v_mfma_f32_16x16x4_f32 (exact fp32).
 // LDS rows are padded by 16 bytes (stride 80 B fp16 / 144 B fp32) to spread the ds_read_b128 lanes.
 #include "conv_params.h"
+#include <stdlib.h>
 
 namespace pp {
 
@@ -533,6 +534,11 @@ extern "C" int pp_conv2d(const pp_conv_args_t* a, void* stream) {
   p.out2 = (char*)a->out2; p.out2_cstride = a->out2_cstride; p.out2_choff = a->out2_choff;
   p.split = a->split; p.out_lo = a->out_lo; p.out2_lo = a->out2_lo; p.preadd_lo = a->preadd_lo; p.res_lo = a->res_lo;
   p.fuse_a_lo = a->fuse_a_lo; p.fuse_b_lo = a->fuse_b_lo;
+  {   // PP_EPI_DIRECT: 0 = never, 1 (default) = the batched GEMMs (short K, output-bound), 2 = every plain fp32 output (read per launch: A/B runs)
+    const char* ed = getenv("PP_EPI_DIRECT");
+    const int mode = ed != nullptr ? atoi(ed) : 1;
+    p.epi_direct = mode == 2 || (mode == 1 && a->groups > 1 && a->out_gstride != 0);
+  }
   if (a->preadd != nullptr || a->fuse != PP_FUSE_NONE) {
     PP_REQUIRE(a->groups == 1 && !deform && a->out_dtype == a->dtype && a->cout_g % 8 == 0, PP_ERR_ARG,
                "pp_conv2d: the fused epilogue (preadd / fuse) needs groups == 1, no deformable sampling, out_dtype == dtype, cout_g %% 8 == 0");

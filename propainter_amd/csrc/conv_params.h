@@ -45,6 +45,9 @@ struct ConvParams {
   // split-plane ("f16x3") operands (pp_conv_args_t.split): element offset of the lo plane of each fp16 operand the epilogue touches
   int split;
   int out_lo, out2_lo, preadd_lo, res_lo, fuse_a_lo, fuse_b_lo;
+  // plain fp32 output without epilogue operands: store the accumulators directly (4 consecutive couts = 16 bytes per lane, 64 contiguous
+  // bytes per pixel row and MFMA tile) instead of staging them through LDS -- short-K, output-bound launches (the correlation-volume GEMM)
+  int epi_direct;
 };
 
 // activation of the late (post-staging) epilogue path: same fast forms as the register path of conv_epilogue.h

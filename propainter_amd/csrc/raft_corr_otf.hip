@@ -281,7 +281,11 @@ __global__ __launch_bounds__(512) void corr_otf_kernel(const CorrOtfParams p) {
 
 // Level l of the f2 feature pyramid: mean over the 2^l x 2^l block at (y << l, x << l) -- what l nested
 // F.avg_pool2d(2, 2) (floor sizes) compute --, accumulated in fp32 from level 0 and rounded to fp16 once.
+// SPLIT: split-plane ("f16x3") features -- rows of 512 fp16 = [256 hi | 256 lo]; the fp32 values hi + lo are averaged in fp32 and the
+// mean is stored as hi = fp16(m), lo = fp16(m - hi) (22 significand bits: the fp32-class operand of the level's correlation GEMM).
+template <bool SPLIT>
 __global__ void corr_feature_pool_kernel(const _Float16* __restrict__ f2, _Float16* __restrict__ out, int P, int h, int w, int lvl) {
+  constexpr int RS = SPLIT ? 512 : 256;                          // fp16 elements per pixel row
   const int Hl = h >> lvl, Wl = w >> lvl, s = 1 << lvl;
   const long long total = (long long)P * Hl * Wl * 32;           // 8-channel chunks
   const float inv = 1.f / (float)(s * s);
@@ -294,13 +298,17 @@ __global__ void corr_feature_pool_kernel(const _Float16* __restrict__ f2, _Float
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, v[8];
     for (int dy = 0; dy < s; ++dy)
       for (int dx = 0; dx < s; ++dx) {
-        load8<_Float16>(f2 + ((n * h + (y * s + dy)) * (long long)w + (x * s + dx)) * 256 + c * 8, v);
+        const _Float16* src = f2 + ((n * h + (y * s + dy)) * (long long)w + (x * s + dx)) * RS + c * 8;
+        if constexpr (SPLIT) load8_split(src, src + 256, v);
+        else load8<_Float16>(src, v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] += v[j];
       }
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] *= inv;
-    store8<_Float16>(out + ((n * Hl + y) * (long long)Wl + x) * 256 + c * 8, acc);
+    _Float16* dst = out + ((n * Hl + y) * (long long)Wl + x) * RS + c * 8;
+    if constexpr (SPLIT) store8_split(dst, dst + 256, acc);
+    else store8<_Float16>(dst, acc);
   }
 }
 
@@ -308,19 +316,33 @@ __global__ void corr_feature_pool_kernel(const _Float16* __restrict__ f2, _Float
 
 using namespace pp;
 
-extern "C" int pp_corr_feature_pyramid(const void* f2, void* lvl1, void* lvl2, void* lvl3, int P, int h, int w, void* stream) {
-  PP_REQUIRE(f2 && lvl1 && lvl2 && lvl3 && P > 0, PP_ERR_ARG, "pp_corr_feature_pyramid: bad arguments");
+static int feature_pyramid(const void* f2, void* lvl1, void* lvl2, void* lvl3, int P, int h, int w, bool split, void* stream, const char* who) {
+  PP_REQUIRE(f2 && lvl1 && lvl2 && lvl3 && P > 0, PP_ERR_ARG, "%s: bad arguments", who);
   PP_REQUIRE((h >> 3) >= 2 && (w >> 3) >= 2, PP_ERR_ARG,
-             "pp_corr_feature_pyramid: level-3 map would be %dx%d (RAFT needs >= 2x2: inputs of at least 128x128)", h >> 3, w >> 3);
+             "%s: level-3 map would be %dx%d (RAFT needs >= 2x2: inputs of at least 128x128)", who, h >> 3, w >> 3);
+  PP_REQUIRE(((uintptr_t)f2 % 16) == 0 && ((uintptr_t)lvl1 % 16) == 0 && ((uintptr_t)lvl2 % 16) == 0 && ((uintptr_t)lvl3 % 16) == 0, PP_ERR_ALIGN,
+             "%s: pointers must be 16-byte aligned", who);
   void* outs[3] = {lvl1, lvl2, lvl3};
   for (int l = 1; l <= 3; ++l) {
     const long long total = (long long)P * (h >> l) * (w >> l) * 32;
     long long g = (total + 255) / 256;
     if (g > 256 * 32) g = 256 * 32;
-    hipLaunchKernelGGL(corr_feature_pool_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const _Float16*)f2,
-                       (_Float16*)outs[l - 1], P, h, w, l);
+    if (split)
+      hipLaunchKernelGGL(corr_feature_pool_kernel<true>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const _Float16*)f2,
+                         (_Float16*)outs[l - 1], P, h, w, l);
+    else
+      hipLaunchKernelGGL(corr_feature_pool_kernel<false>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const _Float16*)f2,
+                         (_Float16*)outs[l - 1], P, h, w, l);
   }
-  return launch_status("pp_corr_feature_pyramid");
+  return launch_status(who);
+}
+
+extern "C" int pp_corr_feature_pyramid(const void* f2, void* lvl1, void* lvl2, void* lvl3, int P, int h, int w, void* stream) {
+  return feature_pyramid(f2, lvl1, lvl2, lvl3, P, h, w, false, stream, "pp_corr_feature_pyramid");
+}
+
+extern "C" int pp_corr_feature_pyramid_split(const void* f2, void* lvl1, void* lvl2, void* lvl3, int P, int h, int w, void* stream) {
+  return feature_pyramid(f2, lvl1, lvl2, lvl3, P, h, w, true, stream, "pp_corr_feature_pyramid_split");
 }
 
 extern "C" int pp_corr_lookup_otf(const void* f1, const void* f2_lvl0, const void* f2_lvl1, const void* f2_lvl2,

@@ -254,33 +254,41 @@ __global__ void inorm_apply_split_kernel(const float* __restrict__ in, const flo
   }
 }
 
-// bilinear x2, align_corners=True: src = dst * (in-1)/(out-1)
+// bilinear x2, align_corners=True: src = dst * (in-1)/(out-1).  One block per output row (n, oy) -- the row's source rows and
+// vertical weight are block-uniform -- and 32-bit index arithmetic inside the row (the grid-stride form spent its time in 64-bit
+// divisions: 2.6 TB/s on a pass that reads every input pixel four times from L1 / L2 and writes 4x its input once).
 template <typename T>
-__global__ void upsample2x_kernel(const T* __restrict__ in, T* __restrict__ out, int N, int H, int W, int C) {
+__global__ __launch_bounds__(256) void upsample2x_kernel(const T* __restrict__ in, T* __restrict__ out, int N, int H, int W, int C) {
   const int OH = 2 * H, OW = 2 * W;
   const int cch = C / 8;
   const float sy = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
   const float sx = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
-  const long long total = (long long)N * OH * OW * cch;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int cc = (int)(i % cch);
-    const long long pix = i / cch;
-    const int ox = (int)(pix % OW), oy = (int)((pix / OW) % OH);
-    const long long n = pix / ((long long)OW * OH);
-    const float fy = sy * (float)oy, fx = sx * (float)ox;
-    const int y0 = (int)fy, x0 = (int)fx;
-    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
-    const float ly = fy - (float)y0, lx = fx - (float)x0;
-    float a[8], b[8], c[8], d[8], o[8];
-    const T* base = in + n * (long long)H * W * C + cc * 8;
-    load8<T>(base + ((long long)y0 * W + x0) * C, a);
-    load8<T>(base + ((long long)y0 * W + x1) * C, b);
-    load8<T>(base + ((long long)y1 * W + x0) * C, c);
-    load8<T>(base + ((long long)y1 * W + x1) * C, d);
+  const int rows = N * OH, per_row = OW * cch;
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    const int n = row / OH, oy = row - n * OH;
+    const float fy = sy * (float)oy;
+    const int y0 = (int)fy;
+    const int y1 = min(y0 + 1, H - 1);
+    const float ly = fy - (float)y0;
+    const T* r0 = in + ((long long)n * H + y0) * W * C;
+    const T* r1 = in + ((long long)n * H + y1) * W * C;
+    T* orow = out + (long long)row * OW * C;
+    for (int i = threadIdx.x; i < per_row; i += 256) {
+      const int ox = i / cch, cc = i - ox * cch;
+      const float fx = sx * (float)ox;
+      const int x0 = (int)fx;
+      const int x1 = min(x0 + 1, W - 1);
+      const float lx = fx - (float)x0;
+      float a[8], b[8], c[8], d[8], o[8];
+      load8<T>(r0 + x0 * C + cc * 8, a);
+      load8<T>(r0 + x1 * C + cc * 8, b);
+      load8<T>(r1 + x0 * C + cc * 8, c);
+      load8<T>(r1 + x1 * C + cc * 8, d);
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      o[j] = (1.f - ly) * ((1.f - lx) * a[j] + lx * b[j]) + ly * ((1.f - lx) * c[j] + lx * d[j]);
-    store8<T>(out + pix * C + cc * 8, o);
+      for (int j = 0; j < 8; ++j)
+        o[j] = (1.f - ly) * ((1.f - lx) * a[j] + lx * b[j]) + ly * ((1.f - lx) * c[j] + lx * d[j]);
+      store8<T>(orow + i * 8, o);
+    }
   }
 }
 
@@ -486,7 +494,9 @@ extern "C" int pp_instance_norm_split(const float* in, void* out, float* stats_w
 extern "C" int pp_upsample2x(const void* in, void* out, int N, int H, int W, int C, int dtype, void* stream) {
   PP_REQUIRE(in && out && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, PP_ERR_ARG, "pp_upsample2x: bad arguments (C=%d)", C);
   PP_REQUIRE(dtype == PP_F32 || dtype == PP_F16, PP_ERR_DTYPE, "pp_upsample2x: dtype %d", dtype);
-  const int g = grid_for((long long)N * 4 * H * W * (C / 8));
+  PP_REQUIRE((long long)N * 2 * H < (1ll << 31) && (long long)2 * W * C < (1ll << 31), PP_ERR_ARG, "pp_upsample2x: %d x %d x %d x %d too large", N, H, W, C);
+  const long long rows = (long long)N * 2 * H;
+  const int g = (int)(rows < 256 * 64 ? rows : 256 * 64);      // one block per output row, grid-stride beyond 64 blocks per CU
   PP_DISPATCH_T(dtype, hipLaunchKernelGGL((upsample2x_kernel<T>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const T*)in, (T*)out,
                                           N, H, W, C);)
   return launch_status("pp_upsample2x");

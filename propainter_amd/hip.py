@@ -412,6 +412,18 @@ def corr_feature_pyramid(f2):
     return [f2] + lv
 
 
+def corr_feature_pyramid_split(f2):
+    """f2 split-plane fp16 NHWC [P,h,w,512] (256 hi | 256 lo) -> [level1, level2, level3], split-plane [P, h>>l, w>>l, 512]: the fp32 means
+    over the 2^l x 2^l blocks (pp_corr_feature_pyramid_split).  f1 . level_l = level l of the avg-pooled correlation pyramid."""
+    P, h, w, c = f2.shape
+    assert f2.dtype == torch.float16 and c == 512 and f2.is_contiguous()
+    lv = [torch.empty((P, h >> l, w >> l, 512), dtype=f2.dtype, device=f2.device) for l in (1, 2, 3)]
+    timed("corr_feature_pyramid", 0, _nbytes(f2) * 3 + sum(_nbytes(t) for t in lv),
+          lambda: _check(lib().pp_corr_feature_pyramid_split(_p(f2), _p(lv[0]), _p(lv[1]), _p(lv[2]), _i(P), _i(h), _i(w), _stream(f2)),
+                         "pp_corr_feature_pyramid_split"))
+    return lv
+
+
 def corr_lookup_otf(f1, f2_levels, coords, out):
     """Correlation lookup without the all-pairs volume (fp16): f1 [P,h,w,256], f2_levels from corr_feature_pyramid,
     coords fp32 [P,h,w,2]; writes out NHWC [P,h,w,328] (channels l*81 + a*9 + b as pp_corr_lookup, 324.. zero)."""

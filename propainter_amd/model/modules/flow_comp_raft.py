@@ -224,6 +224,8 @@ class _RaftEngineSplit(_RaftEngine):
         w2, b2 = sd["cnet.conv2.weight"], sd["cnet.conv2.bias"]
         self.cnet["conv2_net"] = mk(w2[:128], b2[:128])
         self.cnet["conv2_inp"] = mk(w2[128:], b2[128:])
+        self.pool_volume = os.environ.get("PP_RAFT_POOL_VOLUME", "0") == "1"      # levels 1..3 by pooling the level-0 volume (A/B)
+        self.volume_impl = int(os.environ.get("PP_RAFT_VOLUME_IMPL", "0"))        # tile configuration of the volume GEMMs (0 = auto)
 
     def encode(self, L, x, instance_norm):
         """x split-plane NHWC [n,H,W,16] -> split-plane [n,H/8,W/8,512]; for the context encoder (instance_norm False) the
@@ -256,12 +258,19 @@ class _RaftEngineSplit(_RaftEngine):
         P, h, w, _ = f1.shape
         dev, dt = f1.device, torch.float16
         n8 = h * w
-        vol = batched_gemm_nt_split(f1.view(P, n8, 512), f2.view(P, n8, 512), out_scale=1.0 / 16.0)
-        levels = [vol.view(P * n8, h, w)]
-        hh, ww = h, w
-        for _ in range(3):
-            levels.append(hip.corr_avgpool(levels[-1], P * n8, hh, ww))
-            hh, ww = hh // 2, ww // 2
+        # all-pairs correlation pyramid (RAFT/corr.py:13-27,52-60), fp32.  Average pooling is linear -- avg_pool(f1 . f2) = f1 . avg_pool(f2)
+        # -- so levels 1..3 are GEMMs of f1 with the pooled split-plane features (fp32 means, 3 fp16 products per product like level 0)
+        # instead of three pooling passes that re-read the level-0 volume (829 MB per pair-direction at 720p); PP_RAFT_POOL_VOLUME=1 keeps
+        # the pooling passes
+        gemm = lambda b_: batched_gemm_nt_split(f1.view(P, n8, 512), b_.view(P, -1, 512), out_scale=1.0 / 16.0, impl=self.volume_impl)
+        levels = [gemm(f2).view(P * n8, h, w)]
+        if self.pool_volume:
+            hh, ww = h, w
+            for _ in range(3):
+                levels.append(hip.corr_avgpool(levels[-1], P * n8, hh, ww))
+                hh, ww = hh // 2, ww // 2
+        else:
+            levels += [gemm(fl).view(P * n8, fl.shape[1], fl.shape[2]) for fl in hip.corr_feature_pyramid_split(f2.contiguous())]
         net = net0.clone()
         pre = [(G["zr_pre"]([inp]), G["q_pre"]([inp])) for G in self.gru]     # iteration-invariant partial sums
         xbuf = torch.empty((P, h, w, 256), dtype=dt, device=dev)            # [motion(126) | flow(2)] x (hi, lo)

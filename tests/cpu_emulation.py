@@ -148,7 +148,7 @@ def _conv_call(self, srcs, out=None, out_choff=0, act=None, act_param=0.0, out_s
     return out
 
 
-def _batched_gemm_nt_split(a, b, out_scale=1.0):
+def _batched_gemm_nt_split(a, b, out_scale=1.0, impl=0):
     K = a.shape[-1] // 2
     ah, al, bh, bl = a[..., :K].float(), a[..., K:].float(), b[..., :K].float(), b[..., K:].float()
     return (torch.matmul(ah, bh.transpose(1, 2)) + torch.matmul(al, bh.transpose(1, 2)) + torch.matmul(ah, bl.transpose(1, 2))) * out_scale
@@ -204,6 +204,18 @@ def _corr_feature_pyramid(f2):
         s_ = 1 << l
         y = F.avg_pool2d(x[:, :, :(h >> l) * s_, :(w >> l) * s_], s_, s_)
         lv.append(y.permute(0, 2, 3, 1).contiguous().to(f2.dtype))
+    return lv
+
+
+def _corr_feature_pyramid_split(f2):
+    """split-plane features [P,h,w,512]: fp32 means of hi + lo over the 2^l x 2^l blocks, stored as split planes again"""
+    x = merge_planes(f2).permute(0, 3, 1, 2)
+    P, _, h, w = x.shape
+    lv = []
+    for l in (1, 2, 3):
+        s_ = 1 << l
+        y = F.avg_pool2d(x[:, :, :(h >> l) * s_, :(w >> l) * s_], s_, s_)
+        lv.append(split_planes(y.permute(0, 2, 3, 1).contiguous()))
     return lv
 
 
@@ -338,6 +350,7 @@ def emulated_device_ops():
     patches = {
         "flow_warp": _flow_warp, "fb_check": _fb_check, "img_prop_step": _img_prop_step, "corr_avgpool": _corr_avgpool,
         "corr_lookup": _corr_lookup, "corr_feature_pyramid": _corr_feature_pyramid, "corr_lookup_otf": _corr_lookup_otf,
+        "corr_feature_pyramid_split": _corr_feature_pyramid_split,
         "convex_upsample": _convex_upsample, "window_mask": _window_mask, "raft_flow_taps": _raft_flow_taps,
         "sparse_window_attention": _attention, "fold_tokens": _fold_tokens, "layernorm": _layernorm,
         "depthwise_pool": _depthwise_pool, "instance_norm": _instance_norm, "upsample2x": _upsample2x,

@@ -175,6 +175,32 @@ def test_split_plane_batched_gemm(dev):
     check("volume", out, torch.matmul(av, bv.transpose(1, 2)) / 16.0)
 
 
+@pytest.mark.parametrize("impl", [0, 12, 13])
+def test_split_plane_correlation_pyramid_from_pooled_features(dev, impl):
+    """Levels 1..3 of the correlation pyramid (RAFT/corr.py:21-27: avg_pool2d of the volume, floor sizes) as GEMMs of f1 with the
+    pooled split-plane features (pp_corr_feature_pyramid_split; pooling is linear) against fp64 pooling of the fp64 volume --
+    level sizes that are no multiples of 16 rows (22 x 30 -> 11 x 15 = 165, 5 x 7 = 35, 2 x 3 = 6: padded weight rows, ragged
+    cout tiles, rows of 4-byte alignment only) through every tile configuration of the volume GEMM."""
+    from propainter_amd import hip
+    from propainter_amd.conv import batched_gemm_nt_split
+    g = torch.Generator().manual_seed(11)
+    P, h, w = 2, 22, 30
+    f1 = split_planes(torch.randn(P, h, w, 256, generator=g) * 2).cuda()
+    f2 = split_planes(torch.randn(P, h, w, 256, generator=g) * 2).cuda()
+    lv = hip.corr_feature_pyramid_split(f2)
+    f1v = merge_planes(f1.cpu()).double().view(P, h * w, 256)
+    ref = (torch.matmul(f1v, merge_planes(f2.cpu()).double().view(P, h * w, 256).transpose(1, 2)) / 16.0).view(P * h * w, 1, h, w)
+    vol = batched_gemm_nt_split(f1.view(P, h * w, 512), f2.view(P, h * w, 512), out_scale=1.0 / 16.0, impl=impl)
+    torch.cuda.synchronize()
+    check("level0", vol.view(P * h * w, 1, h, w), ref)
+    for l, fl in enumerate(lv, start=1):
+        ref = F.avg_pool2d(ref, 2, 2)
+        assert fl.shape == (P, h >> l, w >> l, 512)
+        got = batched_gemm_nt_split(f1.view(P, h * w, 512), fl.view(P, -1, 512), out_scale=1.0 / 16.0, impl=impl)
+        torch.cuda.synchronize()
+        check(f"level{l}", got.view(P * h * w, 1, h >> l, w >> l), ref, 2 * RTOL)
+
+
 def test_split_plane_aux_ops(dev):
     """Split-plane outputs of the correlation lookup, the flow-tap gather, the NCHW packer and the fused InstanceNorm tail
     against their fp32 forms / torch."""
