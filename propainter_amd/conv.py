@@ -350,7 +350,10 @@ def batched_gemm_nt_split(a, b, out_scale=1.0, impl=0):
     g.act, g.out_scale, g.act2 = hip.ACT_NONE, float(out_scale), hip.ACT_NONE
     g.out_dtype = hip.PP_F32
     g.split = 2                    # tri-product K step (plain fp32 output: no split-plane epilogue operands)
-    g.impl = int(impl)
+    # tile configuration (tri-product steps exist for the 64-wide-K tiles 12 / 13 / 22 only): 128 x 128 tiles at two blocks per CU --
+    # measured 7 % faster than the 256 x 128 tile the cout >= 512 rule of the convolutions would pick (16.6 vs 17.8 ms per 35-pair level-0
+    # volume at 720p, profiles/r3u_split_sweep.txt) --, 256 x 64 for the tiny pooled levels of small inputs
+    g.impl = int(impl) if impl else (12 if Nn > 64 else 22)
     g.ktable_uniform = 8
     g.out, g.out_cstride, g.out_choff, g.out_cgroup = out.data_ptr(), Nn, 0, 0
     g.src_gstride, g.out_gstride = M * K2, M * Nn
