@@ -21,6 +21,9 @@
 //        keeps ((row >> 1) & 7): its fragments start at multiples of 16 rows.
 //   4 waves (2 x 2), wave tile 64 px x BN/2 couts, v_mfma_f32_16x16x32_f16, fp32 accumulate.  Epilogue as in v2.
 #include "conv_halo.h"
+#if defined(PP_DIAG)
+#include "conv_halo_pipe.h"
+#endif
 #include <stdlib.h>
 
 namespace pp {
@@ -74,6 +77,12 @@ int conv_v3_dispatch(const ConvParams& p, int cfg, hipStream_t stream) {
     return -1000;
   }
 #if defined(PP_DIAG)      // tuning / diagnostic variants (tools/kbench, PP_DIAG=1 builds only; measured in profiles/r2_conv_epilogue_ab.txt)
+  if (cfg == 116) {   // software-pipelined form (conv_halo_pipe.h): fragment reads of step k+1 under the MFMAs of step k -- bit-identical, 2-6 % SLOWER (profiles/r3v_halo_pipelined.txt)
+    if (kh == 3 && kw == 3) return n64 ? launch_v3p<8, 16, 3, 3, 64, false>(p, stream) : launch_v3p<8, 16, 3, 3, 128, false>(p, stream);
+    if (kh == 1 && kw == 5) return n64 ? launch_v3p<8, 16, 1, 5, 64, false>(p, stream) : launch_v3p<8, 16, 1, 5, 128, false>(p, stream);
+    if (kh == 5 && kw == 1) return n64 ? launch_v3p<16, 8, 5, 1, 64, false>(p, stream) : launch_v3p<16, 8, 5, 1, 128, false>(p, stream);
+    return -1000;
+  }
   if (cfg == 82) {   // round-1 patch swizzle ((row >> 1) & 7): 2-way bank conflicts at 24 of 32 fragment alignments
     if (kh == 3 && kw == 3) return launch_v3<8, 16, 3, 3, 128, false, 5>(p, stream);
     if (kh == 1 && kw == 5) return launch_v3<8, 16, 1, 5, 128, false, 5>(p, stream);

@@ -9,6 +9,7 @@ Usage (GPU box):  python tools/bench_split.py [--reps 20] [--pairs 35] > gpurun_
 import argparse
 import math
 import os
+import re
 import sys
 
 import torch
@@ -51,14 +52,14 @@ def main():
     print(torch.cuda.get_device_name(0), flush=True)
     g = torch.Generator().manual_seed(5)
     P, h, w = args.pairs, 90, 160
-    halo_alt = [0, 71, 72]
+    halo_alt = [0, 116, 0, 116]      # 116: the software-pipelined halo kernel (conv_halo_pipe.h); each twice
     v2_alt = [0, 12, 13, 22]
     # name, N, H, W, cin list, cout, k, stride, pad, impls, extras
     L = [
         ("convc1_1x1_324", P, h, w, [324], 256, (1, 1), 1, 0, v2_alt, dict(act="relu")),
         ("convc2_3x3_256_192", P, h, w, [256], 192, (3, 3), 1, 1, halo_alt, dict(act="relu")),
         ("convf1_7x1_16_128", P, h, w, [16], 128, (7, 1), 1, (3, 0), v2_alt, dict(act="relu")),
-        ("convf2_3x3_128_64", P, h, w, [128], 64, (3, 3), 1, 1, [0, 71], dict(act="relu")),
+        ("convf2_3x3_128_64", P, h, w, [128], 64, (3, 3), 1, 1, halo_alt, dict(act="relu")),
         ("convm_3x3_256_126", P, h, w, [192, 64], 126, (3, 3), 1, 1, halo_alt, dict(act="relu")),
         ("gru_zr_1x5", P, h, w, [128, 128], 256, (1, 5), 1, (0, 2), halo_alt, dict(act="sigmoid", gru="zr")),
         ("gru_q_1x5", P, h, w, [128, 128], 128, (1, 5), 1, (0, 2), halo_alt, dict(act="tanh", gru="h")),
@@ -67,7 +68,7 @@ def main():
         ("fh1_3x3_128_256", P, h, w, [128], 256, (3, 3), 1, 1, halo_alt, dict(act="relu")),
         ("fh2_3x3_256_2", P, h, w, [256], 2, (3, 3), 1, 1, [0, 110], dict(out_f32=True)),
         ("enc_7x7s2_3_64", 4, 720, 1280, [3], 64, (7, 7), 2, 3, [0, 22, 12], dict(out_f32=True)),
-        ("enc_3x3_64_64", 4, 360, 640, [64], 64, (3, 3), 1, 1, [0, 71], dict(out_f32=True)),
+        ("enc_3x3_64_64", 4, 360, 640, [64], 64, (3, 3), 1, 1, halo_alt, dict(out_f32=True)),
         ("enc_3x3s2_64_96", 4, 360, 640, [64], 96, (3, 3), 2, 1, v2_alt, dict(out_f32=True)),
         ("enc_3x3_96_96", 8, 180, 320, [96], 96, (3, 3), 1, 1, halo_alt, dict(out_f32=True)),
         ("enc_3x3s2_96_128", 8, 180, 320, [96], 128, (3, 3), 2, 1, v2_alt, dict(out_f32=True)),
@@ -76,7 +77,7 @@ def main():
     ]
     print(f"{'layer':22s} {'impl':>4s} {'us':>9s} {'TF(fp32-class)':>14s} {'max|d| vs impl 0':>17s}", flush=True)
     for name, N, H, W, cin, cout, k, stride, pad, impls, ex in L:
-        if args.only and args.only not in name:
+        if args.only and not re.search(args.only, name):
             continue
         kh, kw = k
         wt = torch.randn(cout, sum(cin), kh, kw, generator=g) / math.sqrt(sum(cin) * kh * kw)
@@ -119,7 +120,7 @@ def main():
         torch.cuda.empty_cache()
 
     # ---- correlation pyramid of a chunk: level 0 GEMM tile choice, then levels 1..3 by pooling vs by pooled-feature GEMMs
-    if not args.only or "volume" in args.only:
+    if not args.only or re.search(args.only, "volume"):
         n8 = h * w
         f1, f2 = sp((P, h, w, 256), g, 2.0), sp((P, h, w, 256), g, 2.0)
         vol = None
@@ -160,7 +161,7 @@ def main():
             print(f"  level {l}: max |pooled volume - pooled-feature GEMM| = {d:.3e} (values up to {a[l].abs().max().item():.3e})")
 
     # ---- bilinear x2 up-sampling (decoders): bytes = input read once + output written once
-    if not args.only or "upsample" in args.only:
+    if not args.only or re.search(args.only, "upsample"):
         for shape in ((11, 180, 320, 128), (11, 360, 640, 64), (158, 60, 108, 128)):
             x = torch.randn(*shape, generator=g).to("cuda", torch.float16)
             ms = timeit(lambda: hip.upsample2x(x), args.reps)
