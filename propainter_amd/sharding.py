@@ -578,3 +578,134 @@ def run_logical_shards_graphed(models, frames_u8, flow_masks_u8, masks_dilated_u
         lo, comp = g.result
         out[lo:lo + comp.shape[0]] = comp
     return out, nseg
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# streaming schedule of one long clip on ONE GPU
+# ----------------------------------------------------------------------------------------------------------------
+def wavefront_order(world, nseg, sources):
+    """Host-side issue order of the (rank, segment) launches of a streaming pass.
+
+    ``sources(r, s)`` = the ranks whose segment ``s`` output the exchange after segment ``s`` delivers to rank r (the keys of that
+    Exchange's ``recv``): segment s + 1 of rank r may be issued once segment s of r itself and of every such rank has been issued.
+    Among the ready launches the one with the smallest (rank + segment, segment) goes first -- a diagonal wavefront: when stage D
+    (segment 3) of sub-video k is issued, stage C of k + 1, stage B of k + 2 and RAFT of k + 3 are issued right behind it, each on its
+    own stream.  Pure host arithmetic (tested on CPU); raises if the dependencies admit no order."""
+    pending = sorted((r + s, s, r) for r in range(world) for s in range(nseg))
+    issued, order = set(), []
+    while pending:
+        for i, (_, s, r) in enumerate(pending):
+            if s == 0 or ((r, s - 1) in issued and all((q, s - 1) in issued for q in sources(r, s - 1))):
+                break
+        else:
+            raise RuntimeError("streaming schedule: no segment is ready (cyclic exchange dependencies)")
+        pending.pop(i)
+        issued.add((r, s))
+        order.append((r, s))
+    return order
+
+
+class StreamingClipGraph:
+    """ONE long clip on ONE GPU as a pipeline over its sub-videos: RAFT of sub-video k + 3, flow completion of k + 2 and image
+    propagation of k + 1 run next to the generator windows of sub-video k (the reference walks the four stages over
+    the whole clip one after the other, inference_propainter.py:298-452).
+
+    Every sub-video block is a LOGICAL rank of the sharded pass (``ShardedClipGraph``: its compute segments between the four halo
+    exchanges as hipGraphs, captured once per clip shape); a replay issues the (rank, segment) graphs in ``wavefront_order``, each
+    logical rank on its own HIP stream, the exchanges as device copies between the ranks' static buffers ordered by events.  A
+    generator window of sub-video k reads reference frames of sub-video k + 1, whose image propagation needs completed flows reaching
+    into k + 2, whose completion needs RAFT flows of k + 3 -- that dependency chain IS the halo exchange of the sharded pass, so the
+    wavefront over its segments is the deepest overlap the data flow admits.  Same kernels on the same data as ``run_clip``: the
+    composited frames are bit-identical (tests/test_modules_gpu.py).
+
+    The logical ranks replay concurrently, so each owns a private graph memory pool; the fp32 correlation volumes of RAFT get
+    ``volume_gb`` (default 40 GB, the single-pass budget) split over the ranks and one RAFT stream each.
+
+        s = StreamingClipGraph(models, L, H, W, cfg, device)         # world = number of sub-video blocks of the clip
+        s.load(frames_u8, flow_masks_u8, masks_dilated_u8); s.capture()
+        out_u8 = s.replay()                                           # [L, H, W, 3]; load() + replay() for the next clip
+    """
+
+    def __init__(self, models, L, H, W, cfg, device, world=None, volume_gb=40.0):
+        import dataclasses
+        self.device = torch.device(device)
+        nsub = -(-L // cfg.subvideo_length)
+        self.world = world or nsub
+        if not can_shard(L, cfg, self.world):
+            raise ValueError(f"a {L}-frame clip does not split into {self.world} sub-video blocks of {cfg.subvideo_length} frames")
+        self.models, self.L, self.H, self.W = models, L, H, W
+        self.cfg = dataclasses.replace(cfg, raft_streams=1)         # the ranks run next to each other: one RAFT lane each
+        self.volume_gb = float(volume_gb)
+        self.graphs = [ShardedClipGraph(models, L, H, W, self.cfg, device, r, self.world) for r in range(self.world)]
+        self.streams = [torch.cuda.Stream(self.device) for _ in range(self.world)]
+        self.order = None
+        self._inputs = None
+
+    def load(self, frames_u8, flow_masks_u8, masks_dilated_u8):
+        self._inputs = (frames_u8, flow_masks_u8, masks_dilated_u8)
+        for g in self.graphs:
+            g.load(frames_u8, flow_masks_u8, masks_dilated_u8)
+
+    def capture(self):
+        """Eager warm-up of all logical ranks (engines, tables), then their segments captured in lockstep (as
+        run_logical_shards_graphed); the issue order of the replays is fixed here."""
+        raft = self.models[0]
+        saved = getattr(raft, "volume_budget_bytes", None)
+        if saved is not None:
+            raft.volume_budget_bytes = self.volume_gb * 1e9 / self.world
+        try:
+            run_logical_shards(self.models, *self._inputs, self.cfg, self.device, self.world)
+            torch.cuda.synchronize(self.device)
+            torch.cuda.empty_cache()                      # the warm-up's cached blocks go back before `world` private graph pools grow
+            got = [None] * self.world
+            while True:
+                reqs = [g.capture_next(got[r]) for r, g in enumerate(self.graphs)]
+                assert len({ex.tag if ex is not None else None for ex, _ in reqs}) == 1, "ranks must stop at the same exchange"
+                if reqs[0][0] is None:
+                    break
+                _copy_exchange(reqs)
+                got = [b for _, b in reqs]
+        finally:
+            if saved is not None:
+                raft.volume_budget_bytes = saved
+        torch.cuda.synchronize(self.device)
+        nseg = len(self.graphs[0].segments)
+        assert all(len(g.segments) == nseg for g in self.graphs)
+        self.order = wavefront_order(self.world, nseg, lambda r, s: sorted(self.graphs[r].segments[s][1].recv))
+        return self
+
+    def replay(self, lockstep=False):
+        """One pass over the loaded clip.  lockstep=True: segment by segment over all ranks on the current stream (the schedule of
+        run_logical_shards_graphed: the A/B reference of the streaming order)."""
+        cur = torch.cuda.current_stream(self.device)
+        nseg = len(self.graphs[0].segments)
+        if lockstep:
+            for s in range(nseg):
+                for g in self.graphs:
+                    g.segments[s][0].replay()
+                _copy_exchange([(g.segments[s][1], g.segments[s][2]) for g in self.graphs])
+        else:
+            done = {}
+            for st in self.streams:
+                st.wait_stream(cur)                       # the uploads of load() / the previous pass's readers are ordered before this pass
+            for r, s in self.order:
+                st = self.streams[r]
+                with torch.cuda.stream(st):
+                    if s > 0:
+                        _, ex, bufs = self.graphs[r].segments[s - 1]
+                        for q, (shape, dtype) in sorted(ex.recv.items()):
+                            t = self.graphs[q].segments[s - 1][1].send[r]
+                            assert tuple(t.shape) == tuple(shape) and t.dtype == dtype, (ex.tag, r, q, t.shape, shape)
+                            st.wait_event(done[(q, s - 1)])
+                            bufs[q].copy_(t)
+                    self.graphs[r].segments[s][0].replay()
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    done[(r, s)] = ev
+            for st in self.streams:
+                cur.wait_stream(st)
+        out = torch.zeros((self.L, self.H, self.W, 3), dtype=torch.uint8, device=self.device)
+        for g in self.graphs:
+            lo, comp = g.result
+            out[lo:lo + comp.shape[0]] = comp
+        return out

@@ -409,6 +409,40 @@ def test_sharded_pass_as_hipgraphs_matches_the_unsharded_pass(models):
     assert torch.equal(out, ref_b), f"graphed sharded pass differs in {(out != ref_b).float().mean().item():.3e} of bytes"
 
 
+def test_streaming_schedule_matches_the_unsharded_pass(models):
+    """sharding.StreamingClipGraph: the sub-videos of one clip as logical ranks whose segment graphs replay in wavefront order
+    on one HIP stream per sub-video -- RAFT of sub-video k + 3 next to the generator windows of sub-video k -- must reproduce run_clip
+    bit for bit, in the streaming order, in the lockstep order, and after another clip was loaded (headline precision)."""
+    from propainter_amd.pipeline import InferenceConfig, run_clip
+    from propainter_amd.sharding import StreamingClipGraph
+    from propainter_amd.synthetic import synthetic_clip, synthetic_mask
+    import scipy.ndimage
+    L, H, W = 34, 128, 192
+    m = scipy.ndimage.binary_dilation(synthetic_mask(H, W), iterations=4).astype(np.uint8) * 255
+    masks = np.repeat(m[None], L, 0)
+    clip_a, clip_b = synthetic_clip(L, H, W, seed=12), synthetic_clip(L, H, W, seed=13)
+    dev = torch.device("cuda")
+    cfg = InferenceConfig(raft_iter=3, subvideo_length=10, neighbor_length=4, ref_stride=3, fp16=True)
+    raft = models[0]
+    raft.precision = "f16x3"
+    try:
+        ref_a, ref_b = run_clip(models, clip_a, masks, masks, cfg, dev), run_clip(models, clip_b, masks, masks, cfg, dev)
+        sc = StreamingClipGraph(models, L, H, W, cfg, dev)
+        sc.load(clip_a, masks, masks)
+        sc.capture()
+        assert sc.world == 4 and sc.order[:6] == [(0, 0), (1, 0), (0, 1), (2, 0), (1, 1), (0, 2)]
+        out_a = sc.replay()
+        out_a2 = sc.replay()                      # a second pass over the same static buffers
+        sc.load(clip_b, masks, masks)
+        out_b = sc.replay()
+        out_b_lock = sc.replay(lockstep=True)
+    finally:
+        raft.precision = None
+    torch.cuda.synchronize()
+    for name, got, ref in (("a", out_a, ref_a), ("a again", out_a2, ref_a), ("b", out_b, ref_b), ("b lockstep", out_b_lock, ref_b)):
+        assert torch.equal(got, ref), f"streaming pass ({name}) differs in {(got != ref).float().mean().item():.3e} of bytes"
+
+
 def test_generator_nearest_interpolation_and_batch_of_two(models, sds):
     """InpaintGenerator.forward(interpolation='nearest') (model/propainter.py:148,319) and b = 2 against the oracle."""
     gen = models[2]

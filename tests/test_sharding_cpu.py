@@ -177,3 +177,26 @@ def test_two_ranks_over_gloo_match_the_unsharded_pass():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert ok and lo == 0 and n == 40          # 3 sub-videos of 20 on 2 ranks: blocks of 40 frames
+
+
+def test_wavefront_order_of_the_streaming_schedule():
+    """sharding.wavefront_order: every (rank, segment) exactly once, after its own previous segment and after the previous segment of
+    every rank it receives from; stage D (segment 3) of sub-video k is issued in one wave with C of k + 1, B of k + 2 and RAFT of k + 3;
+    dependencies beyond the direct neighbours are honoured; an unsatisfiable dependency raises instead of hanging."""
+    from propainter_amd.sharding import wavefront_order
+    world, nseg = 5, 5
+    nb = lambda r, s: [q for q in (r - 1, r + 1) if 0 <= q < world]
+    order = wavefront_order(world, nseg, nb)
+    assert sorted(order) == [(r, s) for r in range(world) for s in range(nseg)]
+    pos = {rs: i for i, rs in enumerate(order)}
+    for r, s in order:
+        if s:
+            assert pos[(r, s - 1)] < pos[(r, s)] and all(pos[(q, s - 1)] < pos[(r, s)] for q in nb(r, s - 1))
+    i = pos[(0, 3)]
+    assert order[i - 3:i + 1] == [(3, 0), (2, 1), (1, 2), (0, 3)]
+    far = lambda r, s: [q for q in (r - 2, r + 2) if 0 <= q < world]           # a rank two blocks away delivers
+    order = wavefront_order(world, nseg, far)
+    pos = {rs: i for i, rs in enumerate(order)}
+    assert all(pos[(q, s - 1)] < pos[(r, s)] for r, s in order if s for q in far(r, s - 1))
+    with pytest.raises(RuntimeError):
+        wavefront_order(2, 2, lambda r, s: [5])                                    # a source that never runs

@@ -1,0 +1,98 @@
+#!/usr/bin/env python
+"""One LONG clip on one GPU: the whole-pass hipGraph (pipeline.ClipGraph: stages A-D one after the other over the whole clip, the
+reference's order) against the streaming schedule (sharding.StreamingClipGraph: the sub-videos as a pipeline, RAFT of sub-video k + 3
+next to the generator windows of sub-video k).  BASELINE config 4 by default (720x1280, 320 frames, sub-videos of 80).
+
+    python tools/bench_streaming.py [--frames 320 --height 720 --width 1280 --subvideo_length 80 --steps 2] > gpurun_out/streaming.json
+
+Prints one JSON object: ms per clip and frames/s of both schedules (hipGraph replays, inputs resident, barrier-free single process),
+the lockstep replay of the same segment graphs (the A/B that isolates the ORDER), peak memory, and that the streaming output equals
+the whole-pass output byte for byte."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import scipy.ndimage
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from propainter_amd import hip  # noqa: E402
+from propainter_amd.pipeline import ClipGraph, InferenceConfig  # noqa: E402
+from propainter_amd.sharding import StreamingClipGraph  # noqa: E402
+from propainter_amd.synthetic import seeded_models, synthetic_clip, synthetic_mask  # noqa: E402
+
+
+def timed(fn, steps, dev):
+    fn()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = fn()
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) * 1e3 / steps, out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=320)
+    ap.add_argument("--height", type=int, default=720)
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--subvideo_length", type=int, default=80)
+    ap.add_argument("--neighbor_length", type=int, default=10)
+    ap.add_argument("--ref_stride", type=int, default=10)
+    ap.add_argument("--raft_iter", type=int, default=20)
+    ap.add_argument("--raft-dtype", default="f16x3")
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--volume-gb", type=float, default=40.0)
+    ap.add_argument("--skip-whole-pass", action="store_true")
+    args = ap.parse_args()
+    hip.lib()
+    dev = torch.device("cuda", 0)
+    L, H, W = args.frames, args.height, args.width
+    models = seeded_models(dev, raft_precision=args.raft_dtype)
+    cfg = InferenceConfig(raft_iter=args.raft_iter, subvideo_length=args.subvideo_length, neighbor_length=args.neighbor_length,
+                          ref_stride=args.ref_stride, fp16=True)
+    m = scipy.ndimage.binary_dilation(synthetic_mask(H, W), iterations=4).astype(np.uint8) * 255
+    clip, masks = synthetic_clip(L, H, W, seed=2023), np.repeat(m[None], L, 0)
+    rec = {"workload": f"{H}x{W}x{L} frames, subvideo_length {args.subvideo_length}, fp16 stages + RAFT {args.raft_dtype}, one MI355X",
+           "steps": args.steps}
+
+    torch.cuda.reset_peak_memory_stats(dev)
+    t0 = time.perf_counter()
+    sc = StreamingClipGraph(models, L, H, W, cfg, dev, volume_gb=args.volume_gb)
+    sc.load(clip, masks, masks)
+    sc.capture()
+    rec["streaming_capture_s"] = time.perf_counter() - t0
+    rec["logical_ranks"] = sc.world
+    rec["issue_order_head"] = sc.order[:12]
+    ms_stream, out_stream = timed(sc.replay, args.steps, dev)
+    ms_lock, out_lock = timed(lambda: sc.replay(lockstep=True), args.steps, dev)
+    out_stream, out_lock = out_stream.clone(), out_lock.clone()
+    rec["streaming"] = {"ms_per_clip": ms_stream, "frames_per_s": L / ms_stream * 1e3}
+    rec["same_graphs_lockstep"] = {"ms_per_clip": ms_lock, "frames_per_s": L / ms_lock * 1e3}
+    rec["streaming_equals_lockstep"] = bool(torch.equal(out_stream, out_lock))
+    rec["streaming_peak_reserved_GB"] = torch.cuda.max_memory_reserved(dev) / 1e9
+    print(json.dumps(rec), file=sys.stderr, flush=True)
+
+    if not args.skip_whole_pass:
+        del sc
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats(dev)
+        t0 = time.perf_counter()
+        g = ClipGraph(models, L, H, W, cfg, dev, example=(clip, masks, masks), release_eager_pool=True)
+        rec["whole_pass_capture_s"] = time.perf_counter() - t0
+        ms_whole, out_whole = timed(g.replay, args.steps, dev)
+        rec["whole_pass"] = {"ms_per_clip": ms_whole, "frames_per_s": L / ms_whole * 1e3}
+        rec["whole_pass_peak_reserved_GB"] = torch.cuda.max_memory_reserved(dev) / 1e9
+        rec["streaming_equals_whole_pass"] = bool(torch.equal(out_stream, out_whole))
+        rec["speedup_streaming_vs_whole_pass"] = ms_whole / ms_stream
+    print(json.dumps(rec))
+
+
+if __name__ == "__main__":
+    main()

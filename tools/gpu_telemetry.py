@@ -4,7 +4,7 @@ DESIGN.md section 3 -- the convolution family clocks to the power budget).
 
     python tools/gpu_telemetry.py out.json -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-precisions
 
-Sources, in order of preference: the amdgpu sysfs / hwmon files of card 0 (no subprocess: ~1 ms per sample), `amd-smi metric`,
+Sources, in order of preference: the amdgpu sysfs / hwmon files of every amdgpu card (the busy one is reported; no subprocess: ~1 ms per sample), `amd-smi metric`,
 `rocm-smi`.  Writes {"samples": [{t, sclk_mhz, power_w, temp_c, busy_pct}], "summary": {...}} and prints the summary."""
 import glob
 import json
@@ -25,13 +25,15 @@ def _read(p):
 
 
 def sysfs_sources():
-    devs = sorted(glob.glob("/sys/class/drm/card*/device"))
-    for d in devs:
+    """Every amdgpu card of the box as (device dir, hwmon dir): a pool box may expose several cards while the job sees one of them --
+    all are sampled, the summary reports the card that was busy (the first card alone gave an idle reading on such a box)."""
+    out = []
+    for d in sorted(glob.glob("/sys/class/drm/card*/device")):
         if _read(os.path.join(d, "vendor")) != "0x1002":
             continue
         hw = sorted(glob.glob(os.path.join(d, "hwmon", "hwmon*")))
-        return d, (hw[0] if hw else None)
-    return None, None
+        out.append((d, hw[0] if hw else None))
+    return out
 
 
 def sample_sysfs(dev, hw):
@@ -68,29 +70,43 @@ def sample_smi():
 def main():
     out_path = sys.argv[1]
     cmd = sys.argv[sys.argv.index("--") + 1:]
-    dev, hw = sysfs_sources()
-    samples, stop = [], threading.Event()
+    cards = sysfs_sources()
+    per_card = [[] for _ in cards]
+    smi, stop = [], threading.Event()
     t0 = time.time()
 
     def loop():
         while not stop.is_set():
-            s = sample_sysfs(dev, hw) if dev else {}
-            if not s:
+            t = round(time.time() - t0, 3)
+            got = False
+            for rows, (dev, hw) in zip(per_card, cards):
+                s = sample_sysfs(dev, hw)
+                if s:
+                    s["t"] = t
+                    rows.append(s)
+                    got = True
+            if not got:
                 s = sample_smi()
+                s["t"] = t
+                smi.append(s)
                 time.sleep(0.5)
-            s["t"] = round(time.time() - t0, 3)
-            samples.append(s)
             time.sleep(0.1)
     th = threading.Thread(target=loop, daemon=True)
     th.start()
     rc = subprocess.call(cmd)
     stop.set()
     th.join(timeout=15)
-    busy = [s for s in samples if s.get("busy_pct", 100) >= 50]
+
     def stat(key, rows):
         v = [r[key] for r in rows if key in r]
         return None if not v else {"n": len(v), "mean": sum(v) / len(v), "min": min(v), "max": max(v)}
-    summary = {"command": " ".join(cmd), "exit": rc, "samples": len(samples), "source": "sysfs" if dev else "smi",
+    # the card the job ran on = the one with the highest mean busy percentage
+    means = [(stat("busy_pct", rows) or {"mean": -1})["mean"] for rows in per_card]
+    pick = max(range(len(cards)), key=lambda i: means[i]) if cards else -1
+    samples = per_card[pick] if pick >= 0 else smi
+    busy = [s for s in samples if s.get("busy_pct", 100) >= 50]
+    summary = {"command": " ".join(cmd), "exit": rc, "samples": len(samples), "source": "sysfs" if cards else "smi",
+               "card": cards[pick][0] if pick >= 0 else None, "cards_sampled": len(cards), "mean_busy_pct_per_card": means,
                "all": {k: stat(k, samples) for k in ("sclk_mhz", "sclk_mhz_hwmon", "power_w", "temp_c", "busy_pct")},
                "while_busy": {k: stat(k, busy) for k in ("sclk_mhz", "sclk_mhz_hwmon", "power_w", "temp_c")}}
     json.dump({"summary": summary, "samples": samples}, open(out_path, "w"))
