@@ -649,6 +649,8 @@ class StreamingClipGraph:
     def capture(self):
         """Eager warm-up of all logical ranks (engines, tables), then their segments captured in lockstep (as
         run_logical_shards_graphed); the issue order of the replays is fixed here."""
+        if self._inputs is None:
+            raise RuntimeError("StreamingClipGraph.capture(): load() a clip first (the warm-up and the capture pass run on it)")
         raft = self.models[0]
         saved = getattr(raft, "volume_budget_bytes", None)
         if saved is not None:
@@ -677,6 +679,8 @@ class StreamingClipGraph:
     def replay(self, lockstep=False):
         """One pass over the loaded clip.  lockstep=True: segment by segment over all ranks on the current stream (the schedule of
         run_logical_shards_graphed: the A/B reference of the streaming order)."""
+        if self.order is None:
+            raise RuntimeError("StreamingClipGraph.replay(): capture() first")
         cur = torch.cuda.current_stream(self.device)
         nseg = len(self.graphs[0].segments)
         if lockstep:
