@@ -47,11 +47,13 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--pairs", type=int, default=35)
     ap.add_argument("--only", default="")
+    ap.add_argument("--h8", type=int, default=90, help="feature-map height (1/8 of the frame): 90 = 720p, 135 = 1080p")
+    ap.add_argument("--w8", type=int, default=160)
     args = ap.parse_args()
     hip.lib()
     print(torch.cuda.get_device_name(0), flush=True)
     g = torch.Generator().manual_seed(5)
-    P, h, w = args.pairs, 90, 160
+    P, h, w = args.pairs, args.h8, args.w8
     halo_alt = [0, 116, 0, 116]      # 116: the software-pipelined halo kernel (conv_halo_pipe.h); each twice
     v2_alt = [0, 12, 13, 22]
     # name, N, H, W, cin list, cout, k, stride, pad, impls, extras
