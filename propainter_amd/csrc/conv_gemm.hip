@@ -534,6 +534,7 @@ extern "C" int pp_conv2d(const pp_conv_args_t* a, void* stream) {
   p.out2 = (char*)a->out2; p.out2_cstride = a->out2_cstride; p.out2_choff = a->out2_choff;
   p.split = a->split; p.out_lo = a->out_lo; p.out2_lo = a->out2_lo; p.preadd_lo = a->preadd_lo; p.res_lo = a->res_lo;
   p.fuse_a_lo = a->fuse_a_lo; p.fuse_b_lo = a->fuse_b_lo;
+  p.wfrag = 0;
   {   // PP_EPI_DIRECT: 0 = never, 1 (default) = the batched GEMMs (short K, output-bound), 2 = every plain fp32 output (read per launch: A/B runs)
     const char* ed = getenv("PP_EPI_DIRECT");
     const int mode = ed != nullptr ? atoi(ed) : 1;
@@ -583,7 +584,7 @@ extern "C" int pp_conv2d(const pp_conv_args_t* a, void* stream) {
     // split == 2: TRI-PRODUCT K format (per tap 4 hi + 4 lo chunks of 32 channels, weights [W_hi | W_lo]): the halo-tile kernel only;
     // split == 1: every block walked three times by a plain K loop: the LDS-DMA (v2) kernel
     // ... or, outside the halo family (1x1, strided, batched GEMM, sources that are no multiples of 32 channels), the v2 kernel's tri step
-    const int v2cfg = (a->impl >= 10 && a->impl < 70) || (a->impl > 110 && a->impl != 116) ? a->impl : 0;
+    const int v2cfg = (a->impl >= 10 && a->impl < 70) || (a->impl > 110 && (a->impl < 116 || a->impl > 118)) ? a->impl : 0;
     int rc = -1000;
     if (a->split == 2 && (a->impl == 0 || a->impl == 110)) rc = conv_head_dispatch(p, st, a->impl == 110);   // 3x3 heads with <= 4 couts (opt-in)
     PP_REQUIRE(a->impl != 110 || rc != -1000, PP_ERR_ARG, "pp_conv2d: impl 110 (streaming head kernel) not available for this layer");
@@ -614,7 +615,7 @@ extern "C" int pp_conv2d(const pp_conv_args_t* a, void* stream) {
     if (rc != -1000) return rc;
     PP_REQUIRE(a->impl == 0, PP_ERR_ARG, "pp_conv2d: impl %d (wide halo tiles) not available for this shape", a->impl);
   }
-  if (a->dtype == PP_F16 && !deform && (a->impl == 0 || (a->impl >= 70 && a->impl < 80) || (a->impl >= 82 && a->impl <= 89) || a->impl == 106 || a->impl == 109 || (a->impl >= 111 && a->impl <= 116))) {
+  if (a->dtype == PP_F16 && !deform && (a->impl == 0 || (a->impl >= 70 && a->impl < 80) || (a->impl >= 82 && a->impl <= 89) || a->impl == 106 || a->impl == 109 || (a->impl >= 111 && a->impl <= 118))) {
     // halo-tile kernel family (stride-1 "same" 3x3 / 1x5 / 5x1 windows over 64-channel-multiple sources)
     const int rc = conv_v3_dispatch(p, a->impl, st);
     if (rc != -1000) return rc;

@@ -52,6 +52,18 @@ static int launch_tiny(const ConvParams& p, hipStream_t stream) {     // 16-cout
   return halo_shared_weights() ? launch_v3<TH, TW, KH, KW, 16>(p, stream) : launch_v3<TH, TW, KH, KW, 16, false, 0, 64, false, true>(p, stream);
 }
 
+#if defined(PP_DIAG)
+// [diagnostic] row-major packed weights [cout_pad][kchunks] (16-byte chunks) -> fragment-major: block (cb = row / 16, ks = chunk / 8,
+// kk = (chunk / 4) & 1) is one contiguous KB whose lane l4 * 16 + l15 (l15 = row % 16, l4 = chunk % 4) owns 16 bytes
+__global__ void repack_fragment_major_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int cout_pad, int kchunks) {
+  const long long i = blockIdx.x * 256ll + threadIdx.x;
+  if (i >= (long long)cout_pad * kchunks) return;
+  const int row = (int)(i / kchunks), c = (int)(i % kchunks);
+  const int cb = row >> 4, l15 = row & 15, ks = c >> 3, kk = (c >> 2) & 1, l4 = c & 3;
+  dst[(((long long)cb * (kchunks / 8) + ks) * 2 + kk) * 64 + l4 * 16 + l15] = src[i];
+}
+#endif
+
 // Returns -1000 when the shape is outside the halo-tile family (caller falls back to v2).
 // cfg: 0 = auto, 70 = force (BN by cout), 71 = BN 128, 72 = BN 64.
 int conv_v3_dispatch(const ConvParams& p, int cfg, hipStream_t stream) {
@@ -93,6 +105,26 @@ int conv_v3_dispatch(const ConvParams& p, int cfg, hipStream_t stream) {
                       // instead of 0.5, half the weight DMA per MFMA) -- one block per CU (120 KB LDS), one wave per SIMD
     if (kh == 3 && kw == 3) return launch_v3<16, 16, 3, 3, 128, false, 0, 128>(p, stream);
     if (kh == 1 && kw == 5) return launch_v3<16, 16, 1, 5, 128, false, 0, 128>(p, stream);
+    return -1000;
+  }
+  if (cfg == 117 || cfg == 118) {   // DIRB with the weights repacked fragment-major (coalesced 1 KB fragment loads); 118 = + phase timing
+    static char* d_frag = nullptr;
+    static const char* last_w = nullptr;
+    static size_t cap = 0, last_bytes = 0;
+    const size_t bytes = (size_t)p.cout_pad * p.kchunks * 16;
+    if (bytes > cap) { if (d_frag) hipFree(d_frag); if (hipMalloc((void**)&d_frag, bytes) != hipSuccess) return -1000; cap = bytes; last_w = nullptr; }
+    if (last_w != p.weight || last_bytes != bytes) {
+      const long long nchunk = (long long)bytes / 16;
+      hipLaunchKernelGGL(repack_fragment_major_kernel, dim3((unsigned)((nchunk + 255) / 256)), dim3(256), 0, stream,
+                         reinterpret_cast<const uint4*>(p.weight), reinterpret_cast<uint4*>(d_frag), p.cout_pad, p.kchunks);
+      last_w = p.weight; last_bytes = bytes;
+    }
+    ConvParams q = p;
+    q.weight = d_frag; q.wfrag = 1;
+    const bool pr = cfg == 118;
+    if (kh == 3 && kw == 3) return pr ? launch_v3<8, 16, 3, 3, 128, true, 0, 64, false, false, true>(q, stream) : launch_v3<8, 16, 3, 3, 128, false, 0, 64, false, false, true>(q, stream);
+    if (kh == 1 && kw == 5) return pr ? launch_v3<8, 16, 1, 5, 128, true, 0, 64, false, false, true>(q, stream) : launch_v3<8, 16, 1, 5, 128, false, 0, 64, false, false, true>(q, stream);
+    if (kh == 5 && kw == 1) return pr ? launch_v3<16, 8, 5, 1, 128, true, 0, 64, false, false, true>(q, stream) : launch_v3<16, 8, 5, 1, 128, false, 0, 64, false, false, true>(q, stream);
     return -1000;
   }
   if (cfg == 112 || cfg == 113) {   // weight fragments straight from L2 into registers, one step ahead (DIRB); 113 = + phase timing

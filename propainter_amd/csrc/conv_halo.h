@@ -168,7 +168,7 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : HALO_MIN_WAVES
     if constexpr (DIRB) {                                                                                       \
       _Pragma("unroll") for (int kk_ = 0; kk_ < 2; ++kk_)                                                       \
         _Pragma("unroll") for (int f_ = 0; f_ < TN; ++f_)                                                       \
-          bnxt[kk_][f_] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, bvo[f_], (ks_) * 128 + kk_ * 64, 0)); \
+          bnxt[kk_][f_] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, bvo[f_], p.wfrag ? (ks_) * 2048 + kk_ * 1024 : (ks_) * 128 + kk_ * 64, 0)); \
     } else if constexpr (BCONTIG) {                                                                                    \
       if (!B_RAGGED || wave < B_INST)                                                                           \
         V3WeightPieces<0, B_PER_WAVE>::issue(rw, bst0 + (par_) * BSTAGE + wave * B_PER_WAVE * 1024, wvoff, (ks_) * 128); \
@@ -202,7 +202,9 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : HALO_MIN_WAVES
   f16x8 bcur[2][DIRB ? TN : 1], bnxt[2][DIRB ? TN : 1];
   if constexpr (DIRB) {
 #pragma unroll
-    for (int f = 0; f < TN; ++f) bvo[f] = (n0 + wn * WN + f * 16 + l15) * (p.kchunks * 16) + l4 * 16;
+    for (int f = 0; f < TN; ++f)
+      bvo[f] = p.wfrag ? ((n0 + wn * WN) / 16 + f) * (p.kchunks / 8) * 2048 + lane * 16      // fragment-major: block (cb, ks, kk) = 1 KB, lane-linear
+                       : (n0 + wn * WN + f * 16 + l15) * (p.kchunks * 16) + l4 * 16;
   }
 
   const int nblocks = p.kchunks / (8 * NTAPS);

@@ -48,6 +48,9 @@ struct ConvParams {
   // plain fp32 output without epilogue operands: store the accumulators directly (4 consecutive couts = 16 bytes per lane, 64 contiguous
   // bytes per pixel row and MFMA tile) instead of staging them through LDS -- short-K, output-bound launches (the correlation-volume GEMM)
   int epi_direct;
+  // [PP_DIAG] DIRB halo variant: `weight` holds the FRAGMENT-MAJOR repack (one contiguous KB per (16-cout block, K step, K half): lane
+  // l4 * 16 + l15 owns 16 bytes) instead of row-major rows -- every B-fragment load is one coalesced 1 KB request
+  int wfrag;
 };
 
 // activation of the late (post-staging) epilogue path: same fast forms as the register path of conv_epilogue.h
