@@ -313,6 +313,17 @@ def conv2d_raw(args: ConvArgs, cin_read=None, on=None, split_k=0):
     nbytes = args.N * args.H * args.W * cin * esz + args.groups * args.cout_pad * K * esz + M * args.cout_g * args.groups * osz
     if args.dcn_offmask:
         nbytes += M * 432 * esz
+    # operands of the fused epilogue are algorithmic traffic too (each read / written once per output element): residual or pre-activation
+    # addend, the GRU state h (z | r gate: its r half; h gate: all couts) and gate z, the second output r * h -- without them the byte model of
+    # the fused SepConvGRU layers was ~40 % short and their measured HBM traffic looked like re-reads
+    if args.residual:
+        nbytes += M * args.cout_g * args.groups * esz
+    if args.preadd:
+        nbytes += M * args.cout_g * esz
+    if args.fuse == FUSE_GRU_ZR:
+        nbytes += 2 * M * (args.cout_g - args.fuse_split) * esz              # h read, r * h written
+    elif args.fuse == FUSE_GRU_H:
+        nbytes += 2 * M * args.cout_g * esz                                  # h and z read
     name = "conv_gemm_dcn" if args.dcn_offmask else ("conv_gemm_f16x3" if split_k else "conv_gemm_f16" if args.dtype == PP_F16 else "conv_gemm_f32")
     if _profiler is not None and getattr(_profiler, "detail", False):      # per-layer-shape classes (bench.py --detail)
         name += f" | taps{args.tap_h}x{args.tap_w} s{args.stride_h} K{K} cout{args.cout_g}x{args.groups} M{M} {args.H}x{args.W}"
