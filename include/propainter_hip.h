@@ -251,6 +251,15 @@ int pp_corr_feature_pyramid(const void* f2, void* lvl1, void* lvl2, void* lvl3, 
 int pp_corr_feature_pyramid_split(const void* f2, void* lvl1, void* lvl2, void* lvl3, int P, int h, int w, void* stream);
 int pp_corr_lookup_otf(const void* f1, const void* f2_lvl0, const void* f2_lvl1, const void* f2_lvl2, const void* f2_lvl3,
                        const float* coords, void* out, int out_cstride, int out_cpad, int P, int h, int w, void* stream);
+/* The volume-free lookup at fp32-class precision ("f16x3"; replaces CorrBlock.__init__ + __call__, RAFT/corr.py:13-60, for the engine
+ * that keeps RAFT at the reference's precision, inference_propainter.py:311): f1 and the four f2 levels (f2 itself and the outputs of
+ * pp_corr_feature_pyramid_split) are SPLIT-PLANE fp16 NHWC [P, h>>l, w>>l, 512] = 256 hi | 256 lo; every dot product is
+ * hi.hi + lo.hi + hi.lo on the fp16 matrix cores with fp32 accumulation, the blend uses pp_corr_lookup's per-tap coordinate round trip.
+ * out: split-plane fp16 NHWC [P,h,w,out_cstride], hi plane at channel 0, lo plane at out_cstride / 2; level l, tap (a, b) at channel
+ * l * 88 + a * 9 + b of each plane (81 taps + 7 zero channels per level: the 1x1 convolution behind it reads full 32-channel blocks;
+ * permute its weight columns accordingly); out_cstride >= 704, multiple of 16.  Deterministic, batch-invariant. */
+int pp_corr_lookup_otf_split(const void* f1, const void* f2_lvl0, const void* f2_lvl1, const void* f2_lvl2, const void* f2_lvl3,
+                             const float* coords, void* out, int out_cstride, int P, int h, int w, void* stream);
 
 /* Input of the motion encoder's 7x7 flow convolution (RAFT/update.py:85,92: convf1 = Conv2d(2, 128, 7, padding=3)) laid out so
  * that the convolution needs K = 7 x 16 instead of 49 taps x 8 padded channels: rows[pixel, 2*kx + c] = flow_c(x + kx - 3, y)

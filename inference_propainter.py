@@ -135,6 +135,34 @@ def main(argv=None):
     if rank == 0:
         print(f'\nProcessing: {video_name} [{L} frames]...  (RAFT precision {models[0].precision}, stages {"fp16" if args.fp16 else "fp32"})')
     t0 = time.perf_counter()
+    state = {"sharded": False}
+    failed = True
+    try:
+        _run(args, models, cfg, frames_u8, flow_masks, masks_dilated, L, world, rank, device, t0, save_root, out_size, fps, video_name, state)
+        failed = False
+    finally:
+        if world > 1:
+            import torch.distributed as dist
+            # Idle ranks (nothing to shard: rank 0 works alone) and finished ranks meet at a barrier before the group is torn down.  It
+            # sits in a ``finally`` so that rank 0 failing in an UNSHARDED pass still releases the idle ranks instead of leaving them to
+            # the watchdog.  A rank that fails inside a SHARDED pass must not wait: its peers are blocked in point-to-point exchanges
+            # with it, not at the barrier -- it leaves at once, which closes their connections and fails them promptly.
+            if not (failed and state["sharded"]):
+                try:
+                    dist.barrier()
+                except Exception as e:      # a peer died: nothing left to wait for
+                    print(f'[rank {rank}] barrier before shutdown failed: {type(e).__name__}: {e}', file=sys.stderr)
+            try:
+                dist.destroy_process_group()
+            except Exception:
+                pass
+
+
+def _run(args, models, cfg, frames_u8, flow_masks, masks_dilated, L, world, rank, device, t0, save_root, out_size, fps, video_name, state):
+    import torch
+    from propainter_amd import video_io
+    from propainter_amd.model.modules.flow_comp_raft import assert_finite_flows
+    from propainter_amd.pipeline import run_clip
     comp = None
     if world > 1:
         from propainter_amd.sharding import can_shard, gather_frames, run_clip_sharded
@@ -142,6 +170,7 @@ def main(argv=None):
             raise SystemExit('--save_flow / --load_flow describe ONE unsharded clip: run them without torch.distributed.run '
                              '(under sharding every rank computes the RAFT flows of its own sub-videos)')
         if can_shard(L, cfg, world):
+            state["sharded"] = True
             lo, part = run_clip_sharded(models, frames_u8, flow_masks, masks_dilated, cfg, device)
             comp = gather_frames(lo, part, L, dst=0)
         elif rank == 0:      # nothing to shard: rank 0 runs the unsharded pass, the others idle
@@ -162,16 +191,13 @@ def main(argv=None):
             comp = run_clip(models, frames_u8, flow_masks, masks_dilated, cfg, device, gt_flows=gt)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    assert_finite_flows(models[0])        # split-plane RAFT: a value beyond fp16's range would have produced NaN flows -- fail loudly
     if rank == 0:
         comp = comp.cpu().numpy()
         print(f'{L} frames in {dt:.2f} s ({L / dt:.2f} frames/s on {world} GPU(s))')
         video_io.save_results(save_root, list(comp), video_io.masked_preview(frames_u8, masks_dilated), out_size, fps,
                               args.save_frames)
         print(f'\nAll results are saved in {save_root}')
-    if world > 1:
-        import torch.distributed as dist
-        dist.barrier()           # idle ranks wait for the working ones before the group is torn down
-        dist.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -449,6 +449,26 @@ def corr_lookup_otf(f1, f2_levels, coords, out):
     return out
 
 
+OTF_SPLIT_LEVEL_CHANNELS = 88       # channels per pyramid level in pp_corr_lookup_otf_split's output planes (81 taps + 7 zeros)
+
+
+def corr_lookup_otf_split(f1, f2_levels, coords, out):
+    """Volume-free correlation lookup at fp32-class precision: f1 split-plane [P,h,w,512], f2_levels = [f2] + corr_feature_pyramid_split(f2),
+    coords fp32 [P,h,w,2]; writes out split-plane fp16 [P,h,w,704]: level l, tap (a, b) at channel l*88 + a*9 + b of each 352-channel plane."""
+    P, h, w, _ = coords.shape
+    assert coords.dtype == torch.float32 and coords.is_contiguous() and out.is_contiguous() and out.dtype == torch.float16
+    assert out.shape == (P, h, w, 8 * OTF_SPLIT_LEVEL_CHANNELS), out.shape
+    assert f1.dtype == torch.float16 and f1.is_contiguous() and f1.shape == (P, h, w, 512)
+    assert len(f2_levels) == 4 and all(t.is_contiguous() and t.dtype == torch.float16 and t.shape == (P, h >> l, w >> l, 512) for l, t in enumerate(f2_levels))
+    npix = P * h * w
+    # FLOPs: ~400 positions per pixel x 256 channels (the algorithmic dot products of the 4 x (10 x 10) neighbourhoods), three fp16 products each
+    timed("corr_lookup_otf_split", 2.0 * 256 * 400 * npix, _nbytes(f1) + sum(_nbytes(t) for t in f2_levels) + _nbytes(coords) + _nbytes(out),
+          lambda: _check(lib().pp_corr_lookup_otf_split(_p(f1), _p(f2_levels[0]), _p(f2_levels[1]), _p(f2_levels[2]), _p(f2_levels[3]),
+                                                        _p(coords), _p(out), _i(out.shape[-1]), _i(P), _i(h), _i(w), _stream(f1)),
+                         "pp_corr_lookup_otf_split"))
+    return out
+
+
 def raft_flow_taps(coords1, coords0, rows, flow_out=None, flow_choff=0, split=False):
     """rows[P,h,w,16] <- the 7 horizontal taps of flow = coords1 - coords0 (fp32 [P,h,w,2]) per pixel, channel 2*kx + c; optionally
     flow_out[..., flow_choff:flow_choff+2] <- flow (pp_raft_flow_taps).  split: rows fp16 [P,h,w,32] = 16 hi | 16 lo, flow_out split-plane."""

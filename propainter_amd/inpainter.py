@@ -9,6 +9,7 @@ import torch
 from PIL import Image
 
 from . import hip, video_io
+from .model.modules.flow_comp_raft import assert_finite_flows
 from .pipeline import InferenceConfig, run_clip
 
 
@@ -73,4 +74,5 @@ class ProInpainter:
         comp = run_clip((self.fix_raft, self.fix_flow_complete, self.model), frames_u8, flow_masks, masks_dilated, cfg,
                         self.device)
         comp = comp.cpu().numpy()
+        assert_finite_flows(self.fix_raft)            # (after the D2H: the pass is synchronised)
         return [video_io._resize_u8(f, out_size, Image.BILINEAR) for f in comp]

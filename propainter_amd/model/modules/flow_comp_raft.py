@@ -224,6 +224,17 @@ class _RaftEngineSplit(_RaftEngine):
         w2, b2 = sd["cnet.conv2.weight"], sd["cnet.conv2.bias"]
         self.cnet["conv2_net"] = mk(w2[:128], b2[:128])
         self.cnet["conv2_inp"] = mk(w2[128:], b2[128:])
+        # Correlation WITHOUT the all-pairs volume (round 4; csrc/raft_corr_otf.hip, corr_otf_split_kernel): per iteration the tri-product
+        # dot products of the 4 x (10 x 10) neighbourhoods, blended as pp_corr_lookup does.  Its output planes carry 88 channels per
+        # level (81 taps + 7 zeros), so convc1's weight columns are spread accordingly: 11 full 32-channel blocks per plane.
+        # PP_RAFT_SPLIT_VOLUME=1 keeps the fp32 volume + pyramid GEMMs + pp_corr_lookup (A/B, and the reference's own call pattern).
+        self.corr_otf = os.environ.get("PP_RAFT_SPLIT_VOLUME", "0") != "1"
+        LV = hip.OTF_SPLIT_LEVEL_CHANNELS
+        wc1, bc1 = sd["update_block.encoder.convc1.weight"], sd["update_block.encoder.convc1.bias"]
+        wsp = torch.zeros((wc1.shape[0], 4 * LV, 1, 1), dtype=wc1.dtype)
+        for l in range(4):
+            wsp[:, l * LV:l * LV + 81] = wc1[:, l * 81:(l + 1) * 81]
+        self.convc1_otf = mk(wsp, bc1, src_channels=[4 * LV])
         self.pool_volume = os.environ.get("PP_RAFT_POOL_VOLUME", "0") == "1"      # levels 1..3 by pooling the level-0 volume (A/B)
         self.volume_impl = int(os.environ.get("PP_RAFT_VOLUME_IMPL", "0"))        # tile configuration of the volume GEMMs (0 = auto)
 
@@ -258,19 +269,31 @@ class _RaftEngineSplit(_RaftEngine):
         P, h, w, _ = f1.shape
         dev, dt = f1.device, torch.float16
         n8 = h * w
-        # all-pairs correlation pyramid (RAFT/corr.py:13-27,52-60), fp32.  Average pooling is linear -- avg_pool(f1 . f2) = f1 . avg_pool(f2)
-        # -- so levels 1..3 are GEMMs of f1 with the pooled split-plane features (fp32 means, 3 fp16 products per product like level 0)
-        # instead of three pooling passes that re-read the level-0 volume (829 MB per pair-direction at 720p); PP_RAFT_POOL_VOLUME=1 keeps
-        # the pooling passes
-        gemm = lambda b_: batched_gemm_nt_split(f1.view(P, n8, 512), b_.view(P, -1, 512), out_scale=1.0 / 16.0, impl=self.volume_impl)
-        levels = [gemm(f2).view(P * n8, h, w)]
-        if self.pool_volume:
-            hh, ww = h, w
-            for _ in range(3):
-                levels.append(hip.corr_avgpool(levels[-1], P * n8, hh, ww))
-                hh, ww = hh // 2, ww // 2
+        if self.corr_otf:
+            # no all-pairs volume: avg_pool(f1 . f2) = f1 . avg_pool(f2), so f2 is pooled once per pair (fp32 means, stored as planes) and
+            # every iteration computes exactly the dot products its 9 x 9 x 4 windows touch, three fp16 products per product
+            f2c = f2.contiguous()
+            f2_levels = [f2c] + hip.corr_feature_pyramid_split(f2c)
+            f1c = f1.contiguous()
+            corr = torch.empty((P, h, w, 8 * hip.OTF_SPLIT_LEVEL_CHANNELS), dtype=dt, device=dev)
+            lookup = lambda coords: hip.corr_lookup_otf_split(f1c, f2_levels, coords, corr)
+            convc1 = self.convc1_otf
         else:
-            levels += [gemm(fl).view(P * n8, fl.shape[1], fl.shape[2]) for fl in hip.corr_feature_pyramid_split(f2.contiguous())]
+            # all-pairs correlation pyramid (RAFT/corr.py:13-27,52-60), fp32.  Levels 1..3 are GEMMs of f1 with the pooled split-plane
+            # features (fp32 means, 3 fp16 products per product like level 0) instead of three pooling passes that re-read the level-0
+            # volume (829 MB per pair-direction at 720p); PP_RAFT_POOL_VOLUME=1 keeps the pooling passes
+            gemm = lambda b_: batched_gemm_nt_split(f1.view(P, n8, 512), b_.view(P, -1, 512), out_scale=1.0 / 16.0, impl=self.volume_impl)
+            levels = [gemm(f2).view(P * n8, h, w)]
+            if self.pool_volume:
+                hh, ww = h, w
+                for _ in range(3):
+                    levels.append(hip.corr_avgpool(levels[-1], P * n8, hh, ww))
+                    hh, ww = hh // 2, ww // 2
+            else:
+                levels += [gemm(fl).view(P * n8, fl.shape[1], fl.shape[2]) for fl in hip.corr_feature_pyramid_split(f2.contiguous())]
+            corr = torch.empty((P, h, w, 656), dtype=dt, device=dev)
+            lookup = lambda coords: hip.corr_lookup(levels, coords, corr, split=True)
+            convc1 = self.convc1
         net = net0.clone()
         pre = [(G["zr_pre"]([inp]), G["q_pre"]([inp])) for G in self.gru]     # iteration-invariant partial sums
         xbuf = torch.empty((P, h, w, 256), dtype=dt, device=dev)            # [motion(126) | flow(2)] x (hi, lo)
@@ -278,15 +301,14 @@ class _RaftEngineSplit(_RaftEngine):
                                 torch.arange(w, device=dev, dtype=torch.float32), indexing="ij")
         coords0 = torch.stack([xs, ys], -1)[None].expand(P, h, w, 2).contiguous()
         coords1 = coords0.clone()
-        corr = torch.empty((P, h, w, 656), dtype=dt, device=dev)
         frow = torch.empty((P, h, w, 32), dtype=dt, device=dev)
         zbuf = torch.empty((P, h, w, 256), dtype=dt, device=dev)
         rh = torch.empty((P, h, w, 256), dtype=dt, device=dev)
         delta = torch.zeros((P, h, w, 8), dtype=torch.float32, device=dev)
         for it in range(iters):
-            hip.corr_lookup(levels, coords1, corr, split=True)
+            lookup(coords1)
             hip.raft_flow_taps(coords1, coords0, frow, flow_out=xbuf, flow_choff=126, split=True)
-            cor = self.convc2([self.convc1([corr], act="relu")], act="relu")
+            cor = self.convc2([convc1([corr], act="relu")], act="relu")
             flo = self.convf2([self.convf1([frow], act="relu")], act="relu")
             self.convm([cor, flo], out=xbuf, out_choff=0, act="relu")
             for G, (pzr, pq) in zip(self.gru, pre):
@@ -296,6 +318,24 @@ class _RaftEngineSplit(_RaftEngine):
             coords1 = coords1 + delta[..., :2]
         mask = self.mask2([self.mask0([net], act="relu")], out_scale=0.25, out_dtype=torch.float32)
         return hip.convex_upsample((coords1 - coords0).contiguous(), mask)
+
+
+def assert_finite_flows(raft):
+    """Raises FloatingPointError when the last ``RAFT_bi.forward`` produced a non-finite flow.  Host-synchronising (reads a one-element
+    device flag): call it where the pass is synchronised anyway (after the D2H of the composited frames).
+
+    Why it exists: the default RAFT precision under ``--fp16`` is "f16x3" -- fp32-class values stored as two fp16 planes (hi = fp16(v),
+    lo = fp16(v - hi)).  That format has fp16's EXPONENT range: an activation or weight with |v| > 65504 becomes inf in its hi plane and
+    every flow that depends on it NaN (never a silently wrong finite value; tests/test_split_plane_gpu.py::test_split_plane_overflow_is_loud).
+    With seeded and released-style weights RAFT's activations stay below ~1e3 (features are instance-normalised, correlations are scaled by
+    1/16, flows are pixels), so the guard is a backstop for foreign checkpoints or corrupt inputs; ``precision="f32"`` (exact fp32 matrix
+    instructions) has fp32's range."""
+    flag = getattr(raft, "_flows_finite", None)
+    if flag is not None and not bool(flag):
+        prec = getattr(raft, "_flows_precision", "?")
+        hint = ("a value left fp16's range (|v| > 65504) in the split-plane engine: run RAFT_bi(precision='f32') (CLI: --raft_fp32)"
+                if prec == "f16x3" else "check the input frames / checkpoint")
+        raise FloatingPointError(f"RAFT produced non-finite flows at precision {prec!r}; {hint}")
 
 
 class RAFT_bi(nn.Module):
@@ -337,6 +377,7 @@ class RAFT_bi(nn.Module):
         # fp32 all-pairs correlation volumes + pyramids of the pair-direction chunks in flight (volume modes "f32" / "f16x3")
         self.volume_budget_bytes = float(os.environ.get("PP_RAFT_VOLUME_GB", "40")) * 1e9
         self._engines = {}
+        self._flows_finite = None              # device flag of the last forward (assert_finite_flows)
         self.to(device)
         self.eval()
 
@@ -391,13 +432,28 @@ class RAFT_bi(nn.Module):
         P = 2 * b * (l_t - 1)
         n8 = h8 * w8
         lanes = streams if (streams > 1 and P >= 2 * streams) else 1
-        if eng.corr_otf:      # largest activation of the update block: the [P, h8, w8, 328] lookup tile, < 2 GiB (32-bit buffer offsets)
-            chunk = self.max_pairs or max(1, ((1 << 31) - 1) // (n8 * 328 * 2))
+        if eng.corr_otf:      # largest activation of the update block: the [P, h8, w8, 328] (split-plane: 2 x 352) lookup tile, < 2 GiB (32-bit buffer offsets)
+            chunk = self.max_pairs or max(1, ((1 << 31) - 1) // (n8 * (8 * hip.OTF_SPLIT_LEVEL_CHANNELS if eng.split else 328) * 2))
         else:                 # fp32 all-pairs pyramid: 1.34 x n8^2 x 4 bytes per pair-direction, 40 GB over the chunks in flight
             per_pair = n8 * n8 * 4 * 1.34
             # (at least 4 pair-directions per chunk: at 1080x1920 a pair's pyramid is 5.6 GB and 40 GB over 3 lanes would leave 2-pair
             #  chunks -- convolution launches over 64 800 pixels that do not fill the chip)
-            chunk = self.max_pairs or max(min(4, -(-P // lanes)), int(self.volume_budget_bytes // lanes // per_pair))
+            by_budget = int(self.volume_budget_bytes // lanes // per_pair)
+            floor_ = min(4, -(-P // lanes))
+            if by_budget < floor_:
+                # the floor may exceed the BUDGET (a soft target) but never what the device can actually hold: volumes of every lane in
+                # flight + 25 % for the update block's activations must fit the free memory (1440p: a pair's pyramid is ~18 GB)
+                free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+                fit = int(free * 0.75 // lanes // per_pair)
+                if fit < floor_:
+                    floor_ = max(1, min(floor_, fit))
+                if floor_ > max(by_budget, 1) and not getattr(self, "_warned_budget", False):
+                    self._warned_budget = True
+                    import warnings
+                    warnings.warn(f"RAFT volume budget {self.volume_budget_bytes / 1e9:.0f} GB < {lanes} lanes x {floor_} pair-directions x "
+                                  f"{per_pair / 1e9:.1f} GB = {lanes * floor_ * per_pair / 1e9:.0f} GB: running {floor_}-pair chunks "
+                                  f"(PP_RAFT_VOLUME_GB / RAFT_bi.volume_budget_bytes raise the budget, streams=1 lowers the need)")
+            chunk = self.max_pairs or max(floor_, by_budget)
             if eng.split:     # ... and the largest split-plane activation (the [P, h8, w8, 2 x 328] lookup tile) below 2 GiB
                 chunk = min(chunk, max(1, ((1 << 31) - 1) // (n8 * 656 * 2)))
         if lanes > 1:
@@ -423,5 +479,9 @@ class RAFT_bi(nn.Module):
         ups = hip.fork_join(dev, [(lambda a=a, b_=b_, c_=c_: eng.refine(a, b_, c_[0] if len(c_) == 1 else tuple(c_), iters))
                                   for a, b_, c_ in parts], streams)
         up = torch.cat(ups, 0).to(gt_local_frames.dtype)
+        # finite-flow guard (device flag, no host sync here: graph-capturable; callers check it after their own synchronisation with
+        # assert_finite_flows).  A split-plane value beyond fp16's range (|v| > 65504) puts inf into its hi plane and the flows go NaN.
+        self._flows_finite = torch.isfinite(up.sum())
+        self._flows_precision = prec
         half = P // 2
         return up[:half].view(b, l_t - 1, 2, h, w), up[half:].view(b, l_t - 1, 2, h, w)

@@ -148,8 +148,10 @@ class Compositor:
         numpy array, truncation to uint8: inference_propainter.py:437-438,443) -- so the bytes equal the reference's
         for identical predictions in either precision (tests/test_host_logic_cpu.py::test_compositor_*)."""
         if pred_img.is_cuda:      # one launch per window (pp_composite_window: same roundings, same bytes) instead of ~8 per frame
-            flags = [self.done[idx] for idx in neighbor_ids]
-            hip.composite_window(pred_img.contiguous(), self.bin, self.ori, self.comp, neighbor_ids, flags)
+            pred = pred_img.contiguous()
+            for s0 in range(0, len(neighbor_ids), 32):      # the kernel takes <= 32 frames per launch (--neighbor_length >= 32: groups)
+                ids = list(neighbor_ids[s0:s0 + 32])
+                hip.composite_window(pred[s0:s0 + 32], self.bin, self.ori, self.comp, ids, [self.done[idx] for idx in ids])
             for idx in neighbor_ids:
                 self.done[idx] = True
             return

@@ -233,6 +233,26 @@ def _corr_lookup_otf(f1, f2_levels, coords, out):
     return out
 
 
+def _corr_lookup_otf_split(f1, f2_levels, coords, out):
+    """split-plane features -> split-plane lookup tile with 88 channels per level and plane (81 taps + 7 zeros)"""
+    P, h, w, _ = f1.shape
+    LV = hip.OTF_SPLIT_LEVEL_CHANNELS
+    a = merge_planes(f1).reshape(P, h * w, 256)
+    pyr = []
+    for f2 in f2_levels:
+        hl, wl = f2.shape[1], f2.shape[2]
+        vol = torch.matmul(a, merge_planes(f2).reshape(P, hl * wl, 256).transpose(1, 2)) / 16.0
+        pyr.append(vol.reshape(P * h * w, 1, hl, wl))
+    ref = O.corr_lookup(pyr, coords.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)       # [P,h,w,324]
+    out.zero_()
+    for l in range(4):
+        v = ref[..., l * 81:(l + 1) * 81]
+        hi = v.half()
+        out[..., l * LV:l * LV + 81] = hi
+        out[..., 4 * LV + l * LV:4 * LV + l * LV + 81] = (v - hi.float()).half()
+    return out
+
+
 def _convex_upsample(flow, mask):
     return O.convex_upsample(flow.permute(0, 3, 1, 2), mask[..., :576].permute(0, 3, 1, 2).float())
 
@@ -350,7 +370,7 @@ def emulated_device_ops():
     patches = {
         "flow_warp": _flow_warp, "fb_check": _fb_check, "img_prop_step": _img_prop_step, "corr_avgpool": _corr_avgpool,
         "corr_lookup": _corr_lookup, "corr_feature_pyramid": _corr_feature_pyramid, "corr_lookup_otf": _corr_lookup_otf,
-        "corr_feature_pyramid_split": _corr_feature_pyramid_split,
+        "corr_feature_pyramid_split": _corr_feature_pyramid_split, "corr_lookup_otf_split": _corr_lookup_otf_split,
         "convex_upsample": _convex_upsample, "window_mask": _window_mask, "raft_flow_taps": _raft_flow_taps,
         "sparse_window_attention": _attention, "fold_tokens": _fold_tokens, "layernorm": _layernorm,
         "depthwise_pool": _depthwise_pool, "instance_norm": _instance_norm, "upsample2x": _upsample2x,

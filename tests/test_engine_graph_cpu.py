@@ -137,7 +137,8 @@ def test_raft_split_plane_engine_graph(models):
         raft.precision = "f16x3"
         try:
             eng = raft._get_engine("f16x3", torch.device("cpu"))
-            assert eng.split and not eng.corr_otf
+            assert eng.split and eng.corr_otf                                     # round 4: volume-free correlation at fp32-class precision
+            assert eng.convc1_otf.tri and eng.convc1_otf.kchunks == 11 * 8 and (eng.convc1_otf.ktable_uniform & 8)   # 1x1 over 4 x 88 channels: 11 FULL blocks
             assert eng.convc2.tri and eng.convc2.kchunks == 2 * 9 * 32           # halo-tile layer: tri-product format (both planes per K block)
             assert eng.convc1.tri and eng.convc1.kchunks == 11 * 8 and eng.convc1.ktable_uniform == 0   # 1x1 over 328 channels: 10 full blocks + a ragged one
             assert eng.convf1.split and not eng.convf1.tri and eng.convf1.kchunks == 48            # 7x1 over 16 channels: blocks walked three times (7 x 2 x 3 -> 48)

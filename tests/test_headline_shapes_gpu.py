@@ -23,6 +23,10 @@ pytestmark = pytest.mark.gpu
 # 1080p).  fp16: the stated fp16 tolerance = twice the largest value measured for the stage (flow completion 1.7e-3 / 1.9e-3, generator
 # 8.6e-3 / 9.4e-3 at 720p / 1080p); every run prints its own values (HEADLINE_PARITY lines; profiles/r3_parity_headline_shapes.txt)
 RTOL = {torch.float32: {"fc": 1e-3, "gen": 1e-3}, torch.float16: {"fc": 4e-3, "gen": 2e-2}}
+# the window shape the BENCH times (bench.py, BASELINE config 3: 720x1280x80, neighbor_length 10, ref_stride 10): 11 local frames + the
+# reference frames outside them = 17-18 frames per window (inference_propainter.py:159-173,410-426) -> T_ind phases of 9 key frames,
+# ~5 400 keys per masked window and head (sparse_transformer.py:227-256): ~85 key tiles through the online softmax.
+TIMED_WINDOW = dict(tt=18, lt=11)
 
 
 @pytest.fixture(scope="module")
@@ -69,11 +73,10 @@ def _fc_case(sds, H, W):
     return _cache[key]
 
 
-def _gen_case(sds, H, W):
-    key = ("gen", H, W)
+def _gen_case(sds, H, W, tt=8, lt=5):
+    key = ("gen", H, W, tt, lt)
     if key not in _cache:
-        gq = torch.Generator().manual_seed(2000 + H)
-        tt, lt = 8, 5
+        gq = torch.Generator().manual_seed(2000 + H + 100 * tt)
         fr = torch.rand(1, tt, 3, H, W, generator=gq) * 2 - 1
         mk = _mask(tt, H, W)                                         # 0.5 x 0.6 of the frame: > 25 % of the 5 x 9-token windows
         mu = _mask(tt, H, W, (0.3, 0.7), (0.27, 0.73))               # what image propagation could not fill
@@ -126,3 +129,53 @@ def test_flow_completion_chunk_1080p_vs_oracle(models, sds):
     torch.cuda.synchronize()
     rel_check("fc1080_f16_fwd", pf, ref[0], RTOL[torch.float16]["fc"])
     rel_check("fc1080_f16_bwd", pb, ref[1], RTOL[torch.float16]["fc"])
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16], ids=["f32", "f16"])
+def test_generator_window_720p_timed_shape_vs_oracle(models, sds, dt):
+    """Stage D on the window shape the headline bench times: 720x1280, t = 18 frames of which 11 local.
+    What only this length exercises: 9-entry T_ind phases, ~5 400 keys per masked window and head through the flash kernel's online
+    softmax (t = 8: 2 400), 10 forward + 10 backward deformable propagation steps.  The oracle needs ~2-3 min on the box's host cores
+    (once for both precisions)."""
+    fr, mk, mu, gfl, lt, ref = _gen_case(sds, 720, 1280, **TIMED_WINDOW)
+    assert fr.shape[1] == 18 and lt == 11
+    out = models[2]((fr * (1 - mk)).cuda().to(dt), (gfl[0].cuda().to(dt), gfl[1].cuda().to(dt)), mk.cuda().to(dt), mu.cuda().to(dt), lt)
+    torch.cuda.synchronize()
+    assert out.shape == ref.shape == (1, lt, 3, 720, 1280)
+    rel_check(f"gen720_t18_{'f32' if dt == torch.float32 else 'f16'}", out, ref, RTOL[dt]["gen"])
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16], ids=["f32", "f16"])
+def test_image_propagation_720p_vs_oracle(models, dt):
+    """Stage C (model/propainter.py:104-190,315-317) at 720x1280 over 11 frames (one window's local frames would do; the pass runs it per
+    sub-video): nearest-neighbour warps with forward-backward validity, both directions.  The warp is DISCONTINUOUS in its coordinates
+    (round-half-even of x + flow; the validity test |f + b(warped)|^2 < 0.01 (|f|^2 + |b|^2) + 0.5 is a threshold), so the check is a mismatch
+    FRACTION: fp32 engine vs the fp32 oracle -- isolated 1-ulp coordinate flips only; fp16 engine (fp16 frames / flows / masks as the
+    reference's --fp16 pass hands them over, coordinates in fp32) vs the oracle ON THE fp16-ROUNDED INPUTS, so that input rounding is
+    not counted as an engine error."""
+    g = torch.Generator().manual_seed(77)
+    t, H, W = 11, 720, 1280
+    fr = torch.rand(1, t, 3, H, W, generator=g) * 2 - 1
+    mk = _mask(t, H, W, (0.35, 0.65), (0.4, 0.6))                    # 6 % of the frame
+    # camera-like motion: a translation of ~12 px per pair + a smooth 2 px field; the backward flow is its negative + 1.2 px of noise,
+    # which puts a good share of the pixels near the validity threshold
+    c = torch.randn(t - 1, 2, 1, 1, generator=g) * 12
+    coarse = torch.randn(t - 1, 2, H // 80, W // 80, generator=g) * 2
+    ff = (c + torch.nn.functional.interpolate(coarse, size=(H, W), mode="bilinear", align_corners=False))[None]
+    fb = -ff + torch.randn(1, t - 1, 2, H, W, generator=g) * 1.2
+    if dt == torch.float16:
+        fr, ff, fb = fr.half().float(), ff.half().float(), fb.half().float()
+    with torch.no_grad():
+        ri, rm = O.image_propagation(fr * (1 - mk), ff, fb, mk)
+    pi, pm = models[2].img_propagation((fr * (1 - mk)).cuda().to(dt), (ff.cuda().to(dt), fb.cuda().to(dt)), mk.cuda().to(dt), "nearest")
+    torch.cuda.synchronize()
+    assert pi.shape == ri.shape == (1, t, 3, H, W) and pm.shape == rm.shape
+    filled = ((rm != mk).float().mean() / mk.mean()).item()
+    mism_m = (pm.float().cpu() != rm).float().mean().item()
+    d = (pi.float().cpu() - ri).abs()
+    mism_p = (d > (1e-6 if dt == torch.float32 else 1e-3)).float().mean().item()
+    print(f"HEADLINE_PARITY imgprop720_{'f32' if dt == torch.float32 else 'f16'}: mask mismatch {mism_m:.2e}, pixel mismatch {mism_p:.2e} "
+          f"(share of the hole filled by propagation: {filled:.3f})")
+    assert filled > 0.15, "the case must actually propagate"
+    lim = 2e-4 if dt == torch.float32 else 2e-3
+    assert mism_m < lim and mism_p < lim, (mism_m, mism_p)

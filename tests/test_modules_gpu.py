@@ -31,6 +31,9 @@ def sds():
     return seeded_sds()
 
 
+_oracle_cache = {}
+
+
 def check(name, got, ref, rtol, atol=0.0):
     got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
     assert got.shape == ref.shape, (name, got.shape, ref.shape)
@@ -95,7 +98,9 @@ def test_generator_matches_reference_golden(models, dt):
     check("generator", out, torch.from_numpy(g["out"]), 1e-3 if dt == torch.float32 else FP16_RTOL["gen"])
 
 
-def test_image_propagation_is_bit_exact_fp32(models):
+def test_image_propagation_matches_reference_golden_fp32(models):
+    """Stage C vs the REAL reference's golden at 64x96.  Not a bit-exactness claim: the nearest warp and the validity threshold are
+    discontinuous, so isolated coordinate flips are tolerated as a mismatch fraction (720x1280: tests/test_headline_shapes_gpu.py)."""
     gen = models[2]
     g = load_golden("gen_64x96.npz")
     fr, mk = torch.from_numpy(g["frames"]).cuda(), torch.from_numpy(g["masks_in"]).cuda()
@@ -568,9 +573,16 @@ def test_proinpainter_api_matches_the_oracle_driver(sds):
     assert p16 > 64.2, p16              # measured 67.19
 
 
-def test_evaluation_protocol_vs_oracle(models, sds):
+# measured on MI355X: fp32 stages 91.42 dB; floors 3 dB under the measurement
+EVAL_PSNR_FLOOR = {False: 88.4, True: 64.0}
+
+
+@pytest.mark.parametrize("fp16", [False, True], ids=["f32", "f16"])
+def test_evaluation_protocol_vs_oracle(models, sds, fp16):
     """scripts/evaluate_propainter.py protocol (:103-178,265): neighbor_length = 20 (stride 10), ref_stride = 10, NO
-    sub-video chunking (subvideo_length >= clip), all reference frames -- on a 24-frame 128x192 clip vs the oracle."""
+    sub-video chunking (subvideo_length >= clip), all reference frames -- on a 24-frame 128x192 clip vs the oracle.  The fp16
+    parametrisation (the precision the headline is timed at) runs generator windows of up to 21 local + reference frames:
+    11-entry T_ind phases through the flash-attention kernel's online softmax."""
     from propainter_amd.pipeline import InferenceConfig, run_clip
     from propainter_amd.synthetic import synthetic_clip, synthetic_mask
     import scipy.ndimage
@@ -578,12 +590,20 @@ def test_evaluation_protocol_vs_oracle(models, sds):
     clip = synthetic_clip(L, H, W, seed=21)
     m = scipy.ndimage.binary_dilation(synthetic_mask(H, W), iterations=4).astype(np.uint8) * 255
     masks = np.repeat(m[None], L, 0)
-    cfg = InferenceConfig(raft_iter=4, subvideo_length=10 ** 6, neighbor_length=20, ref_stride=10, fp16=False)
-    comp = run_clip(models, clip, masks, masks, cfg, torch.device("cuda")).cpu().numpy()
-    ref = O.inpaint_video(sds, clip, masks, masks, raft_iter=4, subvideo_length=10 ** 6, neighbor_length=20, ref_stride=10)
-    psnr = O.psnr(comp, np.stack(ref))
-    print(f"EVAL_PROTOCOL_PARITY psnr={psnr:.2f}")
-    assert psnr > 88.4, psnr              # measured 91.42
+    cfg = InferenceConfig(raft_iter=4, subvideo_length=10 ** 6, neighbor_length=20, ref_stride=10, fp16=fp16)
+    models[0].precision = "f16x3" if fp16 else None        # the timed configuration: fp16 stages + fp32-class RAFT
+    try:
+        comp = run_clip(models, clip, masks, masks, cfg, torch.device("cuda")).cpu().numpy()
+    finally:
+        models[0].precision = None
+    key = ("eval_ref",)
+    if key not in _oracle_cache:
+        _oracle_cache[key] = np.stack(O.inpaint_video(sds, clip, masks, masks, raft_iter=4, subvideo_length=10 ** 6, neighbor_length=20, ref_stride=10))
+    ref = _oracle_cache[key]
+    psnr = O.psnr(comp, ref)
+    dmax = int(np.abs(comp.astype(np.int16) - ref.astype(np.int16)).max())
+    print(f"EVAL_PROTOCOL_PARITY[{'f16' if fp16 else 'f32'}] psnr={psnr:.2f} max|d|={dmax} byte(s)")
+    assert psnr > EVAL_PSNR_FLOOR[fp16], psnr
 
 
 def test_outpainting_end_to_end_vs_oracle(models, sds):

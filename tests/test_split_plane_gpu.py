@@ -299,3 +299,174 @@ def test_streaming_head_kernel(dev, cin, cout, act, out_f32, split):
     assert out.shape[-1] == pad8(cout) and (out[..., cout:] == 0).all()
     check(f"head_{cin}_{cout}", out[..., :cout].permute(0, 3, 1, 2), ref, tol)
     check(f"head_vs_mfma_{cin}_{cout}", out[..., :cout].permute(0, 3, 1, 2), base[..., :cout].permute(0, 3, 1, 2), tol)
+
+
+# ---- range stress: the planes' quantisation INCLUDED in the reference -------------------------------
+# A split-plane value is hi = fp16(v), lo = fp16(v - hi).  While lo is a NORMAL fp16 number (|v| >= 2^-3) the pair carries 22
+# significand bits; below that lo falls into fp16's subnormal range (quantum 2^-24) and the pair has an ABSOLUTE resolution of
+# 2^-25; |v| > 65504 overflows the hi plane to inf (the documented failure: non-finite output, caught by RAFT_bi's finite-flow
+# guard).  Error model per operand: |dv| <= 2^-22 |v| + 2^-25.  A product drops lo*lo (<= 2^-22 |x||w|) and the K-term sum is
+# accumulated in fp32.  BOUND below is that model summed over the taps -- elementwise, against fp64 on the TRUE fp32 inputs and
+# weights (not on the values the planes happen to represent, as the tests above do).
+def _stress_values(shape, g, lo_exp, hi_exp):
+    """sign * 10^U(lo_exp, hi_exp): log-uniform magnitudes."""
+    mag = torch.pow(10.0, torch.rand(shape, generator=g) * (hi_exp - lo_exp) + lo_exp)
+    return mag * (torch.randint(0, 2, shape, generator=g).float() * 2 - 1)
+
+
+STRESS_RANGES = {"wide": (-6.0, 4.3), "tiny": (-6.0, -3.0), "huge": (3.0, 4.78)}      # 10^4.78 = 60 256 < 65 504
+STRESS_LAYERS = [
+    dict(name="halo3x3_c128_tri", cin=[128], cout=128, k=(3, 3), pad=1),
+    dict(name="halo1x5_c256_two_src_tri", cin=[128, 128], cout=256, k=(1, 5), pad=(0, 2)),
+    dict(name="v2_1x1_c324_tri", cin=[324], cout=256, k=(1, 1), pad=0),
+    dict(name="v2_7x7s2_c3_plain", cin=[3], cout=64, k=(7, 7), stride=2, pad=3),
+    dict(name="v2_3x3_c128_plain", cin=[128], cout=128, k=(3, 3), pad=1, tri=False),
+]
+
+
+@pytest.mark.parametrize("rng", sorted(STRESS_RANGES))
+@pytest.mark.parametrize("case", STRESS_LAYERS, ids=[c["name"] for c in STRESS_LAYERS])
+def test_split_plane_range_stress(dev, case, rng):
+    from propainter_amd.conv import ConvLayer, pad8
+    g = torch.Generator().manual_seed(101)
+    N, H, W = 1, 24, 40
+    cin, cout, k = case["cin"], case["cout"], case["k"]
+    stride, pad = case.get("stride", 1), case["pad"]
+    xs = [_stress_values((N, c, H, W), g, *STRESS_RANGES[rng]) for c in cin]
+    K = sum(cin) * k[0] * k[1]
+    # weights log-uniform over three decades around 1/sqrt(K): small enough that lo planes of most weights are subnormal
+    w = _stress_values((cout, sum(cin), *k), g, -2.5, 0.0) / math.sqrt(K)
+    b = torch.randn(cout, generator=g) * 0.3
+    srcs = [split_planes(x.permute(0, 2, 3, 1).contiguous(), pad8(c)).cuda() for x, c in zip(xs, cin)]
+    layer = ConvLayer(w, b, stride=stride, padding=pad, src_channels=cin, dtype=torch.float16, device=dev, split=True, tri=case.get("tri"))
+    out = layer(srcs, out_dtype=torch.float32)             # plain fp32 output: the huge range must not overflow an OUTPUT plane
+    torch.cuda.synchronize()
+    got = out[..., :cout].permute(0, 3, 1, 2).double().cpu()
+    x64, w64 = torch.cat(xs, 1).double(), w.double()
+    ref = F.conv2d(x64, w64, b.double(), stride, pad)
+    e22, e25, e24 = 2.0 ** -22, 2.0 ** -25, 2.0 ** -24
+    ax, aw = x64.abs(), w64.abs()
+    bound = (F.conv2d(ax * e22 + e25, aw, None, stride, pad) + F.conv2d(ax, aw * e22 + e25, None, stride, pad)
+             + e22 * F.conv2d(ax, aw, None, stride, pad) + 2 * e24 * math.sqrt(K) * F.conv2d(ax, aw, None, stride, pad))
+    err = (got - ref).abs()
+    assert torch.isfinite(got).all()
+    ratio = (err / bound).max().item()
+    rel_rng = err.max().item() / ref.abs().max().item()
+    print(f"SPLIT_RANGE_STRESS {case['name']} [{rng}]: max err/bound {ratio:.3f}, max|d| {err.max().item():.3e} = {rel_rng:.2e} of the output range "
+          f"(|x| in 1e{STRESS_RANGES[rng][0]:+.1f}..1e{STRESS_RANGES[rng][1]:+.1f})")
+    assert ratio <= 1.0, (ratio, rel_rng)
+    # the fp32-class claim in the units the other tests use: <= 3e-6 of the output range whenever the INPUT planes are normal numbers
+    if rng != "tiny":
+        assert rel_rng <= 3e-6, rel_rng
+
+
+def test_split_plane_overflow_is_loud(dev):
+    """|v| > 65504 cannot be represented: the hi plane is inf, every output that touches it is non-finite (never a silently wrong
+    finite number), and RAFT_bi's finite-flow guard (flow_comp_raft.py) turns that into an error naming precision='f32'."""
+    from propainter_amd.conv import ConvLayer
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 64, 16, 24, generator=g)
+    x[0, 3, 8, 12] = 7.0e4
+    w = torch.randn(64, 64, 3, 3, generator=g) / 24
+    layer = ConvLayer(w, None, padding=1, src_channels=[64], dtype=torch.float16, device=dev, split=True)
+    out = layer([split_planes(x.permute(0, 2, 3, 1).contiguous()).cuda()], out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    bad = ~torch.isfinite(out[0, :, :, :64]).all(-1).cpu()
+    assert bad[7:10, 11:14].all() and bad.sum() == 9, "exactly the 3x3 neighbourhood of the overflowing pixel is non-finite"
+    from propainter_amd.model.modules.flow_comp_raft import RAFT_bi, assert_finite_flows
+    raft = seeded_raft = None
+    from tests.helpers import seeded_models
+    raft = seeded_models("cuda")[0]
+    raft.precision = "f16x3"
+    fr = torch.rand(1, 2, 3, 128, 192) * 2 - 1
+    fr[0, 0, 0, 50, 60] = 1e9                       # far outside [-1, 1]: the encoder's first split-plane activation overflows
+    raft(fr.cuda(), iters=2)
+    with pytest.raises(FloatingPointError, match="f32"):
+        assert_finite_flows(raft)
+    raft(torch.rand(1, 2, 3, 128, 192).cuda() * 2 - 1, iters=2)
+    assert_finite_flows(raft)                        # a clean pass clears the flag
+
+
+@pytest.mark.parametrize("case", ["smooth", "ragged_oob", "divergent", "chaotic"])
+def test_split_plane_corr_lookup_on_the_fly(dev, case):
+    """pp_corr_lookup_otf_split (no all-pairs volume, fp32-class: RAFT/corr.py:13-60) against (i) fp64 volume -> avg-pool pyramid ->
+    bilinear lookup on the values the feature planes represent and (ii) the volume path of the same engine (batched tri-product GEMMs +
+    pp_corr_lookup), whose blend arithmetic it repeats.  Cases as in tests/test_ops_gpu.py: smooth flow (one shared box per 8x8 tile),
+    ragged map + coordinates far outside / on exact integers, a flow diverging inside tiles (quadrant fallback), per-pixel random targets
+    (single-pixel fallback).  Output layout: 88 channels per level and plane (81 taps + 7 zeros)."""
+    from propainter_amd import hip
+    from propainter_amd.conv import batched_gemm_nt_split
+    g = torch.Generator().manual_seed({"smooth": 1, "ragged_oob": 2, "divergent": 3, "chaotic": 4}[case])
+    P, h, w = (2, 24, 40) if case != "ragged_oob" else (2, 19, 29)
+    f1 = split_planes(torch.randn(P, h, w, 256, generator=g) * 2).cuda()
+    f2 = split_planes(torch.randn(P, h, w, 256, generator=g) * 2).cuda()
+    base = O.coords_grid(P, h, w)
+    if case == "smooth":
+        coords = base + torch.tensor([1.7, -2.3]).view(1, 2, 1, 1) + 0.3 * torch.randn(P, 2, h, w, generator=g)
+    elif case == "ragged_oob":
+        coords = base + torch.randn(P, 2, h, w, generator=g) * 1.5
+        coords[0, :, 0, 0] = torch.tensor([-30.3, 2.2]); coords[0, :, 0, 1] = torch.tensor([300.0, 20.5])
+        coords[0, :, 1, :] = base[0, :, 1, :] + 3.0                      # exact integers: 1-ulp round-trip effects
+        coords[1, :, 5, 5] = torch.tensor([-4.0, -4.0]); coords[1, :, 6, 6] = torch.tensor([w + 3.5, h + 3.5])
+        coords[1, :, 7, 7] = torch.tensor([-5.5, 3.0])
+    elif case == "divergent":
+        coords = base * 1.6 - 4.0 + torch.randn(P, 2, h, w, generator=g)
+    else:
+        coords = torch.rand(P, 2, h, w, generator=g) * torch.tensor([w * 1.2, h * 1.2]).view(1, 2, 1, 1) - 2.0
+    cd = coords.permute(0, 2, 3, 1).contiguous().cuda()
+    lv = [f2] + hip.corr_feature_pyramid_split(f2)
+    LV = hip.OTF_SPLIT_LEVEL_CHANNELS
+    out = torch.full((P, h, w, 8 * LV), 7.0, dtype=torch.float16, device=dev)
+    hip.corr_lookup_otf_split(f1, lv, cd, out)
+    again = torch.empty_like(out)
+    hip.corr_lookup_otf_split(f1, lv, cd, again)
+    torch.cuda.synchronize()
+    assert torch.equal(out, again), "the on-the-fly lookup is not run-to-run deterministic"
+    pl = out.view(P, h, w, 2, 4, LV)
+    assert (pl[..., 81:] == 0).all(), "pad channels of every level group must be zero"
+    got = (pl[..., :81].float().sum(3)).reshape(P, h, w, 324)            # hi + lo, channel l*81 + a*9 + b
+    # (i) fp64 on the represented values (the fp32 oracle's lookup on fp64 tensors: its coordinate arithmetic then runs in fp64 -- the
+    #     per-tap fp32 round trip is what (ii) checks)
+    f1v = merge_planes(f1.cpu()).double().permute(0, 3, 1, 2)
+    f2v = merge_planes(f2.cpu()).double().permute(0, 3, 1, 2)
+    ref = O.corr_lookup(O.corr_pyramid(f1v, f2v), coords.double())
+    check(f"otf_split_vs_fp64[{case}]", got.permute(0, 3, 1, 2), ref, 2e-5)    # coordinate rounding (fp32 vs fp64 taps) dominates: ~1e-6 px x gradient
+    # (ii) the volume path of the same engine: same products (tri-product, fp32 accumulation in a different order), same blend arithmetic
+    n8 = h * w
+    gemm = lambda b_: batched_gemm_nt_split(f1.view(P, n8, 512), b_.view(P, -1, 512), out_scale=1.0 / 16.0)
+    levels = [gemm(t).view(P * n8, t.shape[1], t.shape[2]) for t in lv]
+    vol = hip.corr_lookup(levels, cd, torch.empty((P, h, w, 656), dtype=torch.float16, device=dev), split=True)
+    torch.cuda.synchronize()
+    check(f"otf_split_vs_volume[{case}]", got, merge_planes(vol, 0, 324), 2e-6)
+    # batch invariance: pair 1 alone gives the same bytes as inside the batch of 2
+    solo = torch.empty((1, h, w, 8 * LV), dtype=torch.float16, device=dev)
+    hip.corr_lookup_otf_split(f1[1:].contiguous(), [t[1:].contiguous() for t in lv], cd[1:].contiguous(), solo)
+    torch.cuda.synchronize()
+    assert torch.equal(solo[0], out[1])
+
+
+def test_split_plane_raft_volume_free_matches_the_volume_engine():
+    """RAFT_bi(precision="f16x3") with the volume-free correlation (default) against the same engine on the fp32 all-pairs volume
+    (PP_RAFT_SPLIT_VOLUME=1: the reference's own call pattern, RAFT/corr.py:13-60) at 128x192, 6 iterations: same flows to fp32-class
+    end-point error."""
+    import os
+    from tests.helpers import load_golden, seeded_models
+    g = load_golden("raft_128x192.npz")
+    fr = (torch.from_numpy(g["frames_u8"]).permute(0, 3, 1, 2).float().div(255)[None] * 2 - 1).cuda()
+    flows = {}
+    for vol in ("0", "1"):
+        os.environ["PP_RAFT_SPLIT_VOLUME"] = vol
+        try:
+            raft = seeded_models("cuda", raft_precision="f16x3")[0]
+            eng = raft._get_engine("f16x3", fr.device)
+            assert eng.corr_otf == (vol == "0")
+            flows[vol] = raft(fr, iters=int(g["iters"]))
+        finally:
+            os.environ.pop("PP_RAFT_SPLIT_VOLUME", None)
+    torch.cuda.synchronize()
+    for d in (0, 1):
+        e = (flows["0"][d] - flows["1"][d]).pow(2).sum(2).sqrt()
+        print(f"SPLIT_PARITY raft otf vs volume dir {d}: EPE mean {e.mean():.2e} max {e.max():.2e}")
+        assert e.mean() < 2e-5 and e.max() < 1e-3
+    ef = (flows["0"][0][0].cpu() - torch.from_numpy(g["flows_f"])).pow(2).sum(1).sqrt()
+    assert ef.mean() < 5e-5 and ef.max() < 2e-3, (ef.mean(), ef.max())
