@@ -95,6 +95,11 @@ template <typename T> __device__ __forceinline__ void store8(T* p, const float* 
   }
 }
 
+// ReLU of the split-plane ("f16x3") producers.  fmaxf(NaN, 0) = 0 would ERASE the trace of a value that left fp16's range (hi plane inf,
+// lo plane NaN: the pair reads back as NaN): this form propagates NaN (and turns -inf, which only an overflow produces, into NaN), so an
+// overflow anywhere in the split-plane engine reaches the flows as NaN and RAFT_bi's finite-flow guard reports it.
+__device__ __forceinline__ float relu_split(float v) { return v > 0.f ? v : v * 0.f; }
+
 // Split-plane ("f16x3") store: hi = fp16(v), lo = fp16(v - hi); hi + lo carries 22 significand bits of v (|v| < 65504).
 __device__ __forceinline__ void store8_split(_Float16* hi_p, _Float16* lo_p, const float* v) {
   u32x4 rh, rl;

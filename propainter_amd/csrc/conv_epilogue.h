@@ -95,7 +95,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc_)
 #pragma unroll
       for (int b = 0; b < TM; ++b)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc_[A0 + a][b][r] = fmaxf(acc_[A0 + a][b][r], 0.f);
+        for (int r = 0; r < 4; ++r) acc_[A0 + a][b][r] = SPLIT ? relu_split(acc_[A0 + a][b][r]) : fmaxf(acc_[A0 + a][b][r], 0.f);
   }
   if (stage16) {
     // ---- fp16 staging: row stride WN*2 + 16 bytes
@@ -271,7 +271,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc_)
         }
         if (!has_res && relu2) {
 #pragma unroll
-          for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
+          for (int r = 0; r < 8; ++r) v[r] = SPLIT ? relu_split(v[r]) : fmaxf(v[r], 0.f);
         }
       }
       if (has_res) {
@@ -288,7 +288,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc_)
         }
         if (relu2) {
 #pragma unroll
-          for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
+          for (int r = 0; r < 8; ++r) v[r] = SPLIT ? relu_split(v[r]) : fmaxf(v[r], 0.f);
         }
       }
       const long long oidx = m * p.out_cstride + out_cbase + co;

@@ -23,6 +23,7 @@
 // 4x4 quadrants one after another, and single pixels in the worst case -- slower, never wrong.  The blend order is
 // fixed, nothing is accumulated with atomics: results are deterministic and independent of the batch.
 #include "common.h"
+#include <stdlib.h>
 
 namespace pp {
 
@@ -33,6 +34,7 @@ struct CorrOtfParams {
   _Float16* out;             // fp16 NHWC [P, h, w, ocs]; channels [0, 324) written, [324, ocpad) zeroed
   int P, h, w, ocs, ocpad, tiles_x, tiles_y;
   float scale;               // 1 / sqrt(256)
+  int dbg;                   // [PP_OTF_DBG, tuning only: selects the instrumented instantiation] 1 no blend, 2 no MFMA, 4 no B loads, 8 no write-out, 16 stamps
 };
 
 constexpr int OTF_VTOT = 28928;                    // floats of V storage (113 KB): 64 x 452, 16 x 1808, 1 x 28928
@@ -287,33 +289,57 @@ __global__ __launch_bounds__(512) void corr_otf_kernel(const CorrOtfParams p) {
 // Replaces, for the fp32-class engine, the fp32 all-pairs volume (829 MB per pair-direction at 720x1280, 5.6 GB at 1080x1920), its four
 // GEMMs and the 40-byte row gathers of pp_corr_lookup (RAFT/corr.py:13-60).
 //
-// Differences from the fp16 kernel above, all forced by the doubled operand size:
-//   * A (the f1 tile) is 64 px x 1 KB: it no longer fits ONE wave's registers next to the B fragments, so the 8 waves form two groups of
-//     four -- group g owns M tiles 2g, 2g + 1 (32 pixels: 128 VGPRs of hi + lo fragments) and walks the box's N tiles round-robin over
-//     its four waves; both groups stream every B tile (L2 -> registers; the kernel is latency-, not bandwidth-bound);
-//   * B arrives in K halves (4 hi + 4 lo 16-byte loads per lane), two half buffers in flight alternately: the loads of half k + 1 are
-//     issued before the MFMAs of half k;
+// Shape of the kernel, and why it differs from the fp16 one above (measured on MI355X, tools/bench_otf.py + PP_OTF_DBG ablations,
+// profiles/r4_corr_otf_split.txt): a first version kept the 8 x 8 tile / 512-thread block (A = 64 px x 1 KB no longer fits one wave's
+// registers, so two groups of four waves each owned 32 pixels and BOTH streamed every B tile) and ran 65 us per block of which the
+// phases -- prologue + V stores 19, B loads 21, blend 18, write-out 3 -- simply added up: one block per CU, every phase behind a
+// block barrier, nothing to overlap with.  So:
+//   * a block is a 4 x 8 pixel tile and 256 threads: all four waves hold the SAME A fragments (2 M tiles x 8 K steps, hi + lo: 128
+//     VGPRs) and share the box's N tiles round-robin -- every B tile is loaded once per block -- and TWO blocks live on a CU
+//     (54 KB of LDS each, 2 waves per SIMD at <= 256 registers): one block's loads and barriers hide behind the other's blend;
+//   * B arrives in K halves (4 hi + 4 lo 16-byte loads per lane), two half buffers in flight alternately: the loads of half k + 1
+//     are issued before the MFMAs of half k;
+//   * the blend reads per-(pixel, tap column) / per-(pixel, tap row) tables {cell index, fraction} built once per level (18 grid
+//     round trips per pixel instead of 162: the round trip of tap (a, b) depends on a for x and on b for y only) -- the same values,
+//     so the arithmetic of every output is still pp_corr_lookup's;
 //   * output channels are laid out PER LEVEL in 88-channel groups (81 taps + 7 zeros: 176 bytes = 11 16-byte chunks per plane), so a
-//     level's results leave LDS right after its blend (22.5 KB staging instead of 90 KB for whole rows: V keeps its 113 KB) and the 1x1
-//     convolution behind it (convc1) walks 11 full 32-channel blocks per plane (328 channels: 10 full + 1 ragged).  Its weight columns
-//     are permuted accordingly by the engine (flow_comp_raft.py).
+//     level's results leave LDS right after its blend (11 KB staging instead of whole rows) and the 1x1 convolution behind it
+//     (convc1) walks 11 full 32-channel blocks per plane (328 channels: 10 full + 1 ragged).  Its weight columns are permuted
+//     accordingly by the engine (flow_comp_raft.py).
 //   out: fp16 [P, h, w, ocs], hi plane at channel 0, lo plane at ocs / 2; level l, tap (a, b) at channel l * 88 + a * 9 + b.
+// A box too large for the V tile falls back to the two 2 x 8 halves (one M tile each), then to single pixels -- slower, never wrong.
+// [tuning only, PP_OTF_DBG bit 16] cycle stamps of wave 0 summed over the blocks: {prologue, tables + loads + MFMA + V stores, barrier after
+// them, blend, barrier after it, write-out, whole block, blocks}
+__device__ unsigned long long g_otf_prof[8];
 constexpr int OTFS_LVC = 88;                        // channels per level group
-constexpr int OTFS_STAGE = 64 * 2 * OTFS_LVC * 2;   // bytes: [64 px][hi | lo][88]
-constexpr int OTFS_LDS = OTF_VTOT * 4 + OTFS_STAGE + 64 * 8 + 5 * 16;
+constexpr int OTFS_NPX = 32;                        // pixels per block: 4 rows x 8 columns
+constexpr int OTFS_VTOT = OTFS_NPX * 324;           // floats of V (41 KB): 32 x 324 (20 N tiles; 324 = 4 mod 32: conflict-free tile stores), 16 x 648, 1 x 10368
+constexpr int OTFS_STAGE = OTFS_NPX * 2 * OTFS_LVC * 2;   // bytes: [32 px][hi | lo][88]
+constexpr int OTFS_TAB = OTFS_NPX * 18 * 8;         // bytes: [32 px][9 a + 9 b] x {int cell, float fraction}
+constexpr int OTFS_LDS = OTFS_VTOT * 4 + OTFS_STAGE + OTFS_TAB + OTFS_NPX * 8 + 5 * 16;
 
-__global__ __launch_bounds__(512, 2) void corr_otf_split_kernel(const CorrOtfParams p) {
+template <bool PROF>
+__global__ __launch_bounds__(256, 2) void corr_otf_split_kernel(const CorrOtfParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   __shared__ __attribute__((aligned(16))) char lds[OTFS_LDS];
   float* const V = reinterpret_cast<float*>(lds);
-  _Float16* const stage = reinterpret_cast<_Float16*>(lds + OTF_VTOT * 4);
-  float* const cxy = reinterpret_cast<float*>(lds + OTF_VTOT * 4 + OTFS_STAGE);
-  int* const boxes = reinterpret_cast<int*>(lds + OTF_VTOT * 4 + OTFS_STAGE + 64 * 8);
+  _Float16* const stage = reinterpret_cast<_Float16*>(lds + OTFS_VTOT * 4);
+  int2* const tab = reinterpret_cast<int2*>(lds + OTFS_VTOT * 4 + OTFS_STAGE);                  // {cell (level coordinates), fraction bits}
+  float* const cxy = reinterpret_cast<float*>(lds + OTFS_VTOT * 4 + OTFS_STAGE + OTFS_TAB);     // [32][2]; x = NaN: pixel outside the image
+  int* const boxes = reinterpret_cast<int*>(lds + OTFS_VTOT * 4 + OTFS_STAGE + OTFS_TAB + OTFS_NPX * 8);   // [5][4]: levels 0..3 of the whole tile, [4] scratch
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave >> 2, wig = wave & 3;          // M group (pixels 32 grp .. 32 grp + 31), wave inside the group
   const int l15 = lane & 15, l4 = lane >> 4;
+  constexpr bool prof = PROF;
+  unsigned long long tprev = prof ? __builtin_amdgcn_s_memtime() : 0ull, tstart = tprev, tacc[6] = {0, 0, 0, 0, 0, 0};
+  auto stamp = [&](int slot) {
+    if (PROF && (p.dbg & 16)) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      tacc[slot] += t - tprev;
+      tprev = t;
+    }
+  };
 
   int bid = blockIdx.x;
   {
@@ -324,11 +350,8 @@ __global__ __launch_bounds__(512, 2) void corr_otf_split_kernel(const CorrOtfPar
   const int txi = bid % p.tiles_x;
   const int tyi = (bid / p.tiles_x) % p.tiles_y;
   const int n = bid / (p.tiles_x * p.tiles_y);
-  const int ty0 = tyi * 8, tx0 = txi * 8;
-  auto tile_xy = [&](int q, int& x, int& y) {
-    x = tx0 + ((q >> 4) & 1) * 4 + (q & 3);
-    y = ty0 + (q >> 5) * 4 + ((q >> 2) & 3);
-  };
+  const int ty0 = tyi * 4, tx0 = txi * 8;
+  // pixel q of the tile: row q >> 3, column q & 7 (M tile q >> 4 = rows 2m, 2m + 1)
   auto wave_box = [&](int lvl, int p0, int np, int* dst) {
     const int Hl = p.h >> lvl, Wl = p.w >> lvl;
     const float lscale = 1.f / (float)(1 << lvl);
@@ -350,40 +373,47 @@ __global__ __launch_bounds__(512, 2) void corr_otf_split_kernel(const CorrOtfPar
     }
   };
 
-  if (tid < 64) {
-    int x, y;
-    tile_xy(tid, x, y);
-    float cx = __builtin_nanf(""), cy = 0.f;
-    if (x < p.w && y < p.h) {
-      const float* c = p.coords + (((long long)n * p.h + y) * p.w + x) * 2;
-      cx = c[0];
-      cy = c[1];
-    }
-    cxy[tid * 2] = cx;
-    cxy[tid * 2 + 1] = cy;
-  }
-  // the 7 pad channels of every staging row stay zero for the whole block (the blend writes channels 0..80 only)
-  for (int i = tid; i < 128 * 7; i += 512) stage[(i / 7) * OTFS_LVC + 81 + (i % 7)] = (_Float16)0.f;
-  // ---- f1 tile (64 pixels x 1 KB: 32 hi chunks | 32 lo chunks) once per block through LDS (aliases V; chunk j of pixel q at j ^ (q & 31))
+  // ---- f1 tile (32 pixels x 1 KB: 32 hi chunks | 32 lo chunks) once per block through LDS (aliases V; chunk j of pixel q at j ^ (q & 31)).
+  //      Its loads are issued FIRST: they do not depend on the coordinates, whose own load latency would otherwise precede them
+  u32x4 f1raw[8];
   {
     const __amdgpu_buffer_rsrc_t r1 = uniform_buffer_rsrc(p.f1 + (long long)n * p.h * p.w * 1024, p.h * p.w * 1024);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int id = tid + 512 * i, q = id >> 6, j = id & 63;
-      int x, y;
-      tile_xy(q, x, y);
+      const int id = tid + 256 * i, q = id >> 6, j = id & 63;
+      const int x = tx0 + (q & 7), y = ty0 + (q >> 3);
       const int voff = (x < p.w && y < p.h) ? (y * p.w + x) * 1024 + j * 16 : (int)0x80000000;
-      const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(r1, voff, 0, 0);
-      *reinterpret_cast<u32x4*>(lds + q * 1024 + ((j ^ (q & 31)) << 4)) = raw;
+      f1raw[i] = __builtin_amdgcn_raw_buffer_load_b128(r1, voff, 0, 0);
     }
   }
+  {
+    const int q = tid & 31;
+    const int x = tx0 + (q & 7), y = ty0 + (q >> 3);
+    float cx = __builtin_nanf(""), cy = 0.f;
+    if (x < p.w && y < p.h) {
+      const float2 c = *reinterpret_cast<const float2*>(p.coords + (((long long)n * p.h + y) * p.w + x) * 2);
+      cx = c.x;
+      cy = c.y;
+    }
+    if (tid < OTFS_NPX) {
+      cxy[tid * 2] = cx;
+      cxy[tid * 2 + 1] = cy;
+    }
+  }
+  // the 7 pad channels of every staging row stay zero for the whole block (the blend writes channels 0..80 only)
+  for (int i = tid; i < OTFS_NPX * 2 * 7; i += 256) stage[(i / 7) * OTFS_LVC + 81 + (i % 7)] = (_Float16)0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int id = tid + 256 * i, q = id >> 6, j = id & 63;
+    *reinterpret_cast<u32x4*>(lds + q * 1024 + ((j ^ (q & 31)) << 4)) = f1raw[i];
+  }
   __syncthreads();
-  if (wave < 4) wave_box(wave, 0, 64, boxes + wave * 4);
-  // ---- A fragments of the group's two M tiles, both planes: resident for the whole block
+  wave_box(wave, 0, OTFS_NPX, boxes + wave * 4);           // wave l computes the whole-tile box of level l
+  // ---- A fragments of the two M tiles, both planes: resident for the whole block (the same in all four waves)
   f16x8 ahi[2][8], alo[2][8];
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
-    const int q = (grp * 2 + m) * 16 + l15;
+    const int q = m * 16 + l15;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
       ahi[m][ks] = *reinterpret_cast<const f16x8*>(lds + q * 1024 + (((ks * 4 + l4) ^ (q & 31)) << 4));
@@ -391,12 +421,13 @@ __global__ __launch_bounds__(512, 2) void corr_otf_split_kernel(const CorrOtfPar
     }
   }
   __syncthreads();
+  stamp(0);
 
-  // K half `half` (channels 128 half .. +127 of both planes) of N tile nt: 16 positions straight from L2
+  // K half `half` (channels 128 half .. +127 of both planes) of N tile nt: 16 positions straight from L2 (64-byte sectors used in full)
   auto load_half = [&](const __amdgpu_buffer_rsrc_t r2, int Wl, int bx0, int by0, int bw, int area, int nt, int half, u32x4 (&bh)[4], u32x4 (&bl)[4]) {
     const int pos = nt * 16 + l15;
     const int ry = pos / bw, rx = pos - ry * bw;
-    const int voff = pos < area ? ((by0 + ry) * Wl + bx0 + rx) * 1024 + l4 * 16 + half * 256 : (int)0x80000000;
+    const int voff = (pos < area && !(PROF && (p.dbg & 4))) ? ((by0 + ry) * Wl + bx0 + rx) * 1024 + l4 * 16 + half * 256 : (int)0x80000000;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       bh[k] = __builtin_amdgcn_raw_buffer_load_b128(r2, voff, k * 64, 0);
@@ -408,6 +439,7 @@ __global__ __launch_bounds__(512, 2) void corr_otf_split_kernel(const CorrOtfPar
     return uniform_buffer_rsrc(p.f2[lvl] + (long long)n * Hl * Wl * 1024, Hl * Wl * 1024);
   };
   auto tri = [&](f32x4& acc, const u32x4& bh, const u32x4& bl, const f16x8& ah, const f16x8& al) {
+    if (PROF && (p.dbg & 2)) { acc[0] += __builtin_bit_cast(float, bh[0] ^ bl[1]); return; }
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bl), ah, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bh), al, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bh), ah, acc, 0, 0, 0);
@@ -421,89 +453,109 @@ __global__ __launch_bounds__(512, 2) void corr_otf_split_kernel(const CorrOtfPar
     const float lscale = 1.f / (float)(1 << lvl);
     const __amdgpu_buffer_rsrc_t r2 = level_rsrc(lvl);
 
+    // -- per-level tap tables (pp_corr_lookup's per-tap arithmetic, evaluated once per (pixel, a) and (pixel, b)):
+    //    entry (q, a) = {floor(px), px - floor(px)}, px = roundtrip(cx + a - 4, Wl); entry (q, 9 + b) likewise along y
+    for (int i = tid; i < OTFS_NPX * 18; i += 256) {
+      const int q = i / 18, t = i - q * 18;
+      const bool isy = t >= 9;
+      const float c0 = cxy[q * 2 + (isy ? 1 : 0)];
+      const float pc = grid_roundtrip(c0 * lscale + (float)((isy ? t - 9 : t) - 4), isy ? Hl : Wl);
+      const float fl = floorf(pc);
+      // (a NaN / far-out coordinate: the cell is clamped into int range, every corner then fails the box test -> zeros, as outside the map)
+      const float flc = fminf(fmaxf(fl, -1.0e6f), 1.0e6f);
+      tab[i] = make_int2((pc == pc) ? (int)flc : -(1 << 20), __builtin_bit_cast(int, pc - fl));
+    }
+
     auto process = [&](const int p0, const int np, const int* bx) -> bool {
       const int bx0 = bx[0], by0 = bx[1], bw = bx[2], bh_ = bx[3];
       const int area = bw * bh_;
-      const int vstride = OTF_VTOT / np;
+      const int vstride = OTFS_VTOT / np;
       const int ntiles = (area + 15) >> 4;
       if (ntiles * 16 > vstride) return false;
       const int mt0 = p0 >> 4;                         // first M tile of the set
       const bool one_tile = np <= 16;
-      const bool mine = !one_tile || (mt0 >> 1) == grp;      // a single M tile belongs to one group: the other one idles
-      if (mine) {
-        if (!prefetched && wig < ntiles) load_half(r2, Wl, bx0, by0, bw, area, wig, 0, b0h, b0l);
-        for (int nt = wig; nt < ntiles; nt += 4) {
-          load_half(r2, Wl, bx0, by0, bw, area, nt, 1, b1h, b1l);
-          f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      if (!prefetched && wave < ntiles) load_half(r2, Wl, bx0, by0, bw, area, wave, 0, b0h, b0l);
+      prefetched = false;
+      for (int nt = wave; nt < ntiles; nt += 4) {
+        load_half(r2, Wl, bx0, by0, bw, area, nt, 1, b1h, b1l);
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-          for (int m = 0; m < 2; ++m) {
-            if (one_tile && (grp * 2 + m) != mt0) continue;
+        for (int m = 0; m < 2; ++m) {
+          if (one_tile && m != mt0) continue;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) tri(acc[m], b0h[k], b0l[k], ahi[m][k], alo[m][k]);
-          }
-          if (nt + 4 < ntiles) load_half(r2, Wl, bx0, by0, bw, area, nt + 4, 0, b0h, b0l);
+          for (int k = 0; k < 4; ++k) tri(acc[m], b0h[k], b0l[k], ahi[m][k], alo[m][k]);
+        }
+        if (nt + 4 < ntiles) load_half(r2, Wl, bx0, by0, bw, area, nt + 4, 0, b0h, b0l);
 #pragma unroll
-          for (int m = 0; m < 2; ++m) {
-            if (one_tile && (grp * 2 + m) != mt0) continue;
+        for (int m = 0; m < 2; ++m) {
+          if (one_tile && m != mt0) continue;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) tri(acc[m], b1h[k], b1l[k], ahi[m][4 + k], alo[m][4 + k]);
-          }
-          // acc[m][r] = S[position nt*16 + l4*4 + r][pixel (2 grp + m)*16 + l15]
+          for (int k = 0; k < 4; ++k) tri(acc[m], b1h[k], b1l[k], ahi[m][4 + k], alo[m][4 + k]);
+        }
+        // acc[m][r] = S[position nt*16 + l4*4 + r][pixel m*16 + l15]
 #pragma unroll
-          for (int m = 0; m < 2; ++m) {
-            if (one_tile && (grp * 2 + m) != mt0) continue;
-            const int q = (grp * 2 + m) * 16 + l15 - p0;
-            if (q >= 0 && q < np) *reinterpret_cast<f32x4*>(V + q * vstride + nt * 16 + l4 * 4) = acc[m];
-          }
+        for (int m = 0; m < 2; ++m) {
+          if (one_tile && m != mt0) continue;
+          const int q = m * 16 + l15 - p0;
+          if (q >= 0 && q < np) *reinterpret_cast<f32x4*>(V + q * vstride + nt * 16 + l4 * 4) = acc[m];
         }
       }
-      prefetched = false;
-      if (np == 64 && lvl < 3) {       // half 0 of the first N tile of the NEXT level's whole-tile box: its latency hides behind the blend
+      if (np == OTFS_NPX && lvl < 3) {       // half 0 of this wave's first N tile of the NEXT level: its latency hides behind the blend
         const int* nb = boxes + (lvl + 1) * 4;
         const int narea = nb[2] * nb[3], nnt = (narea + 15) >> 4;
-        if (nnt * 16 <= OTF_VTOT / 64) {
-          if (wig < nnt) load_half(level_rsrc(lvl + 1), p.w >> (lvl + 1), nb[0], nb[1], nb[2], narea, wig, 0, b0h, b0l);
+        if (nnt * 16 <= OTFS_VTOT / OTFS_NPX) {
+          if (wave < nnt) load_half(level_rsrc(lvl + 1), p.w >> (lvl + 1), nb[0], nb[1], nb[2], narea, wave, 0, b0h, b0l);
           prefetched = true;
         }
       }
+      stamp(1);
       __syncthreads();
-      // -- blend: one work item per output (pixel, a, b) with pp_corr_lookup's arithmetic (per-tap grid round trip, the four corners
-      //    accumulated in the same order); corners outside the box are outside the map (zeros) -- or, when a tap's round trip crosses
-      //    an integer by one ulp, one cell beyond the box, where their weight is <= 1 ulp of the coordinate
-      for (int item = tid; item < np * 81; item += 512) {
-        const int q = item / 81, j = item - q * 81;
-        const float cx0 = cxy[(p0 + q) * 2];
-        if (!(cx0 == cx0)) continue;
-        const int a = j / 9, b = j - a * 9;
-        const float cx = cx0 * lscale, cy = cxy[(p0 + q) * 2 + 1] * lscale;
-        const float px = grid_roundtrip(cx + (float)(a - 4), Wl);
-        const float py = grid_roundtrip(cy + (float)(b - 4), Hl);
-        const float fx = floorf(px), fy = floorf(py);
-        const float lx = px - fx, ly = py - fy;
-        const int c0 = (int)fx - bx0, r0 = (int)fy - by0;
+      stamp(2);
+      // -- blend: one work item per output (pixel, a, b), the four corners accumulated in pp_corr_lookup's order; corners outside the box
+      //    are outside the map (zeros) -- or, when a tap's round trip crosses an integer by one ulp, one cell beyond the box, where
+      //    their weight is <= 1 ulp of the coordinate
+#pragma unroll 2
+      for (int item = tid; item < ((PROF && (p.dbg & 1)) ? 0 : np * 81); item += 256) {
+        const int q = item / 81, jj = item - q * 81;
+        const int b = jj / 9, a = jj - b * 9;            // a (the tap's x offset) fastest over the lanes: consecutive V columns, no bank conflicts
+        const int j = a * 9 + b;                         // output channel inside the level group (first index moves x: RAFT/corr.py:36-43)
+        const int2 ex = tab[(p0 + q) * 18 + a], ey = tab[(p0 + q) * 18 + 9 + b];
+        const float lx = __builtin_bit_cast(float, ex.y), ly = __builtin_bit_cast(float, ey.y);
+        const int c0 = ex.x - bx0, r0 = ey.x - by0;
         const float* vrow = V + q * vstride;
-        float acc = 0.f;
+        float acc = 0.f, sv[4], wg[4];
+        int okm = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int rr = r0 + (k >> 1), cc = c0 + (k & 1);
           const float wgt = ((k & 1) ? lx : 1.f - lx) * ((k >> 1) ? ly : 1.f - ly);
           const bool ok = (unsigned)rr < (unsigned)bh_ && (unsigned)cc < (unsigned)bw;
-          float s = vrow[ok ? rr * bw + cc : 0];
-          s = ok ? s * p.scale : 0.f;                  // (the volume holds f1 . f2 / 16: scale before the blend, as RAFT/corr.py:60)
-          acc += wgt * s;
+          sv[k] = vrow[ok ? rr * bw + cc : 0];
+          okm |= ok ? (1 << k) : 0;
+          wg[k] = wgt;
+        }
+        // (the four reads are issued back to back, unconditionally: left to itself hipcc sinks each one into its own `ok` branch with a
+        //  full lgkmcnt(0) wait -- four serialised LDS round trips per output, 3.6k cycles per output and wave measured)
+        asm volatile("" : "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3]));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float s = ((okm >> k) & 1) ? sv[k] * p.scale : 0.f;      // (the volume holds f1 . f2 / 16: RAFT/corr.py:60)
+          acc += wg[k] * s;
         }
         const _Float16 hi = (_Float16)acc;
         _Float16* so = stage + (p0 + q) * 2 * OTFS_LVC + j;
         so[0] = hi;
         so[OTFS_LVC] = (_Float16)(acc - (float)hi);
       }
+      stamp(3);
       __syncthreads();
+      stamp(4);
       return true;
     };
 
-    if (!process(0, 64, boxes + lvl * 4)) {
+    if (!process(0, OTFS_NPX, boxes + lvl * 4)) {
       prefetched = false;
-      for (int g = 0; g < 4; ++g) {
+      for (int g = 0; g < 2; ++g) {
         if (wave == 0) wave_box(lvl, g * 16, 16, boxes + 16);
         __syncthreads();
         const bool ok = process(g * 16, 16, boxes + 16);
@@ -519,15 +571,24 @@ __global__ __launch_bounds__(512, 2) void corr_otf_split_kernel(const CorrOtfPar
       }
     }
     // ---- this level's 88-channel group of both planes -> NHWC rows (11 16-byte chunks per pixel and plane)
-    for (int o = tid; o < 64 * 2 * 11; o += 512) {
+    for (int o = tid; o < ((PROF && (p.dbg & 8)) ? 0 : OTFS_NPX * 2 * 11); o += 256) {
       const int q = o / 22, r = o - q * 22, pl = r / 11, c = r - pl * 11;
-      int x, y;
-      tile_xy(q, x, y);
-      if (x < p.w && y < p.h)
-        *reinterpret_cast<u32x4*>(p.out + (((long long)n * p.h + y) * p.w + x) * p.ocs + pl * (p.ocs >> 1) + lvl * OTFS_LVC + c * 8) =
-            *reinterpret_cast<const u32x4*>(stage + (q * 2 + pl) * OTFS_LVC + c * 8);
+      const int x = tx0 + (q & 7), y = ty0 + (q >> 3);
+      if (x < p.w && y < p.h) {
+        u32x4* dst = reinterpret_cast<u32x4*>(p.out + (((long long)n * p.h + y) * p.w + x) * p.ocs + pl * (p.ocs >> 1) + lvl * OTFS_LVC + c * 8);
+        const u32x4 val = *reinterpret_cast<const u32x4*>(stage + (q * 2 + pl) * OTFS_LVC + c * 8);
+        *dst = val;
+      }
     }
-    // (the next level's blend rewrites the staging tile only after its own __syncthreads(), which every thread reaches after these reads)
+    stamp(5);
+    // (the next level's tables / blend rewrite `tab` / the staging tile only after a __syncthreads() every thread reaches after these reads:
+    //  the table loop writes `tab`, which the write-out does not read; the blend comes after process()'s barrier)
+  }
+  if (PROF && (p.dbg & 16) && tid == 0) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) atomicAdd(&g_otf_prof[i], tacc[i]);
+    atomicAdd(&g_otf_prof[6], __builtin_amdgcn_s_memtime() - tstart);
+    atomicAdd(&g_otf_prof[7], 1ull);
   }
 #endif
 }
@@ -615,6 +676,7 @@ extern "C" int pp_corr_lookup_otf(const void* f1, const void* f2_lvl0, const voi
   p.P = P; p.h = h; p.w = w; p.ocs = out_cstride; p.ocpad = out_cpad;
   p.tiles_x = (w + 7) / 8; p.tiles_y = (h + 7) / 8;
   p.scale = 1.f / 16.f;
+  p.dbg = 0;
   const long long nblk = (long long)P * p.tiles_x * p.tiles_y;
   PP_REQUIRE(nblk < (1ll << 31), PP_ERR_ARG, "pp_corr_lookup_otf: too many tiles");
   hipLaunchKernelGGL(corr_otf_kernel, dim3((unsigned)nblk), dim3(512), 0, (hipStream_t)stream, p);
@@ -636,10 +698,21 @@ extern "C" int pp_corr_lookup_otf_split(const void* f1, const void* f2_lvl0, con
   p.f2[0] = (const char*)f2_lvl0; p.f2[1] = (const char*)f2_lvl1; p.f2[2] = (const char*)f2_lvl2; p.f2[3] = (const char*)f2_lvl3;
   p.coords = coords; p.out = (_Float16*)out;
   p.P = P; p.h = h; p.w = w; p.ocs = out_cstride; p.ocpad = 4 * OTFS_LVC;
-  p.tiles_x = (w + 7) / 8; p.tiles_y = (h + 7) / 8;
+  p.tiles_x = (w + 7) / 8; p.tiles_y = (h + 3) / 4;
   p.scale = 1.f / 16.f;
+  static const int dbg = getenv("PP_OTF_DBG") ? atoi(getenv("PP_OTF_DBG")) : 0;
+  p.dbg = dbg;
   const long long nblk = (long long)P * p.tiles_x * p.tiles_y;
   PP_REQUIRE(nblk < (1ll << 31), PP_ERR_ARG, "pp_corr_lookup_otf_split: too many tiles");
-  hipLaunchKernelGGL(corr_otf_split_kernel, dim3((unsigned)nblk), dim3(512), 0, (hipStream_t)stream, p);
+  if (dbg) hipLaunchKernelGGL(corr_otf_split_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(corr_otf_split_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);
   return launch_status("pp_corr_lookup_otf_split");
+}
+
+// [diagnostic, not part of the public header] reads and clears the phase counters of pp_corr_lookup_otf_split (PP_OTF_DBG bit 16)
+extern "C" int pp_debug_otf_prof(unsigned long long* out) {
+  unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(pp::g_otf_prof), sizeof(zero));
+  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(pp::g_otf_prof), zero, sizeof(zero));
+  return (int)e;
 }

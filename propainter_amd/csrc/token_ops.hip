@@ -235,8 +235,8 @@ __global__ void inorm_apply_split_kernel(const float* __restrict__ in, const flo
     for (int j = 0; j < 4; ++j) {
       const float4 m = st[j];
       const float r0 = (v[2 * j] - m.x) * m.y, r1 = (v[2 * j + 1] - m.z) * m.w;
-      v[2 * j] = relu ? fmaxf(r0, 0.f) : r0;
-      v[2 * j + 1] = relu ? fmaxf(r1, 0.f) : r1;
+      v[2 * j] = relu ? relu_split(r0) : r0;
+      v[2 * j + 1] = relu ? relu_split(r1) : r1;
     }
     if (res != nullptr) {
       float r[8];
@@ -247,7 +247,7 @@ __global__ void inorm_apply_split_kernel(const float* __restrict__ in, const flo
     }
     if (relu2) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+      for (int j = 0; j < 8; ++j) v[j] = relu_split(v[j]);
     }
     _Float16* op = out + pix * (2 * C) + cc * 8;
     store8_split(op, op + C, v);
