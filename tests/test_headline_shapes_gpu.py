@@ -136,7 +136,8 @@ def test_generator_window_720p_timed_shape_vs_oracle(models, sds, dt):
     """Stage D on the window shape the headline bench times: 720x1280, t = 18 frames of which 11 local.
     What only this length exercises: 9-entry T_ind phases, ~5 400 keys per masked window and head through the flash kernel's online
     softmax (t = 8: 2 400), 10 forward + 10 backward deformable propagation steps.  The oracle needs ~2-3 min on the box's host cores
-    (once for both precisions)."""
+    (once for both precisions).  Measured on MI355X (profiles/r4_parity_timed_config.txt): fp32 4.0e-5, fp16 8.7e-3 of the output range
+    (t = 8: 1.4e-5 / 8.6e-3) -- the fp16 bar of 2e-2 is 2.3x the measurement."""
     fr, mk, mu, gfl, lt, ref = _gen_case(sds, 720, 1280, **TIMED_WINDOW)
     assert fr.shape[1] == 18 and lt == 11
     out = models[2]((fr * (1 - mk)).cuda().to(dt), (gfl[0].cuda().to(dt), gfl[1].cuda().to(dt)), mk.cuda().to(dt), mu.cuda().to(dt), lt)
@@ -177,5 +178,6 @@ def test_image_propagation_720p_vs_oracle(models, dt):
     print(f"HEADLINE_PARITY imgprop720_{'f32' if dt == torch.float32 else 'f16'}: mask mismatch {mism_m:.2e}, pixel mismatch {mism_p:.2e} "
           f"(share of the hole filled by propagation: {filled:.3f})")
     assert filled > 0.15, "the case must actually propagate"
-    lim = 2e-4 if dt == torch.float32 else 2e-3
+    # measured on MI355X (profiles/r4_parity_timed_config.txt): fp32 0 / 0 mismatching elements of 10.1 M / 30.4 M, fp16 9.2e-6 / 1.05e-5
+    lim = 2e-6 if dt == torch.float32 else 3e-5
     assert mism_m < lim and mism_p < lim, (mism_m, mism_p)

@@ -573,8 +573,9 @@ def test_proinpainter_api_matches_the_oracle_driver(sds):
     assert p16 > 64.2, p16              # measured 67.19
 
 
-# measured on MI355X: fp32 stages 91.42 dB; floors 3 dB under the measurement
-EVAL_PSNR_FLOOR = {False: 88.4, True: 64.0}
+# measured on MI355X (profiles/r4_parity_timed_config.txt): fp32 stages 91.69 dB, fp16 stages + f16x3 RAFT 67.31 dB, max |d| = 1 byte in both;
+# floors 3 dB under the measurement
+EVAL_PSNR_FLOOR = {False: 88.6, True: 64.3}
 
 
 @pytest.mark.parametrize("fp16", [False, True], ids=["f32", "f16"])
