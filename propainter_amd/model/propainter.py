@@ -163,10 +163,18 @@ class _GenEngine:
 
     def feature_propagation(self, x, flows_f, flows_b, mask2, interpolation="bilinear", rows=None, out=None):
         """x [t,h,w,128]; flows_* [t-1,h,w,2] NHWC (1/4-res, already /4); mask2 [t,h,w,2] -> fused [t,h,w,128] (written to `out`
-        when given).  rows = propagation_rows(...) of these frames when the caller has them already (per-clip cache)."""
-        t, h, w, c = x.shape
-        dev, dt = x.device, self.dtype
+        when given).  rows = propagation_rows(...) of these frames when the caller has them already (per-clip cache).
+
+        BATCHED form (engine extension, propagate_windows): x [t,B,h,w,128] and rows of shapes [t-1,B,h,w,8] / [t,B,h,w,8] hold B
+        independent windows of the same length, step-major -- step i of every window is ONE launch per layer over B frames.  A window's
+        recurrence only ever reads its own frames (batch items never mix in a convolution, a warp or a deformable sampling), so every
+        window's result is bit-identical to its own un-batched pass."""
+        batched = x.dim() == 5
         aux_b, aux_f, mk8 = rows if rows is not None else self.propagation_rows(flows_f, flows_b, mask2)
+        if not batched:
+            x, aux_b, aux_f, mk8 = x.unsqueeze(1), aux_b.unsqueeze(1), aux_f.unsqueeze(1), mk8.unsqueeze(1)
+        t, B, h, w, c = x.shape
+        dev, dt = x.device, self.dtype
         feats = {"input": x}
         prev_name = "input"
         for name in ("backward_1", "forward_1"):
@@ -180,28 +188,65 @@ class _GenEngine:
                 order = list(range(t))
                 aux, pair = aux_f, (lambda i, idx: i - 1)
             cur_all = feats[prev_name]
-            outs = torch.empty((t, h, w, c), dtype=dt, device=dev)
+            outs = torch.empty((t, B, h, w, c), dtype=dt, device=dev)
             prop = None
             for i, idx in enumerate(order):
-                cur = cur_all[idx:idx + 1]
+                cur = cur_all[idx]
                 if i == 0:
                     prop = cur
                 else:
-                    j = pair(i, idx)
-                    ax = aux[j:j + 1]
+                    ax = aux[pair(i, idx)]
                     warped = hip.flow_warp(prop, ax, mode=interpolation)
                     o = L["off0"]([cur, warped, ax], act="lrelu", act_param=0.1)
                     o = L["off2"]([o], act="lrelu", act_param=0.1)
                     o = L["off4"]([o], act="lrelu", act_param=0.1)
                     om = L["off6"]([o], fuse=dict(kind="dcn_om", mag=3.0, flow=ax))      # 3 * tanh(offsets) + flow | sigmoid(masks)
                     prop = L["dcn"]([prop], dcn_offmask=om)
-                y = L["bb0"]([cur, prop, mk8[idx:idx + 1]], act="lrelu", act_param=0.2)
-                L["bb2"]([y], out=outs[idx:idx + 1], residual=prop)
-                prop = outs[idx:idx + 1]
+                y = L["bb0"]([cur, prop, mk8[idx]], act="lrelu", act_param=0.2)
+                L["bb2"]([y], out=outs[idx], residual=prop)
+                prop = outs[idx]
             feats[name] = outs
             prev_name = name
-        y = self.fuse0([feats["backward_1"], feats["forward_1"], mk8], act="lrelu", act_param=0.2)
-        return self.fuse2([y], residual=x, out=out)
+        if out is None:
+            out = torch.empty((t, B, h, w, c), dtype=dt, device=dev)
+        out5 = out.view(t, B, h, w, c)
+        for j in range(t) if batched else (slice(None),):       # (batched: one step-slab at a time keeps every operand below 2 GiB)
+            sl = (lambda v: v[j]) if batched else (lambda v: v.view(t * B, h, w, v.shape[-1]))
+            y = self.fuse0([sl(feats["backward_1"]), sl(feats["forward_1"]), sl(mk8)], act="lrelu", act_param=0.2)
+            self.fuse2([y], residual=sl(x), out=sl(out5))
+        return out5 if batched else out5.view(t, h, w, c)
+
+    def propagate_windows(self, clip, windows):
+        """Feature propagation of ALL generator windows of a clip up front, windows of equal length batched (engine extension; the
+        reference runs it inside every window's forward, model/propainter.py:345-349).  windows: [(first local frame, l_t), ...].
+        A window's propagation is a chain of ~170 launches over ONE 1/4-resolution frame each (57 600 pixels at 720p: ~450 blocks for
+        512 slots -- a single generation of blocks, all prologue and epilogue); the windows are independent, so the 14 full-length
+        windows of an 80-frame clip run as ONE chain of launches over 14 frames each.  Results land in clip['prop'][(first, l_t)] =
+        (fused [l_t,B,h,w,128], k): forward_window copies its frames out.  Bit-identical to the per-window chain (see
+        feature_propagation); groups whose first frames are no arithmetic progression stay on the per-window path."""
+        enc = clip["enc"]
+        dev = enc.device
+        h, w = enc.shape[1], enc.shape[2]
+        by_len = {}
+        for first, l_t in windows:
+            by_len.setdefault(l_t, []).append(first)
+        clip["prop"] = {}
+        for l_t, firsts in by_len.items():
+            firsts = sorted(set(firsts))
+            B = len(firsts)
+            step = firsts[1] - firsts[0] if B > 1 else 1
+            if B < 2 or l_t < 2 or any(b - a != step for a, b in zip(firsts, firsts[1:])):
+                continue
+            # frame index of (step j, window k) = firsts[0] + step * k + j -- built on the device (capturable: no host copy)
+            base = torch.arange(B, device=dev) * step + firsts[0]
+            idx = (torch.arange(l_t, device=dev)[:, None] + base[None, :]).reshape(-1)
+            idxp = (torch.arange(l_t - 1, device=dev)[:, None] + base[None, :]).reshape(-1)
+            g5 = lambda src, ix, n: src.index_select(0, ix).view(n, B, h, w, src.shape[-1])
+            fused = self.feature_propagation(g5(enc, idx, l_t), None, None, None, clip["interpolation"],
+                                             rows=(g5(clip["aux_b"], idxp, l_t - 1), g5(clip["aux_f"], idxp, l_t - 1), g5(clip["mk8"], idx, l_t)))
+            for k, first in enumerate(firsts):
+                clip["prop"][(first, l_t)] = (fused, k)
+        return clip
 
     # ------------------------------------------------------------------ transformer
     def _window_tables(self, Hp, Wp):
@@ -334,8 +379,12 @@ class _GenEngine:
         n_ref = int(ref_index.numel())
         encw = torch.empty((l_t + n_ref, h, w, 128), dtype=self.dtype, device=enc.device)
         a, b = first, first + l_t
-        self.feature_propagation(enc[a:b], None, None, None, clip["interpolation"],
-                                 rows=(clip["aux_b"][a:b - 1], clip["aux_f"][a:b - 1], clip["mk8"][a:b]), out=encw[:l_t])
+        done = clip.get("prop", {}).get((first, l_t))
+        if done is not None:          # propagated up front with the other windows of its length (propagate_windows)
+            encw[:l_t].copy_(done[0][:, done[1]])
+        else:
+            self.feature_propagation(enc[a:b], None, None, None, clip["interpolation"],
+                                     rows=(clip["aux_b"][a:b - 1], clip["aux_f"][a:b - 1], clip["mk8"][a:b]), out=encw[:l_t])
         if n_ref:
             torch.index_select(enc, 0, ref_index, out=encw[l_t:])
         return self._window_tail(encw, l_t, clip["token_mask"][a:b], t_dilation, clip["H"], clip["W"])
@@ -450,6 +499,16 @@ class InpaintGenerator(nn.Module):
         eng = self._get_engine(dt, frames.device)
         return eng.prepare_clip(frames, (completed_flows[0].to(dt), completed_flows[1].to(dt)), masks_in.to(dt), masks_updated.to(dt),
                                 interpolation)
+
+    @torch.no_grad()
+    def propagate_windows(self, clip, windows):
+        """Engine extension: the feature propagation (model/propainter.py:345-349) of all windows ``[(first, num_local_frames), ...]`` of a
+        prepared clip up front, windows of equal length as one batch; ``forward_window`` then reads its frames from ``clip['prop']``.
+        Identical results (a window's recurrence only reads its own frames)."""
+        enc = clip["enc"]
+        import contextlib
+        with (torch.cuda.device(enc.device) if enc.is_cuda else contextlib.nullcontext()):
+            return self._get_engine(enc.dtype, enc.device).propagate_windows(clip, [(int(f), int(n)) for f, n in windows])
 
     @hip.on_input_device
     @torch.no_grad()

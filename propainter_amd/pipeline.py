@@ -22,6 +22,7 @@ class InferenceConfig:
     neighbor_length: int = 10
     ref_stride: int = 10
     fp16: bool = False
+    batch_propagation: bool = True       # feature propagation of equal-length generator windows as one batch (InpaintGenerator.propagate_windows)
     window_streams: int = 2      # engine extension: generator windows in flight on separate HIP streams (bit-identical results;
                                  # measured 1167.7 -> 1102.9 ms per 720p clip with 2, 1114.6 with 3: profiles/r2_window_streams.txt)
     raft_streams: int = 3        # engine extension: RAFT's two encoders, and its pair-directions in this many groups, on separate
@@ -256,6 +257,10 @@ def run_clip(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg: InferenceC
                      masks_dilated.index_select(1, ids), updated_masks.index_select(1, ids), len(nb), **kw)
 
     sched = window_schedule(L, cfg.neighbor_length, cfg.ref_stride, cfg.subvideo_length)
+    if clip_cache is not None and cfg.batch_propagation and hasattr(model, "propagate_windows"):
+        # engine extension: the windows' feature propagation up front, windows of equal length batched -- one chain of launches over
+        # ~14 frames each instead of 14 chains over one frame each (single-generation grids); same results
+        model.propagate_windows(clip_cache, [(nb[0], len(nb)) for nb, _ in sched])
     lanes = _window_streams(device, cfg.window_streams) if device.type == "cuda" else []
     if len(lanes) < 2:
         for nb, ref in sched:

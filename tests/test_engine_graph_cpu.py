@@ -106,6 +106,28 @@ def test_clip_pipeline_graph(models):
     assert (comp != g["comp"]).mean() < 0.01
 
 
+def test_batched_feature_propagation_graph(models):
+    """pipeline.run_clip with the windows' feature propagation batched (InpaintGenerator.propagate_windows) against the per-window
+    chain, under the CPU emulation of the device ops: the host logic (step-major gathers, per-window read-back, the windows that stay on
+    the per-window path) must give the same composite."""
+    from propainter_amd.pipeline import InferenceConfig, run_clip, window_schedule
+    from propainter_amd.synthetic import synthetic_clip, synthetic_mask
+    L, H, W = 14, 128, 192
+    clip = synthetic_clip(L, H, W, seed=5)
+    masks = np.repeat(synthetic_mask(H, W)[None], L, 0)
+    lens = [len(nb) for nb, _ in window_schedule(L, 4, 3, 80)]
+    assert max(lens.count(n) for n in set(lens)) >= 3, lens
+    outs = {}
+    with emulated_device_ops():
+        for bp in (False, True):
+            cfg = InferenceConfig(raft_iter=2, subvideo_length=80, neighbor_length=4, ref_stride=3, fp16=False, batch_propagation=bp, window_streams=1)
+            outs[bp] = run_clip(models, clip, masks, masks, cfg, torch.device("cpu")).clone()
+    # (the emulation's F.conv2d is not bit-invariant to the batch size -- oneDNN blocks differently; the HIP kernels are, and the GPU test
+    #  tests/test_modules_gpu.py::test_batched_feature_propagation_is_bit_identical asserts equality)
+    d = (outs[False].int() - outs[True].int()).abs()
+    assert d.max() <= 1 and (d > 0).float().mean() < 1e-4, (d.max(), (d > 0).float().mean())
+
+
 def test_raft_fp16_graph_uses_the_on_the_fly_correlation(models):
     """The fp16 RAFT engine takes the volume-free correlation path (feature pyramid + on-the-fly lookup); under the CPU
     emulation of the device ops its flow must stay within fp16 end-point error of the real reference's golden."""

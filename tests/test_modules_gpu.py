@@ -368,6 +368,33 @@ def test_window_streams_are_bit_identical(models):
 
 
 @pytest.mark.parametrize("fp16", [False, True], ids=["f32", "f16"])
+def test_batched_feature_propagation_is_bit_identical(models, fp16):
+    """InferenceConfig.batch_propagation (InpaintGenerator.propagate_windows): the feature propagation of the equal-length generator windows
+    of a clip as ONE chain of launches over a batch of frames instead of one chain per window (model/propainter.py:345-349 runs it
+    inside every window's forward).  Batch items never mix -- every convolution, warp and deformable sampling reads its own frame --, so
+    the composited bytes must be identical, eager and as a captured hipGraph.  26 frames, neighbor_length 4: 11 windows of 5 local
+    frames (one batch of 11) + the shorter first / last windows on the per-window path."""
+    from propainter_amd.pipeline import ClipGraph, InferenceConfig, run_clip, window_schedule
+    from propainter_amd.synthetic import synthetic_clip, synthetic_mask
+    import scipy.ndimage
+    L, H, W = 26, 128, 192
+    clip = synthetic_clip(L, H, W, seed=23)
+    m = scipy.ndimage.binary_dilation(synthetic_mask(H, W), iterations=4).astype(np.uint8) * 255
+    masks = np.repeat(m[None], L, 0)
+    dev = torch.device("cuda")
+    lens = [len(nb) for nb, _ in window_schedule(L, 4, 3, 80)]
+    assert max(lens.count(n) for n in set(lens)) >= 8, lens          # the case really batches
+    outs = {}
+    for bp in (False, True):
+        cfg = InferenceConfig(raft_iter=3, subvideo_length=80, neighbor_length=4, ref_stride=3, fp16=fp16, batch_propagation=bp)
+        outs[bp] = run_clip(models, clip, masks, masks, cfg, dev).clone()
+    assert torch.equal(outs[False], outs[True])
+    g = ClipGraph(models, L, H, W, cfg, dev)(clip, masks, masks)
+    torch.cuda.synchronize()
+    assert torch.equal(g, outs[True])
+
+
+@pytest.mark.parametrize("fp16", [False, True], ids=["f32", "f16"])
 def test_logical_shards_on_one_gpu_match_the_unsharded_pass(models, fp16):
     """Sub-video sharding with the REAL engines: 3 logical ranks on one GPU (exchanges handed over in-process, the
     same generator the RCCL driver runs) must reproduce run_clip bit for bit -- every kernel is batch-invariant."""
