@@ -137,10 +137,13 @@ class Compositor:
     produced by an earlier window becomes ``uint8(0.5*old + 0.5*new)`` — order dependent, so windows must be
     fed in increasing f."""
 
-    def __init__(self, frames_u8, masks_dilated):
+    def __init__(self, frames_u8, masks_dilated, float_blend=False):
+        """float_blend: the EVALUATION script's composite (scripts/evaluate_propainter.py:170-178 of the reference): a frame covered by
+        several windows is averaged in float32 WITHOUT truncating back to uint8 after every blend; ``comp`` is then float32."""
         self.ori = frames_u8                                          # uint8 [L,H,W,3] on device
         self.bin = masks_dilated[0].permute(0, 2, 3, 1).to(torch.uint8)  # [L,H,W,1] {0,1}
-        self.comp = torch.zeros_like(frames_u8)
+        self.float_blend = bool(float_blend)
+        self.comp = torch.zeros(frames_u8.shape, dtype=torch.float32 if float_blend else torch.uint8, device=frames_u8.device)
         self.done = [False] * frames_u8.shape[0]
 
     def add(self, neighbor_ids, pred_img):
@@ -148,6 +151,14 @@ class Compositor:
         per operation, exactly like the reference (``(pred_img + 1) / 2`` on the device, ``* 255`` on a float16 / float32
         numpy array, truncation to uint8: inference_propainter.py:437-438,443) -- so the bytes equal the reference's
         for identical predictions in either precision (tests/test_host_logic_cpu.py::test_compositor_*)."""
+        if self.float_blend:
+            img = (((pred_img + 1) / 2).permute(0, 2, 3, 1) * 255).to(torch.uint8)
+            for i, idx in enumerate(neighbor_ids):
+                m = self.bin[idx]
+                cur = (img[i] * m + self.ori[idx] * (1 - m)).float()
+                self.comp[idx] = self.comp[idx] * 0.5 + cur * 0.5 if self.done[idx] else cur
+                self.done[idx] = True
+            return
         if pred_img.is_cuda:      # one launch per window (pp_composite_window: same roundings, same bytes) instead of ~8 per frame
             pred = pred_img.contiguous()
             for s0 in range(0, len(neighbor_ids), 32):      # the kernel takes <= 32 frames per launch (--neighbor_length >= 32: groups)
@@ -205,7 +216,7 @@ def _dev_index(ids, device):
 
 @torch.no_grad()
 def run_clip(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg: InferenceConfig, device, return_stages=False,
-             stage_hook=None, gt_flows=None):
+             stage_hook=None, gt_flows=None, float_blend=False):
     """Whole path for one clip.  frames_u8 [L,H,W,3] uint8, masks [L,H,W] uint8 {0,255} (numpy or tensors).
     models = (RAFT_bi, RecurrentFlowCompleteNet, InpaintGenerator).  Returns uint8 tensor [L,H,W,3] on `device`.
     ``stage_hook(name)`` (optional) is called at every stage boundary (bench.py records HIP events there).
@@ -214,7 +225,7 @@ def run_clip(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg: InferenceC
     device = torch.device(device)
     if device.type == "cuda" and device.index is not None and device.index != torch.cuda.current_device():
         with torch.cuda.device(device):      # launches bind to the current device: make the clip's device current
-            return run_clip(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg, device, return_stages, stage_hook, gt_flows)
+            return run_clip(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg, device, return_stages, stage_hook, gt_flows, float_blend)
     mark = stage_hook or (lambda name: None)
     fix_raft, fix_flow_complete, model = models
     to_t = lambda a: a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))
@@ -239,7 +250,7 @@ def run_clip(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg: InferenceC
     mark('flow_completion')
     updated_frames, updated_masks = propagate_images(model, frames, masks_dilated, pred_flows_bi, cfg.subvideo_length)
     mark('image_propagation')
-    comp = Compositor(fr_u8, masks_dilated)
+    comp = Compositor(fr_u8, masks_dilated, float_blend=float_blend)      # (float_blend: the evaluation script's float32 averaging)
     # engine extension: everything of the generator windows that depends on a frame / flow pair only (encoder features, 1/4-resolution
     # flows and masks, propagation side inputs) once per clip; a window then reads slices of it -- same results
     clip_cache = model.prepare_clip(updated_frames, pred_flows_bi, masks_dilated, updated_masks) if hasattr(model, "prepare_clip") else None

@@ -273,3 +273,65 @@ def test_window_index_cache_is_lru_and_graphs_keep_their_tensors(monkeypatch):
     assert (3, 4) not in keys and (0, 1, 2) in keys and len(keys) == 3
     assert pinned[0] is a and pinned[1] is b and pinned[2] is a and b.tolist() == [3, 4]      # the graph's references survive eviction
     assert P._dev_index([3, 4], "cpu") is not b          # re-created on demand for later eager passes
+
+
+def test_evaluation_metrics_restate_the_reference():
+    """scripts/evaluate_propainter.py: PSNR = core/metrics.py:20-36; SSIM = scikit-image's compare_ssim(data_range=255, multichannel=True,
+    win_size=w) as core/metrics.py:47-51 calls it, restated on scipy (scikit-image is absent) -- checked against a brute-force
+    evaluation of the published definition (uniform w x w windows fully inside the image, sample covariance, K1 0.01, K2 0.03)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("evaluate_propainter", os.path.join(os.path.dirname(os.path.dirname(__file__)), "scripts", "evaluate_propainter.py"))
+    ev = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ev)
+    rng = np.random.RandomState(0)
+    a = rng.randint(0, 256, (23, 31, 3)).astype(np.uint8)
+    b = np.clip(a.astype(np.int32) + rng.randint(-20, 21, a.shape), 0, 255).astype(np.uint8)
+    assert ev.calculate_psnr(a.astype(np.float64), a.astype(np.float64)) == float("inf")
+    mse = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
+    assert abs(ev.calculate_psnr(a.astype(np.float64), b.astype(np.float64)) - 10 * np.log10(255.0 ** 2 / mse)) < 1e-9
+    w = 7
+    C1, C2, n = (0.01 * 255) ** 2, (0.03 * 255) ** 2, w * w
+    vals = []
+    for ch in range(3):
+        X, Y = a[..., ch].astype(np.float64), b[..., ch].astype(np.float64)
+        acc = []
+        for y in range(a.shape[0] - w + 1):
+            for x in range(a.shape[1] - w + 1):
+                px, py = X[y:y + w, x:x + w].ravel(), Y[y:y + w, x:x + w].ravel()
+                ux, uy = px.mean(), py.mean()
+                vx, vy, vxy = px.var(ddof=1), py.var(ddof=1), ((px - ux) * (py - uy)).sum() / (n - 1)
+                acc.append(((2 * ux * uy + C1) * (2 * vxy + C2)) / ((ux ** 2 + uy ** 2 + C1) * (vx + vy + C2)))
+        vals.append(np.mean(acc))
+    assert abs(ev.structural_similarity(a, b, 255, w) - np.mean(vals)) < 1e-9
+    assert abs(ev.structural_similarity(a, a, 255, w) - 1.0) < 1e-12
+    with pytest.raises(ValueError):
+        ev.structural_similarity(a, b, 255, 65)            # the reference's window needs >= 65 pixels per side
+    args = ev.build_parser().parse_args([])
+    assert (args.height, args.width, args.neighbor_length, args.ref_stride, args.raft_iter, args.task) == (240, 432, 20, 10, 20, "video_completion")
+
+
+def test_float_blend_compositor_is_the_evaluation_scripts_composite():
+    """pipeline.Compositor(float_blend=True) against scripts/evaluate_propainter.py:160-178 of the reference restated in numpy: the
+    uint8 prediction pasted inside the mask, frames seen by several windows averaged in float32 with NO truncation in between (the
+    inference script's composite truncates after every blend: the two differ by up to 0.75 of a grey level after three windows)."""
+    from propainter_amd.pipeline import Compositor
+    rng = np.random.RandomState(3)
+    L, H, W = 7, 12, 16
+    ori = rng.randint(0, 256, (L, H, W, 3)).astype(np.uint8)
+    masks = (rng.rand(L, H, W, 1) > 0.5).astype(np.uint8)
+    windows = [([0, 1, 2, 3], rng.rand(4, 3, H, W).astype(np.float32) * 2 - 1), ([2, 3, 4, 5], rng.rand(4, 3, H, W).astype(np.float32) * 2 - 1),
+               ([3, 4, 5, 6], rng.rand(4, 3, H, W).astype(np.float32) * 2 - 1)]
+    comp_ref = [None] * L
+    for ids, pred in windows:                                            # (:160-178)
+        pi = (torch.from_numpy(pred) + 1) / 2
+        pi = pi.permute(0, 2, 3, 1).numpy() * 255
+        for i, idx in enumerate(ids):
+            img = np.array(pi[i]).astype(np.uint8) * masks[idx] + ori[idx] * (1 - masks[idx])
+            comp_ref[idx] = img if comp_ref[idx] is None else comp_ref[idx].astype(np.float32) * 0.5 + img.astype(np.float32) * 0.5
+    c = Compositor(torch.from_numpy(ori), torch.from_numpy(masks).permute(0, 3, 1, 2)[None].float(), float_blend=True)
+    for ids, pred in windows:
+        c.add(ids, torch.from_numpy(pred))
+    assert c.comp.dtype == torch.float32
+    for idx in range(L):
+        assert np.array_equal(c.comp[idx].numpy(), np.asarray(comp_ref[idx], dtype=np.float32)), idx
+    assert (c.comp[3] != c.comp[3].floor()).any()                        # frame 3 sits in three windows: quarter levels survive

@@ -731,3 +731,30 @@ def test_forward_window_of_a_prepared_clip_equals_forward(models, dt):
         got = gen.forward_window(clip, first, lt, torch.tensor(ref, dtype=torch.long, device="cuda"))
         torch.cuda.synchronize()
         assert got.shape == want.shape == (1, lt, 3, H, W) and torch.equal(got, want), (first, lt, ref, (got.float() - want.float()).abs().max().item())
+
+
+def test_evaluate_entry_point_prints_the_reference_report(tmp_path, capsys):
+    """scripts/evaluate_propainter.py (the reference's evaluation entry point, scripts/evaluate_propainter.py:181-222) on two seeded synthetic
+    clips: the per-video and closing report lines in the reference's format, the metrics file next to them, PSNR / SSIM finite, Time =
+    seconds per frame."""
+    import importlib.util
+    import re
+    spec = importlib.util.spec_from_file_location("evaluate_propainter", os.path.join(os.path.dirname(os.path.dirname(__file__)), "scripts", "evaluate_propainter.py"))
+    ev = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ev)
+    args = ev.build_parser().parse_args(["--synthetic", "2", "--frames", "12", "--height", "128", "--width", "192", "--raft_iter", "3",
+                                         "--result_root", str(tmp_path), "--save_results"])
+    lines = []
+    res = ev.evaluate(args, out=lines.append)
+    per_video = [l for l in lines if l.startswith("[")]
+    assert len(per_video) == 2
+    pat = re.compile(r"^\[\s*(\d+)/2\] Name: synthetic_0\d\s+\| PSNR/SSIM: (\d+\.\d{4})/(\d\.\d{4}) \| Avg PSNR/SSIM: (\d+\.\d{4})/(\d\.\d{4}) \| Time: (\d+\.\d{4})$")
+    for l in per_video:
+        assert pat.match(l), l
+    last = [l for l in lines if l.startswith("Finish evaluation")]
+    assert len(last) == 1 and re.match(r"^Finish evaluation\.\.\. Average Frame PSNR/SSIM/VFID: \d+\.\d{2}/\d\.\d{4}/nan \| Time: \d+\.\d{4}$", last[0]), last
+    assert 20.0 < res["psnr"] < 100.0 and 0.5 < res["ssim"] <= 1.0 and res["time"] > 0
+    txt = open(os.path.join(res["path"], "synthetic_metrics.txt")).read().splitlines()
+    assert txt[:2] == per_video and txt[2] == last[0]
+    assert len(os.listdir(os.path.join(res["path"], "synthetic_00"))) == 12
+    print("EVALUATE_REPORT", last[0])

@@ -179,6 +179,86 @@ def test_two_ranks_over_gloo_match_the_unsharded_pass():
     assert ok and lo == 0 and n == 40          # 3 sub-videos of 20 on 2 ranks: blocks of 40 frames
 
 
+def _plan_worker(rank, world, port, L, S, H, W, q):
+    """One rank of a BASELINE config-4 / config-5 shard plan at toy resolution: bit identity + the bytes every exchange moved."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        clip, m = _inputs(L, H, W)
+        cfg = InferenceConfig(raft_iter=20, subvideo_length=S, neighbor_length=10, ref_stride=10)
+        stats = {}
+        lo, comp = run_clip_sharded(MODELS, clip, m, m, cfg, torch.device("cpu"), stats=stats)
+        full = gather_frames(lo, comp, L, dst=0)
+        mine = {k: (v["sent_bytes"], v["recv_bytes"]) for k, v in stats.items()}
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        if rank == 0:
+            ref = run_clip(MODELS, clip, m, m, cfg, torch.device("cpu"))
+            q.put((bool(torch.equal(full, ref)), every))
+    finally:
+        dist.destroy_process_group()
+
+
+def _expected_exchange_bytes(L, S, world, H, W, elem):
+    """Bytes rank r sends / receives per exchange stage, from the plan's index ranges alone (RAFT flows +-5,
+    completed flows +-10, updated frames + masks for the neighbour / reference frames, uint8 composites of straddling windows)."""
+    cfg = InferenceConfig(subvideo_length=S, neighbor_length=10, ref_stride=10)
+    plan = ShardPlan(L, cfg, world)
+    ov = lambda a, b: max(0, min(a[1], b[1]) - max(a[0], b[0]))
+    fo = [plan.flows_own(r) for r in range(world)]
+    out = []
+    for r in range(world):
+        rec = {}
+        for tag, own, need, per_item in (("gt_flows", fo, plan.need_gt_flows, 2 * 2 * H * W * elem),
+                                         ("pred_flows", fo, plan.need_pred_flows, 2 * 2 * H * W * elem),
+                                         ("updated_frames", plan.own, plan.need_updated, 4 * H * W * elem)):
+            sent = sum(ov(own[r], need(q)) for q in range(world) if q != r) * per_item
+            recv = sum(ov(own[q], need(r)) for q in range(world) if q != r) * per_item
+            rec[tag] = (sent, recv)
+        routes = plan.blend_routes()
+        rec["blend"] = (sum(len(v) for (s_, d), v in routes.items() if s_ == r) * H * W * 3,
+                        sum(len(v) for (s_, d), v in routes.items() if d == r) * H * W * 3)
+        out.append(rec)
+    return out
+
+
+@pytest.mark.parametrize("L,S,world", [(320, 80, 4), (160, 20, 8)], ids=["config4_320f_4ranks", "config5_160f_8ranks"])
+def test_baseline_shard_plans_over_gloo(L, S, world):
+    """BASELINE configs 4 (720x1280x320, four sub-videos of 80 on 4 GPUs) and 5 (1080x1920x160, sub-videos of 20 on 8 GPUs) as REAL
+    process groups (gloo, one process per rank, toy resolution, stand-in models with the real temporal footprints): the gathered
+    result is bit-identical to the unsharded pass, and every rank moved exactly the bytes the plan's index ranges predict, within
+    SURVEY.md section 8(e)'s per-side estimate (0.45 GB at 720p fp16 = 488 B per pixel and side; the fp32 stand-ins carry 2x)."""
+    H, W = 16, 24
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_plan_worker, args=(r, world, port, L, S, H, W, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    ok, every = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert ok, "the gathered frames differ from the unsharded pass"
+    exp = _expected_exchange_bytes(L, S, world, H, W, elem=4)
+    for r in range(world):
+        got = {k: tuple(v) for k, v in every[r].items()}
+        for tag in ("gt_flows", "pred_flows", "updated_frames", "blend"):
+            assert got.get(tag, (0, 0)) == exp[r][tag], (r, tag, got.get(tag), exp[r][tag])
+        sent = sum(v[0] for v in got.values())
+        sides = (r > 0) + (r < world - 1)
+        assert sent <= sides * 2 * 488 * H * W, (r, sent, sides * 2 * 488 * H * W)       # (x 2: fp32 stand-ins vs the fp16 estimate)
+    # what the plan means at the real sizes (fp16 stages), per interior rank: documented next to the estimate it is checked against
+    for (HH, WW) in ((720, 1280),) if world == 4 else ((1080, 1920),):
+        e = _expected_exchange_bytes(L, S, world, HH, WW, elem=2)[1]
+        total = sum(v[0] for v in e.values())
+        print(f"SHARD_EXCHANGE {L} frames / {world} ranks at {HH}x{WW} fp16, interior rank 1 sends "
+              + ", ".join(f"{k} {v[0] / 1e6:.0f} MB" for k, v in e.items()) + f" = {total / 1e9:.2f} GB (both sides)")
+        assert total <= 2 * 0.45e9 * (HH * WW) / (720 * 1280)
+
+
 def test_wavefront_order_of_the_streaming_schedule():
     """sharding.wavefront_order: every (rank, segment) exactly once, after its own previous segment and after the previous segment of
     every rank it receives from; stage D (segment 3) of sub-video k is issued in one wave with C of k + 1, B of k + 2 and RAFT of k + 3;
