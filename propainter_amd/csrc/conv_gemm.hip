@@ -534,7 +534,6 @@ extern "C" int pp_conv2d(const pp_conv_args_t* a, void* stream) {
   p.out2 = (char*)a->out2; p.out2_cstride = a->out2_cstride; p.out2_choff = a->out2_choff;
   p.split = a->split; p.out_lo = a->out_lo; p.out2_lo = a->out2_lo; p.preadd_lo = a->preadd_lo; p.res_lo = a->res_lo;
   p.fuse_a_lo = a->fuse_a_lo; p.fuse_b_lo = a->fuse_b_lo;
-  p.wfrag = 0;
   {   // PP_EPI_DIRECT: 0 = never, 1 (default) = the batched GEMMs (short K, output-bound), 2 = every plain fp32 output (read per launch: A/B runs)
     const char* ed = getenv("PP_EPI_DIRECT");
     const int mode = ed != nullptr ? atoi(ed) : 1;
@@ -588,7 +587,7 @@ extern "C" int pp_conv2d(const pp_conv_args_t* a, void* stream) {
     int rc = -1000;
     if (a->split == 2 && (a->impl == 0 || a->impl == 110)) rc = conv_head_dispatch(p, st, a->impl == 110);   // 3x3 heads with <= 4 couts (opt-in)
     PP_REQUIRE(a->impl != 110 || rc != -1000, PP_ERR_ARG, "pp_conv2d: impl 110 (streaming head kernel) not available for this layer");
-    if (rc == -1000 && a->split == 2 && v2cfg == 0) rc = conv_v3s_dispatch(p, a->impl == 71 || a->impl == 72 || a->impl == 116 ? a->impl : 0, st);
+    if (rc == -1000 && a->split == 2 && v2cfg == 0) rc = conv_v3s_dispatch(p, a->impl == 71 || a->impl == 72 ? a->impl : 0, st);
     if (rc == -1000) rc = conv_v2s_dispatch(p, v2cfg, st);
     PP_REQUIRE(rc != -1000, PP_ERR_ARG, "pp_conv2d: no split-plane kernel for this layer (split %d, kchunks %d, %dx%d taps, impl %d)", a->split,
                a->kchunks, a->tap_h, a->tap_w, a->impl);
@@ -609,13 +608,7 @@ extern "C" int pp_conv2d(const pp_conv_args_t* a, void* stream) {
     if (rc != -1000) return rc;
     PP_REQUIRE(a->impl == 0, PP_ERR_ARG, "pp_conv2d: impl 110 (streaming head kernel) not available for this layer");
   }
-  if (a->dtype == PP_F16 && !deform && (a->impl == 0 || a->impl == 107)) {
-    // wide halo tiles (256 px x 128 couts per block, 128 x 64 wave tiles): large maps with full 128-cout tiles
-    const int rc = conv_v4_dispatch(p, a->impl, st);
-    if (rc != -1000) return rc;
-    PP_REQUIRE(a->impl == 0, PP_ERR_ARG, "pp_conv2d: impl %d (wide halo tiles) not available for this shape", a->impl);
-  }
-  if (a->dtype == PP_F16 && !deform && (a->impl == 0 || (a->impl >= 70 && a->impl < 80) || (a->impl >= 82 && a->impl <= 89) || a->impl == 106 || a->impl == 109 || (a->impl >= 111 && a->impl <= 118))) {
+  if (a->dtype == PP_F16 && !deform && (a->impl == 0 || (a->impl >= 70 && a->impl < 80) || a->impl == 109)) {
     // halo-tile kernel family (stride-1 "same" 3x3 / 1x5 / 5x1 windows over 64-channel-multiple sources)
     const int rc = conv_v3_dispatch(p, a->impl, st);
     if (rc != -1000) return rc;

@@ -21,9 +21,6 @@
 //        keeps ((row >> 1) & 7): its fragments start at multiples of 16 rows.
 //   4 waves (2 x 2), wave tile 64 px x BN/2 couts, v_mfma_f32_16x16x32_f16, fp32 accumulate.  Epilogue as in v2.
 #include "conv_halo.h"
-#if defined(PP_DIAG)
-#include "conv_halo_pipe.h"
-#endif
 #include <stdlib.h>
 
 namespace pp {
@@ -52,18 +49,6 @@ static int launch_tiny(const ConvParams& p, hipStream_t stream) {     // 16-cout
   return halo_shared_weights() ? launch_v3<TH, TW, KH, KW, 16>(p, stream) : launch_v3<TH, TW, KH, KW, 16, false, 0, 64, false, true>(p, stream);
 }
 
-#if defined(PP_DIAG)
-// [diagnostic] row-major packed weights [cout_pad][kchunks] (16-byte chunks) -> fragment-major: block (cb = row / 16, ks = chunk / 8,
-// kk = (chunk / 4) & 1) is one contiguous KB whose lane l4 * 16 + l15 (l15 = row % 16, l4 = chunk % 4) owns 16 bytes
-__global__ void repack_fragment_major_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int cout_pad, int kchunks) {
-  const long long i = blockIdx.x * 256ll + threadIdx.x;
-  if (i >= (long long)cout_pad * kchunks) return;
-  const int row = (int)(i / kchunks), c = (int)(i % kchunks);
-  const int cb = row >> 4, l15 = row & 15, ks = c >> 3, kk = (c >> 2) & 1, l4 = c & 3;
-  dst[(((long long)cb * (kchunks / 8) + ks) * 2 + kk) * 64 + l4 * 16 + l15] = src[i];
-}
-#endif
-
 // Returns -1000 when the shape is outside the halo-tile family (caller falls back to v2).
 // cfg: 0 = auto, 70 = force (BN by cout), 71 = BN 128, 72 = BN 64.
 int conv_v3_dispatch(const ConvParams& p, int cfg, hipStream_t stream) {
@@ -88,116 +73,14 @@ int conv_v3_dispatch(const ConvParams& p, int cfg, hipStream_t stream) {
     if (kh == 5 && kw == 1) return launch_tiny<16, 8, 5, 1>(p, stream);
     return -1000;
   }
-#if defined(PP_DIAG)      // tuning / diagnostic variants (tools/kbench, PP_DIAG=1 builds only; measured in profiles/r2_conv_epilogue_ab.txt)
-  if (cfg == 116) {   // software-pipelined form (conv_halo_pipe.h): fragment reads of step k+1 under the MFMAs of step k -- bit-identical, 2-6 % SLOWER (profiles/r3v_halo_pipelined.txt)
-    if (kh == 3 && kw == 3) return n64 ? launch_v3p<8, 16, 3, 3, 64, false>(p, stream) : launch_v3p<8, 16, 3, 3, 128, false>(p, stream);
-    if (kh == 1 && kw == 5) return n64 ? launch_v3p<8, 16, 1, 5, 64, false>(p, stream) : launch_v3p<8, 16, 1, 5, 128, false>(p, stream);
-    if (kh == 5 && kw == 1) return n64 ? launch_v3p<16, 8, 5, 1, 64, false>(p, stream) : launch_v3p<16, 8, 5, 1, 128, false>(p, stream);
-    return -1000;
-  }
-  if (cfg == 82) {   // round-1 patch swizzle ((row >> 1) & 7): 2-way bank conflicts at 24 of 32 fragment alignments
-    if (kh == 3 && kw == 3) return launch_v3<8, 16, 3, 3, 128, false, 5>(p, stream);
-    if (kh == 1 && kw == 5) return launch_v3<8, 16, 1, 5, 128, false, 5>(p, stream);
-    if (kh == 5 && kw == 1) return launch_v3<16, 8, 5, 1, 128, false, 5>(p, stream);
-    return -1000;
-  }
-  if (cfg == 106) {   // probe: 256 px x 128 couts per block, FOUR waves of 128 px x 64 couts (0.375 KB of fragment reads per MFMA
-                      // instead of 0.5, half the weight DMA per MFMA) -- one block per CU (120 KB LDS), one wave per SIMD
-    if (kh == 3 && kw == 3) return launch_v3<16, 16, 3, 3, 128, false, 0, 128>(p, stream);
-    if (kh == 1 && kw == 5) return launch_v3<16, 16, 1, 5, 128, false, 0, 128>(p, stream);
-    return -1000;
-  }
-  if (cfg == 117 || cfg == 118) {   // DIRB with the weights repacked fragment-major (coalesced 1 KB fragment loads); 118 = + phase timing
-    static char* d_frag = nullptr;
-    static const char* last_w = nullptr;
-    static size_t cap = 0, last_bytes = 0;
-    const size_t bytes = (size_t)p.cout_pad * p.kchunks * 16;
-    if (bytes > cap) { if (d_frag) hipFree(d_frag); if (hipMalloc((void**)&d_frag, bytes) != hipSuccess) return -1000; cap = bytes; last_w = nullptr; }
-    if (last_w != p.weight || last_bytes != bytes) {
-      const long long nchunk = (long long)bytes / 16;
-      hipLaunchKernelGGL(repack_fragment_major_kernel, dim3((unsigned)((nchunk + 255) / 256)), dim3(256), 0, stream,
-                         reinterpret_cast<const uint4*>(p.weight), reinterpret_cast<uint4*>(d_frag), p.cout_pad, p.kchunks);
-      last_w = p.weight; last_bytes = bytes;
-    }
-    ConvParams q = p;
-    q.weight = d_frag; q.wfrag = 1;
-    const bool pr = cfg == 118;
-    if (kh == 3 && kw == 3) return pr ? launch_v3<8, 16, 3, 3, 128, true, 0, 64, false, false, true>(q, stream) : launch_v3<8, 16, 3, 3, 128, false, 0, 64, false, false, true>(q, stream);
-    if (kh == 1 && kw == 5) return pr ? launch_v3<8, 16, 1, 5, 128, true, 0, 64, false, false, true>(q, stream) : launch_v3<8, 16, 1, 5, 128, false, 0, 64, false, false, true>(q, stream);
-    if (kh == 5 && kw == 1) return pr ? launch_v3<16, 8, 5, 1, 128, true, 0, 64, false, false, true>(q, stream) : launch_v3<16, 8, 5, 1, 128, false, 0, 64, false, false, true>(q, stream);
-    return -1000;
-  }
-  if (cfg == 112 || cfg == 113) {   // weight fragments straight from L2 into registers, one step ahead (DIRB); 113 = + phase timing
-    if (kh == 3 && kw == 3) return cfg == 112 ? launch_v3<8, 16, 3, 3, 128, false, 0, 64, false, false, true>(p, stream) : launch_v3<8, 16, 3, 3, 128, true, 0, 64, false, false, true>(p, stream);
-    if (kh == 1 && kw == 5) return cfg == 112 ? launch_v3<8, 16, 1, 5, 128, false, 0, 64, false, false, true>(p, stream) : launch_v3<8, 16, 1, 5, 128, true, 0, 64, false, false, true>(p, stream);
-    if (kh == 5 && kw == 1) return cfg == 112 ? launch_v3<16, 8, 5, 1, 128, false, 0, 64, false, false, true>(p, stream) : launch_v3<16, 8, 5, 1, 128, true, 0, 64, false, false, true>(p, stream);
-    return -1000;
-  }
-  if (cfg == 114 || cfg == 115) {   // all 16 fragment reads of a step ahead of its MFMAs; 115 = + phase timing
-    if (kh == 3 && kw == 3) return cfg == 114 ? launch_v3<8, 16, 3, 3, 128, false, 13>(p, stream) : launch_v3<8, 16, 3, 3, 128, true, 13>(p, stream);
-    if (kh == 1 && kw == 5) return cfg == 114 ? launch_v3<8, 16, 1, 5, 128, false, 13>(p, stream) : launch_v3<8, 16, 1, 5, 128, true, 13>(p, stream);
-    if (kh == 5 && kw == 1) return cfg == 114 ? launch_v3<16, 8, 5, 1, 128, false, 13>(p, stream) : launch_v3<16, 8, 5, 1, 128, true, 13>(p, stream);
-    return -1000;
-  }
-  if (cfg == 111) {   // weight pieces of a wave 4 KB apart, M0 rewritten per piece (the layout before the one-M0 / instruction-offset form)
-    if (kh == 3 && kw == 3) return launch_v3<8, 16, 3, 3, 128, false, 12>(p, stream);
-    if (kh == 1 && kw == 5) return launch_v3<8, 16, 1, 5, 128, false, 12>(p, stream);
-    if (kh == 5 && kw == 1) return launch_v3<16, 8, 5, 1, 128, false, 12>(p, stream);
-    return -1000;
-  }
-  if (cfg == 109) {   // the pre-activation addend / residual read by the epilogue instead of going through the matrix cores (A/B)
+  if (cfg == 109) {   // the pre-activation addend / residual read by the epilogue instead of going through the matrix cores (A/B; tests/test_ops_gpu.py)
     if (kh == 3 && kw == 3) return launch_v3<8, 16, 3, 3, 128, false, 11>(p, stream);
     if (kh == 1 && kw == 5) return launch_v3<8, 16, 1, 5, 128, false, 11>(p, stream);
     if (kh == 5 && kw == 1) return launch_v3<16, 8, 5, 1, 128, false, 11>(p, stream);
     return -1000;
   }
-  if (cfg == 85) {   // 8 waves of 32 x 64 per 128 x 128 block tile, 4 waves per SIMD
-    if (kh == 3 && kw == 3) return launch_v3<8, 16, 3, 3, 128, false, 0, 32>(p, stream);
-    if (kh == 1 && kw == 5) return launch_v3<8, 16, 1, 5, 128, false, 0, 32>(p, stream);
-    if (kh == 5 && kw == 1) return launch_v3<16, 8, 5, 1, 128, false, 0, 32>(p, stream);
-    return -1000;
-  }
-  if (cfg >= 86 && cfg <= 89) {   // ablations (WRONG RESULTS by design): 86 no weight DMA, 87 no MFMA, 88 no fragment reads, 89 no DMA
-    if (kh == 1 && kw == 5) {
-      if (cfg == 86) return launch_v3<8, 16, 1, 5, 128, false, 6>(p, stream);
-      if (cfg == 87) return launch_v3<8, 16, 1, 5, 128, false, 7>(p, stream);
-      if (cfg == 88) return launch_v3<8, 16, 1, 5, 128, false, 8>(p, stream);
-      return launch_v3<8, 16, 1, 5, 128, false, 9>(p, stream);
-    }
-    return -1000;
-  }
-  if (cfg == 76 || cfg == 77) {   // staggered start (76) / + phase timing (77)
-    if (kh == 3 && kw == 3) return cfg == 76 ? launch_v3<8, 16, 3, 3, 128, false, 1>(p, stream) : launch_v3<8, 16, 3, 3, 128, true, 2>(p, stream);
-    if (kh == 1 && kw == 5) return cfg == 76 ? launch_v3<8, 16, 1, 5, 128, false, 1>(p, stream) : launch_v3<8, 16, 1, 5, 128, true, 2>(p, stream);
-    if (kh == 5 && kw == 1) return cfg == 76 ? launch_v3<16, 8, 5, 1, 128, false, 1>(p, stream) : launch_v3<16, 8, 5, 1, 128, true, 2>(p, stream);
-    return -1000;
-  }
-  if (cfg == 74 || cfg == 78) {   // variant: weight DMA interleaved with the MFMAs (74) / + phase timing (78)
-    if (kh == 3 && kw == 3) return cfg == 74 ? launch_v3<8, 16, 3, 3, 128, false, 3>(p, stream) : launch_v3<8, 16, 3, 3, 128, true, 3>(p, stream);
-    if (kh == 1 && kw == 5) return cfg == 74 ? launch_v3<8, 16, 1, 5, 128, false, 3>(p, stream) : launch_v3<8, 16, 1, 5, 128, true, 3>(p, stream);
-    if (kh == 5 && kw == 1) return cfg == 74 ? launch_v3<16, 8, 5, 1, 128, false, 3>(p, stream) : launch_v3<16, 8, 5, 1, 128, true, 3>(p, stream);
-    return -1000;
-  }
-  if (cfg == 84) {   // 256 px x 256 couts per block, 8 waves of 64 px x 128 couts (experimental: compile-checked only)
-    if (p.cout_g < 192) return -1000;
-    if (kh == 3 && kw == 3) return launch_v3<16, 16, 3, 3, 256>(p, stream);
-    if (kh == 1 && kw == 5) return launch_v3<16, 16, 1, 5, 256>(p, stream);
-    if (kh == 5 && kw == 1) return launch_v3<16, 16, 5, 1, 256>(p, stream);
-    return -1000;
-  }
-  if (cfg == 83) {   // A fragments requested ahead of the step barrier (experimental: compile-checked only)
-    if (kh == 3 && kw == 3) return launch_v3<8, 16, 3, 3, 128, false, 4>(p, stream);
-    if (kh == 1 && kw == 5) return launch_v3<8, 16, 1, 5, 128, false, 4>(p, stream);
-    if (kh == 5 && kw == 1) return launch_v3<16, 8, 5, 1, 128, false, 4>(p, stream);
-    return -1000;
-  }
-  if (cfg == 79) {   // 256-pixel tiles, 8 waves, one block per CU: the weight tile is fetched from L2 once per CU and step
-    if (kh == 3 && kw == 3) return launch_v3<16, 16, 3, 3, 128>(p, stream);
-    if (kh == 1 && kw == 5) return launch_v3<16, 16, 1, 5, 128>(p, stream);
-    if (kh == 5 && kw == 1) return launch_v3<16, 16, 5, 1, 128>(p, stream);
-    return -1000;
-  }
-  if (cfg == 75) {   // diagnostic: phase timing (BN 128)
+#if defined(PP_DIAG)      // tools/kbench --prof: in-kernel phase stamps (BN 128); every other schedule experiment of rounds 2-3 lives in experiments/
+  if (cfg == 75) {
     if (kh == 3 && kw == 3) return launch_v3<8, 16, 3, 3, 128, true>(p, stream);
     if (kh == 1 && kw == 5) return launch_v3<8, 16, 1, 5, 128, true>(p, stream);
     if (kh == 5 && kw == 1) return launch_v3<16, 8, 5, 1, 128, true>(p, stream);

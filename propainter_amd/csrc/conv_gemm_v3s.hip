@@ -6,9 +6,6 @@
 // three products -- the LDS-DMA gather, the swizzles and the LDS image are the fp16 kernel's own (a 128-byte patch row = [hi | lo]).
 // The epilogue reads its operands as hi + lo and writes two planes (conv_epilogue.h, SPLIT).
 #include "conv_halo.h"
-#if defined(PP_DIAG)
-#include "conv_halo_pipe.h"
-#endif
 #include <stdlib.h>
 
 namespace pp {
@@ -46,13 +43,6 @@ int conv_v3s_dispatch(const ConvParams& p, int cfg, hipStream_t stream) {
     q.preadd = p.residual; q.preadd_cstride = p.res_cstride; q.preadd_choff = p.res_choff; q.preadd_lo = p.res_lo;
     q.residual = nullptr; q.act = p.act2; q.act_param = 0.f; q.act2 = PP_ACT_NONE;
   }
-#if defined(PP_DIAG)      // (diagnostic builds: measured neutral to 3 % slower on the split-plane layers, profiles/r3v_halo_pipelined.txt)
-  if (cfg == 116 && bn != 16) {   // software-pipelined form (conv_halo_pipe.h)
-    if (kh == 3) return bn == 64 ? launch_v3p<8, 16, 3, 3, 64, true>(q, stream) : launch_v3p<8, 16, 3, 3, 128, true>(q, stream);
-    if (kh == 1) return bn == 64 ? launch_v3p<8, 16, 1, 5, 64, true>(q, stream) : launch_v3p<8, 16, 1, 5, 128, true>(q, stream);
-    return bn == 64 ? launch_v3p<16, 8, 5, 1, 64, true>(q, stream) : launch_v3p<16, 8, 5, 1, 128, true>(q, stream);
-  }
-#endif
   static const bool shared_w = !(getenv("PP_HALO_PRIVATE_WEIGHTS") != nullptr && getenv("PP_HALO_PRIVATE_WEIGHTS")[0] == '1');
   if (kh == 3) return launch_v3s<3, 3>(q, bn, shared_w, stream);
   if (kh == 1) return launch_v3s<1, 5>(q, bn, shared_w, stream);

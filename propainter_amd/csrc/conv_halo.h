@@ -58,7 +58,7 @@ static __device__ unsigned long long g_v3_prof[16];     // (per translation unit
 #else
 #define HALO_MIN_WAVES(th, tw, bn, wmt, split) ((th) * (tw) == 128 && (wmt) == 64 && (bn) <= 128 ? 2 : 1)
 #endif
-template <int TH, int TW, int KH, int KW, int BN, bool PROF = false, int STAGGER = 0, int WMT = 64, bool SPLIT = false, bool PRIVB = false, bool DIRB = false>
+template <int TH, int TW, int KH, int KW, int BN, bool PROF = false, int STAGGER = 0, int WMT = 64, bool SPLIT = false, bool PRIVB = false>
 __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : HALO_MIN_WAVES(TH, TW, BN, WMT, SPLIT)) void conv_halo_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef _Float16 T;
@@ -73,7 +73,6 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : HALO_MIN_WAVES
   constexpr int PPW = PIECES / NW;                              // ... per wave
   constexpr int PATCH_BYTES = PIECES * 1024;
   static_assert(!PRIVB || (BN <= 64 && STAGGER == 0 && WMT == 64), "private weight stages: tiles of at most 64 couts");
-  static_assert(!DIRB || (!PRIVB && STAGGER == 0 && WMT == 64), "direct weight fragments: the plain schedule only");
   constexpr int BW_ROWS = PRIVB ? WN : BN;                     // weight rows of one stage buffer (the wave's own couts when private)
   constexpr int BSTAGE = BW_ROWS * 128;
   constexpr int B_INST = BW_ROWS / 8;                          // weight-tile DMA instructions per stage (8 rows each)
@@ -81,13 +80,13 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : HALO_MIN_WAVES
   constexpr bool B_RAGGED = !PRIVB && (B_INST % NW) != 0;      // BN 16, shared stages: only waves 0..B_INST-1 fetch weights
   // BCONTIG (shared stages): a wave's B_PER_WAVE weight pieces are CONSECUTIVE 8-row groups of the stage, so one M0 value + the
   // instruction offset addresses all of them (an M0 rewrite between two LDS-DMA instructions serialises them)
-  constexpr bool BCONTIG = !PRIVB && STAGGER != 3 && STAGGER != 12 && B_PER_WAVE <= 4;
-  constexpr int PIPE_BYTES = 2 * PATCH_BYTES + (DIRB ? 0 : (PRIVB ? 2 * NW : 2) * BSTAGE);
+  constexpr bool BCONTIG = !PRIVB && B_PER_WAVE <= 4;
+  constexpr int PIPE_BYTES = 2 * PATCH_BYTES + (PRIVB ? 2 * NW : 2) * BSTAGE;
   constexpr int EPI_WN = WN > 64 ? 64 : WN;                    // the epilogue stages at most 64 couts of the wave tile at a time
   constexpr int EPI_LD = EPI_WN + 4;
   constexpr int EPI_BYTES = NW * WM * EPI_LD * 4;
   constexpr int LDS_BYTES = PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES;
-  constexpr bool PRE_MFMA = (STAGGER == 0 || STAGGER == 12 || STAGGER == 13) && BM == 128 && (BN == 128 || BN == 64) && WMT == 64 && PATCH_BYTES >= 16 * 1024;   // (STAGGER 11, impl 109: off, for A/B)
+  constexpr bool PRE_MFMA = STAGGER == 0 && BM == 128 && (BN == 128 || BN == 64) && WMT == 64 && PATCH_BYTES >= 16 * 1024;   // (STAGGER 11, impl 109: off, for A/B)
   static_assert((BM == 128 || BM == 256) && (TW == 16 || TW == 8) && PPW <= 3 * NTAPS && (BN % 32 == 0 || BN == 16) &&
                     LDS_BYTES <= (BM == 128 ? 80 : 160) * 1024, "tile");
 
@@ -122,7 +121,7 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : HALO_MIN_WAVES
   // (q*8 + rin) >> 1 & 7 == (4*q + (rin >> 1)) & 7 and q has the parity of `wave` (NW is even): one logical chunk per lane.
   const int rin = lane >> 3, slot = lane & 7;
   const int lc = slot ^ ((4 * (wave & 1) + (rin >> 1)) & 7);        // weight rows: slot ^ ((row >> 1) & 7)
-  const int lca = STAGGER == 5 ? lc : (slot ^ rin);                 // patch rows: slot ^ (row & 7); piece rows start at multiples of 8
+  const int lca = slot ^ rin;                                       // patch rows: slot ^ (row & 7); piece rows start at multiples of 8
   int ppix[PPW];                                          // global pixel index of the lane's patch row, -1 = zero fill
 #pragma unroll
   for (int j = 0; j < PPW; ++j) {
@@ -165,11 +164,7 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : HALO_MIN_WAVES
   } while (0)
 #define V3_ISSUE_B(ks_, par_)                                                                                   \
   do {                                                                                                          \
-    if constexpr (DIRB) {                                                                                       \
-      _Pragma("unroll") for (int kk_ = 0; kk_ < 2; ++kk_)                                                       \
-        _Pragma("unroll") for (int f_ = 0; f_ < TN; ++f_)                                                       \
-          bnxt[kk_][f_] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, bvo[f_], p.wfrag ? (ks_) * 2048 + kk_ * 1024 : (ks_) * 128 + kk_ * 64, 0)); \
-    } else if constexpr (BCONTIG) {                                                                                    \
+    if constexpr (BCONTIG) {                                                                                    \
       if (!B_RAGGED || wave < B_INST)                                                                           \
         V3WeightPieces<0, B_PER_WAVE>::issue(rw, bst0 + (par_) * BSTAGE + wave * B_PER_WAVE * 1024, wvoff, (ks_) * 128); \
     } else {                                                                                                    \
@@ -194,32 +189,8 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : HALO_MIN_WAVES
   }
   const int b_off = (PRIVB ? l15 : wn * WN + l15) * 128;
   const int bswz = (l15 >> 1) & 7;
-  // DIRB: the weight fragments never pass through LDS -- every lane fetches its own 16 bytes of the NEXT step's B fragments from L2
-  // (row = cout, 64 contiguous bytes per cout and K half; rows past cout_pad are out of the buffer's range and read as zero) one
-  // step ahead, straight into registers: no weight stages, no weight DMA issue, no B ds_reads, and the block barrier only when a new
-  // patch becomes current.  The two waves that share a cout half fetch the same lines (the second one hits the CU's L1).
-  int bvo[DIRB ? TN : 1];
-  f16x8 bcur[2][DIRB ? TN : 1], bnxt[2][DIRB ? TN : 1];
-  if constexpr (DIRB) {
-#pragma unroll
-    for (int f = 0; f < TN; ++f)
-      bvo[f] = p.wfrag ? ((n0 + wn * WN) / 16 + f) * (p.kchunks / 8) * 2048 + lane * 16      // fragment-major: block (cb, ks, kk) = 1 KB, lane-linear
-                       : (n0 + wn * WN + f * 16 + l15) * (p.kchunks * 16) + l4 * 16;
-  }
-
   const int nblocks = p.kchunks / (8 * NTAPS);
   const int nk = nblocks * NTAPS;
-  if constexpr (STAGGER == 1) {
-    // De-phase the resident blocks.  All blocks of a launch start together and take the same time, so without this all
-    // ~512 resident tiles reach their epilogue at once: a 16 MB store burst at HBM write speed with nothing to overlap,
-    // once per round.  The first generation of blocks sleeps 0..7/8 of a tile time (phase = bits 3..5 of the block id, so
-    // every XCD gets every phase); later blocks are dispatched as slots free up and inherit the spread.
-    if (blockIdx.x < 512u && gridDim.x >= 1536u) {
-      const int phase = (blockIdx.x >> 3) & 7;
-      const int iters = (phase * nk * 1700 / 8) >> 12;          // ~4096 cycles per iteration (64 x s_sleep 64 cycles)
-      for (int i = 0; i < iters; ++i) __builtin_amdgcn_s_sleep(64);
-    }
-  }
   unsigned long long pf_wait = 0, pf_vm = 0, pf_issue = 0, pf_comp = 0, pf_t0 = 0, pf_a = 0, pf_b = 0, pf_c = 0;
   if constexpr (PROF) pf_t0 = __builtin_readcyclecounter();
   // ---- prologue: patch of block 0 (all pieces) + weights of step 0
@@ -248,23 +219,7 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : HALO_MIN_WAVES
 #pragma unroll
     for (int t = 0; t < NTAPS; ++t) {
       if constexpr (PROF) pf_a = __builtin_readcyclecounter();
-      // [variant STAGGER == 4, impl 83, NOT yet run on a GPU] the patch is resident for the whole channel block, so for
-      // t > 0 the A fragments of this step can be requested BEFORE the barrier: their LDS latency hides behind the wait
-      // for the weight tile.  (t == 0 reads a patch other waves may still be receiving: after the barrier.)
       const int sh = (t / KW) * PW + (t % KW);          // compile-time after unrolling
-      f16x8 afp[2][TM];
-      if constexpr (STAGGER == 4) {
-        if (t > 0) {
-#pragma unroll
-          for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int f = 0; f < TM; ++f) {
-              const int row = pp0[f] + sh;
-              afp[kk][f] = *reinterpret_cast<const f16x8*>(pcur + row * 128 + (((kk * 4 + l4) ^ (row & 7)) << 4));
-            }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
       if constexpr (PRIVB) {
         // the wave's own weight stage of this step was requested one step ago, BEFORE that step's patch pieces: at most PCP younger
         // requests (pieces of the next block's patch) may stay in flight.  Only the first tap of a channel block needs the block: the
@@ -279,25 +234,17 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : HALO_MIN_WAVES
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       if constexpr (PROF) { pf_b = __builtin_readcyclecounter(); pf_vm += pf_b - pf_a; }
-      if constexpr (DIRB) {                                          // this step's fragments arrived with the wait above
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-          for (int f = 0; f < TN; ++f) bcur[kk][f] = bnxt[kk][f];
-      }
-      if ((!PRIVB && !DIRB) || t == 0) __builtin_amdgcn_s_barrier();          // weights of step ks (and, at t == 0, the whole patch of this block) are in LDS
+      if (!PRIVB || t == 0) __builtin_amdgcn_s_barrier();          // weights of step ks (and, at t == 0, the whole patch of this block) are in LDS
       if constexpr (PROF) { pf_c = __builtin_readcyclecounter(); pf_wait += pf_c - pf_b; }
       if (t == 0 && have_next) {
         v3_entry_ready(en);
         if constexpr (SPLIT) { v3_entry_ready(enl); lobn = (enl[3] - en[3]) * 2; }
       }
       const bool more_b = ks + 1 < nk;
-      if constexpr (STAGGER != 3 && STAGGER != 6 && STAGGER != 9) { if (more_b) V3_ISSUE_B(ks + 1, par ^ 1); }
-      if constexpr (STAGGER != 9) {
-        if (have_next) {
+      if (more_b) V3_ISSUE_B(ks + 1, par ^ 1);
+      if (have_next) {
 #pragma unroll
-          for (int jj = t; jj < PPW; jj += NTAPS) V3_ISSUE_PIECE(jj, pnext, en, lobn);     // (one piece per step for the shipped tiles: PPW <= NTAPS)
-        }
+        for (int jj = t; jj < PPW; jj += NTAPS) V3_ISSUE_PIECE(jj, pnext, en, lobn);     // (one piece per step for the shipped tiles: PPW <= NTAPS)
       }
       if constexpr (PROF) { pf_a = __builtin_readcyclecounter(); pf_issue += pf_a - pf_c; }
       const char* sb = bst0 + (PRIVB ? wave * 2 + par : par) * BSTAGE;
@@ -314,8 +261,7 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : HALO_MIN_WAVES
           }
 #pragma unroll
           for (int f = 0; f < TN; ++f) {
-            if constexpr (DIRB) bf[kk][f] = bcur[kk][f];
-            else bf[kk][f] = *reinterpret_cast<const f16x8*>(sb + b_off + f * 16 * 128 + (((kk * 4 + l4) ^ bswz) << 4));
+            bf[kk][f] = *reinterpret_cast<const f16x8*>(sb + b_off + f * 16 * 128 + (((kk * 4 + l4) ^ bswz) << 4));
           }
         }
 #pragma unroll
@@ -330,10 +276,10 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : HALO_MIN_WAVES
         for (int a = 0; a < TN; ++a)
 #pragma unroll
           for (int b = 0; b < TM; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[0][a], af[0][b], acc[a][b], 0, 0, 0);   // W_hi x A_hi
-      } else if constexpr ((STAGGER == 0 || STAGGER == 13) && BN == 128 && WMT == 64 && BM == 128 && !DIRB) {
+      } else if constexpr (STAGGER == 0 && BN == 128 && WMT == 64 && BM == 128) {
         // the fragments of BOTH K halves are requested before the first MFMA (32 more live fragment registers; 231 in all for 3x3): the
         // reads of the second half complete under the 16 MFMAs of the first instead of being waited for in four small groups
-        // (+1.5 % on average over seven layer shapes, bit-identical: profiles/r3q_halo_kernel_phases.txt; impl 111 = the interleaved form)
+        // (+1.5 % on average over seven layer shapes, bit-identical: profiles/r3q_halo_kernel_phases.txt)
         f16x8 af[2][TM], bf[2][TN];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -359,42 +305,15 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : HALO_MIN_WAVES
         f16x8 af[TM], bf[TN];
 #pragma unroll
         for (int f = 0; f < TM; ++f) {
-          if (STAGGER == 4 && t > 0) {
-            af[f] = afp[kk][f];
-          } else if constexpr (STAGGER == 8) {      // [ablation] no fragment reads
-            af[f] = f16x8{(_Float16)1, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)(float)f};
-          } else {
-            const int row = pp0[f] + sh;
-            af[f] = *reinterpret_cast<const f16x8*>(pcur + row * 128 + (((kk * 4 + l4) ^ (STAGGER == 5 ? (row >> 1) & 7 : row & 7)) << 4));
-          }
+          const int row = pp0[f] + sh;
+          af[f] = *reinterpret_cast<const f16x8*>(pcur + row * 128 + (((kk * 4 + l4) ^ (row & 7)) << 4));
         }
 #pragma unroll
-        for (int f = 0; f < TN; ++f) {
-          if constexpr (DIRB) bf[f] = bcur[kk][f];
-          else if constexpr (STAGGER == 8) bf[f] = f16x8{(_Float16)1, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)(float)f};
-          else bf[f] = *reinterpret_cast<const f16x8*>(sb + b_off + f * 16 * 128 + (((kk * 4 + l4) ^ bswz) << 4));
-        }
-        if constexpr (STAGGER == 7) {               // [ablation] no MFMA: keep the fragments alive only
+        for (int f = 0; f < TN; ++f) bf[f] = *reinterpret_cast<const f16x8*>(sb + b_off + f * 16 * 128 + (((kk * 4 + l4) ^ bswz) << 4));
 #pragma unroll
-          for (int f = 0; f < TM; ++f) asm volatile("" ::"v"(af[f]));
+        for (int a = 0; a < TN; ++a)
 #pragma unroll
-          for (int f = 0; f < TN; ++f) asm volatile("" ::"v"(bf[f]));
-        }
-#pragma unroll
-        for (int a = 0; a < TN; ++a) {
-#pragma unroll
-          for (int b = 0; b < TM; ++b)
-            if constexpr (STAGGER != 7) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[a], af[b], acc[a][b], 0, 0, 0);
-          if constexpr (STAGGER == 3) {
-            // [variant] next step's weight DMA interleaved with the MFMA groups of kk == 0 (one instruction per group) instead
-            // of a burst after the barrier: the TA queue is shared by 8 waves, a burst costs ~100 cycles per instruction
-            if (kk == 0 && a < B_PER_WAVE && more_b && (!B_RAGGED || a * NW + wave < B_INST)) {
-              __builtin_amdgcn_sched_barrier(0);
-              v3_dma16(rw, bst0 + (par ^ 1) * BSTAGE + (a * NW + wave) * 1024, wvoff[a], (ks + 1) * 128);
-              __builtin_amdgcn_sched_barrier(0);
-            }
-          }
-        }
+          for (int b = 0; b < TM; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[a], af[b], acc[a][b], 0, 0, 0);
       }
       }
       if constexpr (PROF) { asm volatile("s_nop 0" ::: "memory"); pf_comp += __builtin_readcyclecounter() - pf_a; }
@@ -492,13 +411,13 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : HALO_MIN_WAVES
 #endif
 }
 
-template <int TH, int TW, int KH, int KW, int BN, bool PROF = false, int STAGGER = 0, int WMT = 64, bool SPLIT = false, bool PRIVB = false, bool DIRB = false>
+template <int TH, int TW, int KH, int KW, int BN, bool PROF = false, int STAGGER = 0, int WMT = 64, bool SPLIT = false, bool PRIVB = false>
 static int launch_v3(ConvParams p, hipStream_t stream) {
   p.tiles_n = (p.cout_g + BN - 1) / BN;
   const long long tiles = (long long)p.N * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
   const long long nblk = tiles * p.tiles_n;
   if (nblk >= (1ll << 31)) return -1000;
-  hipLaunchKernelGGL((conv_halo_kernel<TH, TW, KH, KW, BN, PROF, STAGGER, WMT, SPLIT, PRIVB, DIRB>), dim3((unsigned)nblk), dim3(TH * TW * 128 / WMT), 0, stream, p);
+  hipLaunchKernelGGL((conv_halo_kernel<TH, TW, KH, KW, BN, PROF, STAGGER, WMT, SPLIT, PRIVB>), dim3((unsigned)nblk), dim3(TH * TW * 128 / WMT), 0, stream, p);
   return launch_status("pp_conv2d(v3)");
 }
 

@@ -48,9 +48,6 @@ struct ConvParams {
   // plain fp32 output without epilogue operands: store the accumulators directly (4 consecutive couts = 16 bytes per lane, 64 contiguous
   // bytes per pixel row and MFMA tile) instead of staging them through LDS -- short-K, output-bound launches (the correlation-volume GEMM)
   int epi_direct;
-  // [PP_DIAG] DIRB halo variant: `weight` holds the FRAGMENT-MAJOR repack (one contiguous KB per (16-cout block, K step, K half): lane
-  // l4 * 16 + l15 owns 16 bytes) instead of row-major rows -- every B-fragment load is one coalesced 1 KB request
-  int wfrag;
 };
 
 // activation of the late (post-staging) epilogue path: same fast forms as the register path of conv_epilogue.h
@@ -68,8 +65,6 @@ int conv_v3_dispatch(const ConvParams& p, int cfg, hipStream_t stream);
 // conv_gemm_v3s.hip / conv_gemm_v2s.hip: the same kernels with split-plane epilogues (p.split); -1000 outside the family
 int conv_v3s_dispatch(const ConvParams& p, int cfg, hipStream_t stream);
 int conv_v2s_dispatch(const ConvParams& p, int cfg, hipStream_t stream);
-// conv_gemm_v4.hip (wide halo tiles: 256 px x 128 couts, 32-channel steps); returns -1000 outside that family (caller falls back to v3)
-int conv_v4_dispatch(const ConvParams& p, int cfg, hipStream_t stream);
 // conv_dcn.hip (patch-staged modulated deformable 3x3 convolution, fp16); returns -1000 when the layer is outside that family
 int conv_dcn_dispatch(const ConvParams& p, hipStream_t stream, int dbg = 0);
 // conv_head.hip (streaming 3x3 convolution with at most 4 couts, VALU dot products); -1000 outside that family
