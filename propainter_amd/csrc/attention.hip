@@ -136,6 +136,32 @@ static __device__ __forceinline__ f16x4 lds_read_tr16(const _Float16* p) {
 // the matrix work.
 __device__ unsigned long long g_attn_prof[8];
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// Reductions over the four 16-lane rows of a wave (lanes l, l ^ 16, l ^ 32, l ^ 48 hold values of the same query) on the VALU:
+// v_permlane32_swap / v_permlane16_swap (gfx950) exchange half-waves / odd-even rows between two registers -- with both operands the
+// same value, the two results are the value and its partner's.  __shfl_xor is a ds_bpermute: an LDS round trip (~100+ cycles of
+// latency each, four in a row per tile of the online softmax).
+typedef unsigned int attn_u32x2 __attribute__((ext_vector_type(2)));
+// (elements through .x / .y and __uint_as_float: with __builtin_bit_cast(float, r[i]) hipcc 7.2 reads element 0 twice -- max(r0, r1)
+//  compiled to r0 and the reduction silently covered one row pair only; tools: grep the ISA for the v_max after the swap)
+static __device__ __forceinline__ float rows_max(float v) {
+  attn_u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const unsigned a0 = r.x, a1 = r.y;
+  v = fmaxf(__uint_as_float(a0), __uint_as_float(a1));
+  r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const unsigned b0 = r.x, b1 = r.y;
+  return fmaxf(__uint_as_float(b0), __uint_as_float(b1));
+}
+static __device__ __forceinline__ float rows_sum(float v) {
+  attn_u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const unsigned a0 = r.x, a1 = r.y;
+  v = __uint_as_float(a0) + __uint_as_float(a1);
+  r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const unsigned b0 = r.x, b1 = r.y;
+  return __uint_as_float(b0) + __uint_as_float(b1);
+}
+#endif
+
 template <int QT, bool MASKED, bool PROF>
 __device__ __forceinline__ void attn_block(const AttnParams& p, const int b, const int w, const int head, const int yb,
                                            _Float16* Ks, _Float16* Vs, int* idx_lds, int* tind_lds, int* koff_lds) {
@@ -285,6 +311,10 @@ __device__ __forceinline__ void attn_block(const AttnParams& p, const int b, con
     const bool more = ti + 1 < ntiles;                  // next tile: its four quarters are requested inside the kt loop below
     if constexpr (PROF) { tb = __builtin_readcyclecounter(); pf[2] += tb - ta; }
 
+    // the next tile's eight loads per lane are requested in ONE batch ahead of the S^T MFMAs: their address lookups (key frame, row
+    // offsets: LDS) then cost one wait instead of one per quarter in between the fragment reads (S phase 2 308 -> 1 829 cycles per
+    // wave and tile, profiles/r4_attention.txt)
+    if (more) load_tile(fi_n, r0_n);
     // ---- S^T tiles: sacc[qt][kt][r] = score(key = k0 + kt*16 + (lane>>4)*4 + r, query = lane&15 of tile qt)
     f32x4 sacc[QT][4];
 #pragma unroll
@@ -292,7 +322,6 @@ __device__ __forceinline__ void attn_block(const AttnParams& p, const int b, con
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) sacc[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
       const T* kp = &Ks[(kt * 16 + (lane & 15)) * KS_LD];
-      if (more) load_part(fi_n, r0_n, kt);              // in flight during the MFMAs
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const f16x8 kf = *reinterpret_cast<const f16x8*>(kp + (((s * 4 + (lane >> 4)) ^ (lane & 15)) << 3));
@@ -322,8 +351,7 @@ __device__ __forceinline__ void attn_block(const AttnParams& p, const int b, con
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, sacc[qt][kt][r]);
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+      tmax = rows_max(tmax);
       const float m_new = fmaxf(m_run[qt], tmax * sc2);
       const bool moved = m_new > m_run[qt];
       float psum = 0.f;
@@ -374,9 +402,7 @@ __device__ __forceinline__ void attn_block(const AttnParams& p, const int b, con
   }
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
-    float l = l_run[qt];
-    l += __shfl_xor(l, 16);
-    l += __shfl_xor(l, 32);
+    const float l = rows_sum(l_run[qt]);
     if (qvalid[qt] && otok[qt] >= 0) {
       const float inv = 1.f / l;
       // lane holds rows (lane>>4)*4 + r of every tile dt -> channels (lane>>4)*32 + dt*4 + r: 32 consecutive channels

@@ -66,7 +66,7 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.build(force=False, verbose=False)      # no-op unless the sources no longer match the built library
+    path = os.environ.get("PP_LIB_PATH") or _build.build(force=False, verbose=False)      # (build: no-op unless the sources no longer match the built library; PP_LIB_PATH: a tools/build_variant.sh library for A/B tuning runs)
     L = C.CDLL(path)
     L.pp_last_error_string.restype = C.c_char_p
     for name in ("pp_conv2d", "pp_sparse_window_attention"):
