@@ -119,6 +119,7 @@ class _GenEngine:
                 fc2=mk(sd[t + "mlp.fc2.1.weight"].view(HIDDEN, 40, 7, 7), sd[t + "mlp.fc2.1.bias"], stride=3, padding=3)))
         self._win_cache = {}
         self._tind_cache = {}
+        self.prop_batch_bytes = 2.5e9        # propagate_windows: bytes of one step-major batch of window frames
 
     # ------------------------------------------------------------------ encoder / decoder
     def encode(self, x):
@@ -233,19 +234,27 @@ class _GenEngine:
         clip["prop"] = {}
         for l_t, firsts in by_len.items():
             firsts = sorted(set(firsts))
-            B = len(firsts)
-            step = firsts[1] - firsts[0] if B > 1 else 1
-            if B < 2 or l_t < 2 or any(b - a != step for a, b in zip(firsts, firsts[1:])):
+            step = firsts[1] - firsts[0] if len(firsts) > 1 else 1
+            if len(firsts) < 2 or l_t < 2 or any(b - a != step for a, b in zip(firsts, firsts[1:])):
                 continue
-            # frame index of (step j, window k) = firsts[0] + step * k + j -- built on the device (capturable: no host copy)
-            base = torch.arange(B, device=dev) * step + firsts[0]
-            idx = (torch.arange(l_t, device=dev)[:, None] + base[None, :]).reshape(-1)
-            idxp = (torch.arange(l_t - 1, device=dev)[:, None] + base[None, :]).reshape(-1)
-            g5 = lambda src, ix, n: src.index_select(0, ix).view(n, B, h, w, src.shape[-1])
-            fused = self.feature_propagation(g5(enc, idx, l_t), None, None, None, clip["interpolation"],
-                                             rows=(g5(clip["aux_b"], idxp, l_t - 1), g5(clip["aux_f"], idxp, l_t - 1), g5(clip["mk8"], idx, l_t)))
-            for k, first in enumerate(firsts):
-                clip["prop"][(first, l_t)] = (fused, k)
+            # batches of at most `bmax` windows: the step-major gather of a batch stays below ~2.5 GB (five such tensors are alive during
+            # the chain; launches over >= 8 frames already run at the large-M rate, profiles/r4_batched_propagation.txt)
+            per_window = l_t * h * w * 128 * enc.element_size()
+            bmax = max(2, min(len(firsts), int(self.prop_batch_bytes // per_window)))
+            for b0 in range(0, len(firsts), bmax):
+                group = firsts[b0:b0 + bmax]
+                B = len(group)
+                if B < 2:
+                    continue                  # a single left-over window: per-window path
+                # frame index of (step j, window k) = group[0] + step * k + j -- built on the device (capturable: no host copy)
+                base = torch.arange(B, device=dev) * step + group[0]
+                idx = (torch.arange(l_t, device=dev)[:, None] + base[None, :]).reshape(-1)
+                idxp = (torch.arange(l_t - 1, device=dev)[:, None] + base[None, :]).reshape(-1)
+                g5 = lambda src, ix, n: src.index_select(0, ix).view(n, B, h, w, src.shape[-1])
+                fused = self.feature_propagation(g5(enc, idx, l_t), None, None, None, clip["interpolation"],
+                                                 rows=(g5(clip["aux_b"], idxp, l_t - 1), g5(clip["aux_f"], idxp, l_t - 1), g5(clip["mk8"], idx, l_t)))
+                for k, first in enumerate(group):
+                    clip["prop"][(first, l_t)] = (fused, k)
         return clip
 
     # ------------------------------------------------------------------ transformer

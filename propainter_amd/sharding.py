@@ -695,14 +695,20 @@ class StreamingClipGraph:
             for r, s in self.order:
                 st = self.streams[r]
                 with torch.cuda.stream(st):
-                    if s > 0:
-                        _, ex, bufs = self.graphs[r].segments[s - 1]
-                        for q, (shape, dtype) in sorted(ex.recv.items()):
-                            t = self.graphs[q].segments[s - 1][1].send[r]
-                            assert tuple(t.shape) == tuple(shape) and t.dtype == dtype, (ex.tag, r, q, t.shape, shape)
+                    if s > 0:                             # the sources of exchange s - 1 have delivered into this rank's receive buffers
+                        for q in sorted(self.graphs[r].segments[s - 1][1].recv):
                             st.wait_event(done[(q, s - 1)])
-                            bufs[q].copy_(t)
                     self.graphs[r].segments[s][0].replay()
+                    # PUSH: the sender delivers -- the copies of exchange s run on ITS stream, right behind the graph that produced the
+                    # tensors, into the receivers' static buffers (one per exchange and source: written once per pass, read by the receiver
+                    # only after the event below).  Round 3 had the RECEIVER copy on its own stream after waiting for the sender's event:
+                    # on MI355X that read stale tensors of the previous clip in ~1 of 4 passes (tools/diag_stream.py, profiles/r4_streaming_race.txt)
+                    ex_s = self.graphs[r].segments[s][1]
+                    if ex_s is not None:
+                        for q, t in sorted(ex_s.send.items()):
+                            shape, dtype = self.graphs[q].segments[s][1].recv[r]
+                            assert tuple(t.shape) == tuple(shape) and t.dtype == dtype, (ex_s.tag, r, q, t.shape, shape)
+                            self.graphs[q].segments[s][2][r].copy_(t)
                     ev = torch.cuda.Event()
                     ev.record(st)
                     done[(r, s)] = ev

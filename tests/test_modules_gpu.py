@@ -392,6 +392,15 @@ def test_batched_feature_propagation_is_bit_identical(models, fp16):
     g = ClipGraph(models, L, H, W, cfg, dev)(clip, masks, masks)
     torch.cuda.synchronize()
     assert torch.equal(g, outs[True])
+    # a small byte budget splits the 11 equal windows into batches of 4 + 4 + 3 (long clips / 1080p: the gather of a batch is bounded)
+    eng = models[2]._get_engine(torch.float16 if fp16 else torch.float32, dev)
+    saved = eng.prop_batch_bytes
+    try:
+        eng.prop_batch_bytes = 4.5 * 5 * (H // 4) * (W // 4) * 128 * (2 if fp16 else 4)
+        split = run_clip(models, clip, masks, masks, cfg, dev)
+    finally:
+        eng.prop_batch_bytes = saved
+    assert torch.equal(split, outs[True])
 
 
 @pytest.mark.parametrize("fp16", [False, True], ids=["f32", "f16"])
