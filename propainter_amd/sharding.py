@@ -16,6 +16,8 @@ process by handing the tensors over directly (single-GPU validation of the shard
 """
 from dataclasses import dataclass, field
 
+import os
+
 import numpy as np
 import torch
 
@@ -676,9 +678,21 @@ class StreamingClipGraph:
         self.order = wavefront_order(self.world, nseg, lambda r, s: sorted(self.graphs[r].segments[s][1].recv))
         return self
 
-    def replay(self, lockstep=False):
+    def replay(self, lockstep=False, concurrent=None):
         """One pass over the loaded clip.  lockstep=True: segment by segment over all ranks on the current stream (the schedule of
-        run_logical_shards_graphed: the A/B reference of the streaming order)."""
+        run_logical_shards_graphed: the A/B reference of the streaming order).
+
+        concurrent (default: env PP_STREAM_CONCURRENT == "1", else False): let the ranks' segment graphs overlap on their streams, ordered
+        by the exchange events only -- the schedule the class was built for.  ROUND-4 FINDING (tools/diag_stream.py,
+        profiles/r4_streaming_race.txt): on ROCm 7.2 / MI355X the FIRST concurrent pass after new inputs were loaded gives wrong frames in
+        ~40 % of the runs -- the RAFT segment of a later rank (no exchange before it, inputs uploaded and the device synchronised) computes
+        on stale data; a second pass over the same inputs, the same graphs on one stream (lockstep) and a wavefront whose launches each wait
+        for the previously issued one are always right.  Neither the upload stream, nor blocking uploads, nor sender-side copies, nor a
+        kernel between the event wait and the graph launch change it: independent hipGraph launches that overlap on several streams do
+        not see each other's / the copy engine's writes reliably.  So the default keeps the wavefront ISSUE ORDER but chains the launches
+        (correct, no overlap); the overlap is opt-in and must be validated on the target runtime."""
+        if concurrent is None:
+            concurrent = os.environ.get("PP_STREAM_CONCURRENT") == "1"
         if self.order is None:
             raise RuntimeError("StreamingClipGraph.replay(): capture() first")
         cur = torch.cuda.current_stream(self.device)
@@ -689,7 +703,7 @@ class StreamingClipGraph:
                     g.segments[s][0].replay()
                 _copy_exchange([(g.segments[s][1], g.segments[s][2]) for g in self.graphs])
         else:
-            done = {}
+            done, prev = {}, None
             for st in self.streams:
                 st.wait_stream(cur)                       # the uploads of load() / the previous pass's readers are ordered before this pass
             for r, s in self.order:
@@ -698,6 +712,8 @@ class StreamingClipGraph:
                     if s > 0:                             # the sources of exchange s - 1 have delivered into this rank's receive buffers
                         for q in sorted(self.graphs[r].segments[s - 1][1].recv):
                             st.wait_event(done[(q, s - 1)])
+                    if not concurrent and prev is not None:
+                        st.wait_event(done[prev])        # chained launches: see the docstring
                     self.graphs[r].segments[s][0].replay()
                     # PUSH: the sender delivers -- the copies of exchange s run on ITS stream, right behind the graph that produced the
                     # tensors, into the receivers' static buffers (one per exchange and source: written once per pass, read by the receiver
@@ -712,6 +728,7 @@ class StreamingClipGraph:
                     ev = torch.cuda.Event()
                     ev.record(st)
                     done[(r, s)] = ev
+                    prev = (r, s)
             for st in self.streams:
                 cur.wait_stream(st)
         out = torch.zeros((self.L, self.H, self.W, 3), dtype=torch.uint8, device=self.device)

@@ -1,5 +1,6 @@
-import numpy as np, torch, scipy.ndimage, dataclasses, sys
-sys.path.insert(0, "/root/repo")
+"""Statistics of the streaming replay after loading a new clip (see profiles/r4_streaming_race.txt)."""
+import numpy as np, torch, scipy.ndimage, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from propainter_amd.pipeline import InferenceConfig, run_clip
 from propainter_amd.sharding import StreamingClipGraph
 from propainter_amd.synthetic import synthetic_clip, synthetic_mask, seeded_models
@@ -7,26 +8,23 @@ models = seeded_models("cuda")
 L, H, W = 34, 128, 192
 m = scipy.ndimage.binary_dilation(synthetic_mask(H, W), iterations=4).astype(np.uint8) * 255
 masks = np.repeat(m[None], L, 0)
-clip_a, clip_b = synthetic_clip(L, H, W, seed=12), synthetic_clip(L, H, W, seed=13)
+clips = [synthetic_clip(L, H, W, seed=12 + i) for i in range(3)]
 dev = torch.device("cuda")
-mode = sys.argv[1] if len(sys.argv) > 1 else "batch"
-cfg = InferenceConfig(raft_iter=3, subvideo_length=10, neighbor_length=4, ref_stride=3, fp16=True, batch_propagation=(mode == "batch"))
+cfg = InferenceConfig(raft_iter=3, subvideo_length=10, neighbor_length=4, ref_stride=3, fp16=True, batch_propagation=False)
 models[0].precision = "f16x3"
-ref_a, ref_b = run_clip(models, clip_a, masks, masks, cfg, dev), run_clip(models, clip_b, masks, masks, cfg, dev)
+refs = [run_clip(models, c, masks, masks, cfg, dev).clone() for c in clips]
 sc = StreamingClipGraph(models, L, H, W, cfg, dev)
-sc.load(clip_a, masks, masks); sc.capture()
-out_a = sc.replay()
-out_a2 = sc.replay()
-sc.load(clip_b, masks, masks)
-import os
-if os.environ.get('SYNC_AFTER_LOAD') == '1':
-    torch.cuda.synchronize()
-out_b = sc.replay()
-out_b_lock = sc.replay(lockstep=True)
-torch.cuda.synchronize()
-ref_b2 = run_clip(models, clip_b, masks, masks, cfg, dev)
-torch.cuda.synchronize()
-def d(n, x, y):
-    ne = (x != y)
-    print(f"[{mode}] {n}: {ne.float().mean().item():.3e} frames {[i for i in range(L) if ne[i].any()]}")
-d("a", out_a, ref_a); d("a again", out_a2, ref_a); d("b", out_b, ref_b); d("b lock", out_b_lock, ref_b); d("ref_b vs ref_b2", ref_b, ref_b2); d("b vs ref_b2", out_b, ref_b2)
+sc.load(clips[0], masks, masks); sc.capture()
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+for mode in ("wavefront", "wavefront_concurrent", "lockstep"):
+    bad = []
+    for it in range(N):
+        k = (it + 1) % 3
+        sc.load(clips[k], masks, masks)
+        out = sc.replay(lockstep=(mode == "lockstep"), concurrent=(mode == "wavefront_concurrent"))
+        torch.cuda.synchronize()
+        ne = out != refs[k]
+        if ne.any():
+            bad.append((it, [i for i in range(L) if ne[i].any()][:3]))
+    print(f"STREAM_DIAG {mode}: {len(bad)} of {N} passes wrong {bad[:4]}")
+
