@@ -420,6 +420,20 @@ def main():
     peak_total = torch.cuda.max_memory_allocated(dev)
     exch = {k: dict(v, ms_per_step=v["ms"] / args.steps, sent_bytes_per_step=v["sent_bytes"] // args.steps,
                     recv_bytes_per_step=v["recv_bytes"] // args.steps) for k, v in exchange_stats.items()} if use_ranks else None
+    exch_plan = None
+    if sharded and rank == 0:
+        # what the halo exchanges of THIS clip move on the BASELINE rank counts (4 / 8 GPUs), from the shard plan's index ranges -- the
+        # bytes a real multi-GPU run was checked against over gloo (tests/test_sharding_cpu.py); reported also when this run has one GPU
+        from propainter_amd.sharding import can_shard, plan_exchange_bytes
+        exch_plan = {}
+        for nw in sorted({4, 8, world} - {1}):
+            if can_shard(L, cfg, nw):
+                per_rank = plan_exchange_bytes(L, cfg, nw, args.height, args.width, 4 if args.fp32 else 2)
+                busiest = max(range(nw), key=lambda r_: sum(v[0] for v in per_rank[r_].values()))
+                exch_plan[f"{nw}_ranks"] = {"busiest_rank": busiest,
+                                            "sent_MB": {k: round(v[0] / 1e6, 1) for k, v in per_rank[busiest].items()},
+                                            "sent_total_MB": round(sum(v[0] for v in per_rank[busiest].values()) / 1e6, 1),
+                                            "ms_if_split_over_two_153GBps_xgmi_links": round(sum(v[0] for v in per_rank[busiest].values()) / 153e9 * 1e3 / 2, 2)}
 
     # ---- one instrumented step: stage split + per-kernel-class HIP-event timing (not part of `value`)
     stages, kernels, roof = None, None, None
@@ -575,7 +589,7 @@ def main():
                                "eager pass is what a one-shot CLI run needs, the process figures add the hipGraphs' private pools; "
                                "reference README.md:192 quotes 25 GB fp16 at 720x1280x80 (it runs RAFT in 4-frame clips; this engine "
                                "batches the pair-directions in chunks with a 40 GB budget for the fp32 correlation volumes in flight)"},
-            "exchange": exch, "stages_ms": stages,
+            "exchange": exch, "exchange_plan": exch_plan, "stages_ms": stages,
             "submission": submission,
             "eager_ms_per_step": eager_ms, "graph_capture_s": capture_s,
             "step_ms": step_ms, "host_submit_ms": host_submit, "kernels": kernels,

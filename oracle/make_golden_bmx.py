@@ -3,8 +3,8 @@
 driver pre-processing (resize to the same size, mask dilation 4: inference_propainter.py:70-115) and the fp32 CPU oracle
 with the reference's default settings (raft_iter 20, neighbor_length 10, ref_stride 10).
 
-Run in the authoring container only:  python -m oracle.make_golden_bmx
-Writes tests/golden/bmx_trees_432x240x8.npz = decoded frames, dilated masks, composited oracle frames.  (Seeded weights: the
+Run in the authoring container only:  python -m oracle.make_golden_bmx [8 | 40]
+Writes tests/golden/bmx_trees_432x240x<n>.npz = decoded frames, dilated masks, composited oracle frames.  (Seeded weights: the
 pretrained checkpoints are not available offline; what the fixture adds over the synthetic clips is real image statistics --
 JPEG texture, camera motion, a moving object mask that changes every frame.)"""
 import os
@@ -19,10 +19,11 @@ from propainter_amd import video_io
 from propainter_amd.synthetic import seeded_models
 
 SRC = "/root/reference/inputs/object_removal"
-OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "bmx_trees_432x240x8.npz")
+GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
 
 def main(n=8):
+    OUT = os.path.join(GOLDEN, f"bmx_trees_432x240x{n}.npz")
     warnings.filterwarnings("ignore")
     torch.set_num_threads(os.cpu_count())
     names = sorted(os.listdir(os.path.join(SRC, "bmx-trees")))[:n]
@@ -46,4 +47,5 @@ def main(n=8):
 
 
 if __name__ == "__main__":
-    main()
+    import sys
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 8)      # 8: the small fixture; 40: BASELINE config 1 as stated (the first 40 frames)

@@ -115,6 +115,29 @@ class ShardPlan:
         return routes
 
 
+def plan_exchange_bytes(L, cfg, world, H, W, elem_bytes):
+    """Bytes every rank sends / receives per exchange stage of a sharded pass, from the plan's index ranges alone (no tensors):
+    [{tag: (sent, received)}] per rank for the four exchanges of sharded_clip_steps -- RAFT flows (+-5 pairs), completed flows (+-10),
+    updated frames + masks of the neighbour / reference frames (4 channels), uint8 composites of the windows that straddle a boundary
+    (SURVEY.md section 8(e)).  elem_bytes = 2 (fp16 stages) or 4.  tests/test_sharding_cpu.py checks real gloo runs against it."""
+    plan = ShardPlan(L, cfg, world)
+    ov = lambda a, b: max(0, min(a[1], b[1]) - max(a[0], b[0]))
+    fo = [plan.flows_own(r) for r in range(world)]
+    routes = plan.blend_routes()
+    out = []
+    for r in range(world):
+        rec = {}
+        for tag, own, need, per_item in (("gt_flows", fo, plan.need_gt_flows, 2 * 2 * H * W * elem_bytes),
+                                         ("pred_flows", fo, plan.need_pred_flows, 2 * 2 * H * W * elem_bytes),
+                                         ("updated_frames", plan.own, plan.need_updated, 4 * H * W * elem_bytes)):
+            rec[tag] = (sum(ov(own[r], need(q)) for q in range(world) if q != r) * per_item,
+                        sum(ov(own[q], need(r)) for q in range(world) if q != r) * per_item)
+        rec["blend"] = (sum(len(v) for (s_, d), v in routes.items() if s_ == r) * H * W * 3,
+                        sum(len(v) for (s_, d), v in routes.items() if d == r) * H * W * 3)
+        out.append(rec)
+    return out
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # exchange plumbing
 # ----------------------------------------------------------------------------------------------------------------

@@ -202,26 +202,8 @@ def _plan_worker(rank, world, port, L, S, H, W, q):
 
 
 def _expected_exchange_bytes(L, S, world, H, W, elem):
-    """Bytes rank r sends / receives per exchange stage, from the plan's index ranges alone (RAFT flows +-5,
-    completed flows +-10, updated frames + masks for the neighbour / reference frames, uint8 composites of straddling windows)."""
-    cfg = InferenceConfig(subvideo_length=S, neighbor_length=10, ref_stride=10)
-    plan = ShardPlan(L, cfg, world)
-    ov = lambda a, b: max(0, min(a[1], b[1]) - max(a[0], b[0]))
-    fo = [plan.flows_own(r) for r in range(world)]
-    out = []
-    for r in range(world):
-        rec = {}
-        for tag, own, need, per_item in (("gt_flows", fo, plan.need_gt_flows, 2 * 2 * H * W * elem),
-                                         ("pred_flows", fo, plan.need_pred_flows, 2 * 2 * H * W * elem),
-                                         ("updated_frames", plan.own, plan.need_updated, 4 * H * W * elem)):
-            sent = sum(ov(own[r], need(q)) for q in range(world) if q != r) * per_item
-            recv = sum(ov(own[q], need(r)) for q in range(world) if q != r) * per_item
-            rec[tag] = (sent, recv)
-        routes = plan.blend_routes()
-        rec["blend"] = (sum(len(v) for (s_, d), v in routes.items() if s_ == r) * H * W * 3,
-                        sum(len(v) for (s_, d), v in routes.items() if d == r) * H * W * 3)
-        out.append(rec)
-    return out
+    from propainter_amd.sharding import plan_exchange_bytes
+    return plan_exchange_bytes(L, InferenceConfig(subvideo_length=S, neighbor_length=10, ref_stride=10), world, H, W, elem)
 
 
 @pytest.mark.parametrize("L,S,world", [(320, 80, 4), (160, 20, 8)], ids=["config4_320f_4ranks", "config5_160f_8ranks"])
