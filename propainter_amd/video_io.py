@@ -25,6 +25,7 @@ def read_frames(path):
     """Image folder or video file -> (list of RGB PIL images, fps or None, (w, h), name) (:52-71)."""
     if path.endswith(VIDEO_EXT):
         name = os.path.basename(path)[:-4]
+        frames = None
         try:
             import imageio.v2 as imageio
             rd = imageio.get_reader(path)
@@ -35,9 +36,13 @@ def read_frames(path):
                 import torchvision
                 v, _, info = torchvision.io.read_video(filename=path, pts_unit='sec')
                 frames, fps = [Image.fromarray(f) for f in v.numpy()], info['video_fps']
-            except ImportError as e:
-                raise RuntimeError("reading video files needs imageio(+ffmpeg) or torchvision.io; neither is installed -- "
-                                   "pass a folder of frames instead") from e
+            except (ImportError, AttributeError):      # (no torchvision, or one without the video reader)
+                pass
+        if frames is None:
+            # neither imageio(+ffmpeg) nor torchvision.io: the pure-Python path reads JPEG-coded .mp4 / .mov tracks (what save_results
+            # writes in such an image, and what `ffmpeg -c:v mjpeg` writes); other codecs raise, naming the codec and the remedy
+            from . import mp4_mjpeg
+            frames, fps = mp4_mjpeg.read_mp4(path)
     else:
         name = os.path.basename(os.path.normpath(path))
         files = sorted(f for f in os.listdir(path) if f.endswith(IMAGE_EXT))
@@ -126,8 +131,8 @@ def _resize_u8(a, size, resample):
 
 
 def save_results(save_root, comp_frames, masked_frames, out_size, fps, save_frames):
-    """results/<name>/{masked_in.mp4, inpaint_out.mp4, frames/%04d.png} (:453-472).  Without imageio/ffmpeg the videos
-    cannot be encoded: the frames are written as PNG folders instead (and the caller is told)."""
+    """results/<name>/{masked_in.mp4, inpaint_out.mp4, frames/%04d.png} (:453-472).  With imageio + ffmpeg the videos are H.264 as the
+    reference's; without them (this image) the same files are written as Motion-JPEG .mp4 by the pure-Python muxer (mp4_mjpeg.py)."""
     os.makedirs(save_root, exist_ok=True)
     wrote = []
     if save_frames:
@@ -142,13 +147,10 @@ def save_results(save_root, comp_frames, masked_frames, out_size, fps, save_fram
         import imageio.v2 as imageio
         imageio.mimwrite(os.path.join(save_root, 'masked_in.mp4'), masked, fps=fps, quality=7)
         imageio.mimwrite(os.path.join(save_root, 'inpaint_out.mp4'), comp, fps=fps, quality=7)
-        wrote += [os.path.join(save_root, 'masked_in.mp4'), os.path.join(save_root, 'inpaint_out.mp4')]
-    except Exception as e:   # no imageio / no ffmpeg in this image
-        for name, seq in (('masked_in', masked), ('inpaint_out', comp)):
-            d = os.path.join(save_root, name)
-            os.makedirs(d, exist_ok=True)
-            for i, f in enumerate(seq):
-                Image.fromarray(f).save(os.path.join(d, f"{i:04d}.png"))
-            wrote.append(d)
-        print(f"[propainter_amd] mp4 encoding unavailable ({type(e).__name__}); wrote PNG folders instead")
+    except Exception as e:   # no imageio / no ffmpeg in this image: the same file names as Motion-JPEG .mp4 (mp4_mjpeg.py; quality 7 -> JPEG 85)
+        from . import mp4_mjpeg
+        mp4_mjpeg.write_mp4(os.path.join(save_root, 'masked_in.mp4'), masked, fps=fps, quality=7)
+        mp4_mjpeg.write_mp4(os.path.join(save_root, 'inpaint_out.mp4'), comp, fps=fps, quality=7)
+        print(f"[propainter_amd] imageio / ffmpeg unavailable ({type(e).__name__}): wrote Motion-JPEG .mp4 files (propainter_amd/mp4_mjpeg.py)")
+    wrote += [os.path.join(save_root, 'masked_in.mp4'), os.path.join(save_root, 'inpaint_out.mp4')]
     return wrote

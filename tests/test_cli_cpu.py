@@ -180,3 +180,46 @@ def test_mp4_round_trip_with_real_imageio(tmp_path):
     got, fps, size, name = video_io.read_frames(mp4[0])
     assert len(got) == 5 and size == (96, 64) and abs(fps - 10) < 1e-3 and name == "inpaint_out"
     assert np.abs(np.asarray(got[3]).astype(int) - frames[3].astype(int)).mean() < 6
+
+
+def test_mp4_round_trip_without_ffmpeg(tmp_path):
+    """mp4 in / out in THIS image (no imageio, no ffmpeg): save_results writes masked_in.mp4 / inpaint_out.mp4 as Motion-JPEG ISO-BMFF
+    files through propainter_amd/mp4_mjpeg.py, read_frames reads them back (inference_propainter.py:49-67,471-472): frame count, size and
+    frame rate preserved, frames equal up to JPEG quantisation at the reference's quality=7; the box structure is checked field by field;
+    a track with another codec is refused with the codec named."""
+    import struct
+    from propainter_amd import mp4_mjpeg, video_io
+    from propainter_amd.synthetic import synthetic_clip
+    if "imageio" in sys.modules or __import__("importlib").util.find_spec("imageio") is not None:
+        pytest.skip("imageio is installed: save_results takes the ffmpeg path (covered by test_mp4_round_trip_with_real_imageio)")
+    frames = list(synthetic_clip(7, 64, 96, seed=3))
+    wrote = video_io.save_results(str(tmp_path / "out"), frames, frames, (96, 64), 12.5, False)
+    assert [os.path.basename(w) for w in wrote] == ["masked_in.mp4", "inpaint_out.mp4"]
+    got, fps, size, name = video_io.read_frames(wrote[1])
+    assert len(got) == 7 and size == (96, 64) and name == "inpaint_out" and abs(fps - 12.5) < 1e-3
+    a, b = np.stack(frames).astype(np.float64), np.stack([np.asarray(f) for f in got]).astype(np.float64)
+    psnr = 10 * np.log10(255.0 ** 2 / np.mean((a - b) ** 2))
+    assert psnr > 32.0, psnr              # (measured 33.4 dB: the synthetic frames carry sigma = 5 grey levels of per-pixel noise, the worst case for JPEG 85)
+    # container structure: ftyp | mdat | moov, one video track, mp4v sample entry with esds object type 0x6C (JPEG), 7 samples whose chunk
+    # offsets point at JPEG SOI markers
+    data = open(wrote[1], "rb").read()
+    top = [(k, lo, hi) for k, lo, hi in mp4_mjpeg._boxes(data, 0, len(data))]
+    assert [k for k, _, _ in top] == [b"ftyp", b"mdat", b"moov"] and data[8:12] == b"isom"
+    (sa, sb), = list(mp4_mjpeg._find(data, 0, len(data), (b"moov", b"trak", b"mdia", b"minf", b"stbl")))
+    tbl = {k: (lo, hi) for k, lo, hi in mp4_mjpeg._boxes(data, sa, sb)}
+    assert set(tbl) == {b"stsd", b"stts", b"stsc", b"stsz", b"stco"}
+    kind, ea, eb = next(mp4_mjpeg._boxes(data, tbl[b"stsd"][0] + 8, tbl[b"stsd"][1]))
+    assert kind == b"mp4v" and struct.unpack_from(">HH", data, ea + 24) == (96, 64)
+    n = struct.unpack_from(">I", data, tbl[b"stco"][0] + 4)[0]
+    offs = struct.unpack_from(f">{n}I", data, tbl[b"stco"][0] + 8)
+    assert n == 7 and all(data[o:o + 2] == b"\\xff\\xd8" for o in offs)
+    assert struct.unpack_from(">III", data, tbl[b"stts"][0] + 4) == (1, 7, 7200)            # 90 kHz / 12.5 fps
+    # an H.264 track is refused, naming the codec
+    h264 = data.replace(b"mp4v", b"avc1")
+    p = tmp_path / "h264.mp4"
+    p.write_bytes(h264)
+    with pytest.raises(mp4_mjpeg.UnsupportedCodec, match="avc1"):
+        video_io.read_frames(str(p))
+    with pytest.raises(ValueError):
+        (tmp_path / "junk.mp4").write_bytes(b"not an mp4 file at all")
+        video_io.read_frames(str(tmp_path / "junk.mp4"))
