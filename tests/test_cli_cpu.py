@@ -212,7 +212,7 @@ def test_mp4_round_trip_without_ffmpeg(tmp_path):
     assert kind == b"mp4v" and struct.unpack_from(">HH", data, ea + 24) == (96, 64)
     n = struct.unpack_from(">I", data, tbl[b"stco"][0] + 4)[0]
     offs = struct.unpack_from(f">{n}I", data, tbl[b"stco"][0] + 8)
-    assert n == 7 and all(data[o:o + 2] == b"\\xff\\xd8" for o in offs)
+    assert n == 7 and all(data[o:o + 2] == bytes([0xFF, 0xD8]) for o in offs)
     assert struct.unpack_from(">III", data, tbl[b"stts"][0] + 4) == (1, 7, 7200)            # 90 kHz / 12.5 fps
     # an H.264 track is refused, naming the codec
     h264 = data.replace(b"mp4v", b"avc1")
