@@ -100,7 +100,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU-oracle sample (and with it the parity block)")
     ap.add_argument("--no-profile", action="store_true", help="skip the instrumented (per-kernel HIP events) step")
     ap.add_argument("--no-precisions", action="store_true", help="skip the extra timed steps at the other RAFT precisions")
-    ap.add_argument("--raft-streams", type=int, default=3,
+    ap.add_argument("--raft-streams", type=int, default=2,
                     help="RAFT encoders / pair-direction groups on this many HIP streams (InferenceConfig.raft_streams; identical flows)")
     ap.add_argument("--window-streams", type=int, default=2,
                     help="generator windows in flight on separate HIP streams (pipeline.InferenceConfig.window_streams)")

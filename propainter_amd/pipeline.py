@@ -25,9 +25,10 @@ class InferenceConfig:
     batch_propagation: bool = True       # feature propagation of equal-length generator windows as one batch (InpaintGenerator.propagate_windows)
     window_streams: int = 2      # engine extension: generator windows in flight on separate HIP streams (bit-identical results;
                                  # measured 1167.7 -> 1102.9 ms per 720p clip with 2, 1114.6 with 3: profiles/r2_window_streams.txt)
-    raft_streams: int = 3        # engine extension: RAFT's two encoders, and its pair-directions in this many groups, on separate
+    raft_streams: int = 2        # engine extension: RAFT's two encoders, and its pair-directions in this many groups, on separate
                                  # HIP streams (every pair is computed independently: identical flows; measured on one box, f16x3 pass:
-                                 # 1 -> 1557 ms / 120 GB peak, 2 -> 1554 / 95, 3 -> 1541 / 87, 4 -> 1545 / 83: profiles/r3k_streams.txt)
+                                 # 1 -> 1557 ms / 120 GB peak, 2 -> 1554 / 95, 3 -> 1541 / 87, 4 -> 1545 / 83: profiles/r3k_streams.txt;
+                                 # round 4, volume-free correlation: 2 -> 1452.5, 3 -> 1467 / 1471, 4 -> 1454.6: profiles/r4_stream_sweep.txt)
 
 
 def get_ref_index(mid_neighbor_id, neighbor_ids, length, ref_stride=10, ref_num=-1):
