@@ -45,7 +45,7 @@ PEAK_HBM_GBS = 8000.0
 # KernelProfiler class -> kernel family of tools/rocprof_summary.py (profiles/*_hbm_traffic.json, PMC passes)
 TRAFFIC_FAMILY = {"conv_gemm_f16": "conv_gemm_f16 (LDS-DMA implicit GEMM)", "conv_gemm_f32": "conv_gemm_f32",
                   "conv_gemm_f16x3": "conv_gemm_f16x3 (split-plane LDS-DMA implicit GEMM)",
-                  "conv_gemm_dcn": "conv_gemm_dcn (patch-staged)", "corr_lookup_otf": "corr_lookup_otf", "sparse_window_attention": "sparse_window_attention",
+                  "conv_gemm_dcn": "conv_gemm_dcn (patch-staged)", "corr_lookup_otf": "corr_lookup_otf", "corr_lookup_otf_split": "corr_lookup_otf_split", "sparse_window_attention": "sparse_window_attention",
                   "fold_tokens": "fold_tokens", "corr_lookup": "corr_lookup"}
 # minimal algorithmic FLOPs of BASELINE config 3 (720x1280x80, 25 % of the windows masked)
 C3_ALGORITHMIC_TFLOP = 599.0

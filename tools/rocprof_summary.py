@@ -24,6 +24,7 @@ FAMILIES = [   # (substring of the demangled OR mangled kernel name, family)
     ("conv_ast_kernel", "conv_gemm_f16 (LDS-DMA implicit GEMM)"),
     ("conv_gemm_v2_kernel", "conv_gemm_f16 (LDS-DMA implicit GEMM)"),
     ("conv_dcn_patch_kernel", "conv_gemm_dcn (patch-staged)"),
+    ("corr_otf_split_kernel", "corr_lookup_otf_split"),
     ("corr_otf_kernel", "corr_lookup_otf"),
     ("corr_feature_pool", "corr_feature_pyramid"),
     ("conv_gemm_kernel<_Float16", "conv_gemm_f16/dcn (register-staged)"),
@@ -65,7 +66,7 @@ def _template_args(name, kernel):
 
 
 # position of the SPLIT template argument (split-plane "f16x3" instantiations): conv_halo_kernel<TH, TW, KH, KW, BN, PROF, STAGGER, WMT,
-# SPLIT, PRIVB, DIRB>, conv_gemm_v2_kernel<BM, BN, BK, WM, WN, STAGES, UNI, CFG, SPLIT, TRI>
+# SPLIT, PRIVB>, conv_gemm_v2_kernel<BM, BN, BK, WM, WN, STAGES, UNI, CFG, SPLIT, TRI>
 _SPLIT_ARG = {"conv_halo_kernel": 8, "conv_gemm_v2_kernel": 8}
 
 
