@@ -330,8 +330,9 @@ def assert_finite_flows(raft):
     With seeded and released-style weights RAFT's activations stay below ~1e3 (features are instance-normalised, correlations are scaled by
     1/16, flows are pixels), so the guard is a backstop for foreign checkpoints or corrupt inputs; ``precision="f32"`` (exact fp32 matrix
     instructions) has fp32's range."""
-    flag = getattr(raft, "_flows_finite", None)
-    if flag is not None and not bool(flag):
+    flags = getattr(raft, "_flows_finite", None) or []
+    raft._flows_finite = [fc for fc in flags if fc[1]]
+    if flags and not bool(torch.stack([f.reshape(()) for f, _ in flags]).all()):
         prec = getattr(raft, "_flows_precision", "?")
         hint = ("a value left fp16's range (|v| > 65504) in the split-plane engine: run RAFT_bi(precision='f32') (CLI: --raft_fp32)"
                 if prec == "f16x3" else "check the input frames / checkpoint")
@@ -377,7 +378,7 @@ class RAFT_bi(nn.Module):
         # fp32 all-pairs correlation volumes + pyramids of the pair-direction chunks in flight (volume modes "f32" / "f16x3")
         self.volume_budget_bytes = float(os.environ.get("PP_RAFT_VOLUME_GB", "40")) * 1e9
         self._engines = {}
-        self._flows_finite = None              # device flag of the last forward (assert_finite_flows)
+        self._flows_finite = []                # device flags of the last forwards (assert_finite_flows)
         self.to(device)
         self.eval()
 
@@ -481,7 +482,12 @@ class RAFT_bi(nn.Module):
         up = torch.cat(ups, 0).to(gt_local_frames.dtype)
         # finite-flow guard (device flag, no host sync here: graph-capturable; callers check it after their own synchronisation with
         # assert_finite_flows).  A split-plane value beyond fp16's range (|v| > 65504) puts inf into its hi plane and the flows go NaN.
-        self._flows_finite = torch.isfinite(up.sum())
+        # one flag per call (a sharded / streaming pass calls once per rank); flags recorded under hipGraph capture are refreshed by every
+        # replay and stay, eager ones are dropped once assert_finite_flows has looked at them
+        captured = up.is_cuda and torch.cuda.is_current_stream_capturing()
+        flags = getattr(self, "_flows_finite", None) or []
+        flags.append((torch.isfinite(up.sum()), captured))
+        self._flows_finite = flags[-64:]
         self._flows_precision = prec
         half = P // 2
         return up[:half].view(b, l_t - 1, 2, h, w), up[half:].view(b, l_t - 1, 2, h, w)
