@@ -313,6 +313,7 @@ __global__ __launch_bounds__(512) void corr_otf_kernel(const CorrOtfParams p) {
 __device__ unsigned long long g_otf_prof[8];
 constexpr int OTFS_LVC = 88;                        // channels per level group
 constexpr int OTFS_NPX = 32;                        // pixels per block: 4 rows x 8 columns
+constexpr int OTFS_STRIP = 5;                       // tile columns per strip of the block order (see the kernel)
 constexpr int OTFS_VTOT = OTFS_NPX * 324;           // floats of V (41 KB): 32 x 324 (20 N tiles; 324 = 4 mod 32: conflict-free tile stores), 16 x 648, 1 x 10368
 constexpr int OTFS_STAGE = OTFS_NPX * 2 * OTFS_LVC * 2;   // bytes: [32 px][hi | lo][88]
 constexpr int OTFS_TAB = OTFS_NPX * 18 * 8;         // bytes: [32 px][9 a + 9 b] x {int cell, float fraction}
@@ -347,9 +348,26 @@ __global__ __launch_bounds__(256, 2) void corr_otf_split_kernel(const CorrOtfPar
     const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, loc = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
   }
-  const int txi = bid % p.tiles_x;
-  const int tyi = (bid / p.tiles_x) % p.tiles_y;
-  const int n = bid / (p.tiles_x * p.tiles_y);
+  // tile order inside a pair: COLUMN STRIPS of OTFS_STRIP tiles (40 pixels) walked top to bottom.  A tile's level-0 box is 14 rows x 18
+  // positions x 1 KB; row-major over the whole 160-pixel map keeps 14 full rows (2.2 MB + the other levels) live between two tile
+  // rows -- with the f1 stream and the output rows more than an XCD's 4 MB L2 holds, and f2 was fetched 1.8 x (PMC, profiles/r4y_*);
+  // a strip re-uses 10 of its 14 box rows out of ~0.7 MB.
+  const int per_pair = p.tiles_x * p.tiles_y;
+  const int n = bid / per_pair;
+  int txi, tyi;
+  {
+    const int t = bid - n * per_pair;
+    const int full = (p.tiles_x / OTFS_STRIP) * OTFS_STRIP * p.tiles_y;      // tiles inside full-width strips
+    if (t < full) {
+      const int s_ = t / (OTFS_STRIP * p.tiles_y), r_ = t - s_ * (OTFS_STRIP * p.tiles_y);
+      tyi = r_ / OTFS_STRIP;
+      txi = s_ * OTFS_STRIP + (r_ - tyi * OTFS_STRIP);
+    } else {                                                                 // the ragged last strip
+      const int wlast = p.tiles_x - (p.tiles_x / OTFS_STRIP) * OTFS_STRIP, r_ = t - full;
+      tyi = r_ / wlast;
+      txi = (p.tiles_x / OTFS_STRIP) * OTFS_STRIP + (r_ - tyi * wlast);
+    }
+  }
   const int ty0 = tyi * 4, tx0 = txi * 8;
   // pixel q of the tile: row q >> 3, column q & 7 (M tile q >> 4 = rows 2m, 2m + 1)
   auto wave_box = [&](int lvl, int p0, int np, int* dst) {
