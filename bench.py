@@ -588,7 +588,8 @@ def main():
                                "from the driver over all stream pools (max_memory_reserved: the figure a device-memory monitor shows); the "
                                "eager pass is what a one-shot CLI run needs, the process figures add the hipGraphs' private pools; "
                                "reference README.md:192 quotes 25 GB fp16 at 720x1280x80 (it runs RAFT in 4-frame clips; this engine "
-                               "batches the pair-directions in chunks with a 40 GB budget for the fp32 correlation volumes in flight)"},
+                               "batches all pair-directions; since round 4 the default f16x3 RAFT keeps no correlation volume -- only the "
+                               "exact-f32 mode materialises fp32 volumes, within a 40 GB budget)"},
             "exchange": exch, "exchange_plan": exch_plan, "stages_ms": stages,
             "submission": submission,
             "eager_ms_per_step": eager_ms, "graph_capture_s": capture_s,
