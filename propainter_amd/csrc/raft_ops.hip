@@ -64,7 +64,9 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(const float* __restric
         const int i = lane + 64 * k;
         if (i < 100) patch[lvl][i / 10][i % 10] = v[lvl][k];
       }
-    // (the patch is wave-private and LDS operations of one wave execute in order: no barrier)
+    // (the patch is wave-private: no block barrier; the wave barrier is free on wave64 and keeps the compiler from moving or caching the
+    //  dynamically indexed LDS accesses across the hand-over between lanes)
+    __builtin_amdgcn_wave_barrier();
     TO* op = out + pix * ocs;
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
@@ -105,6 +107,7 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(const float* __restric
       op[i] = from_f32<TO>(0.f);
       if constexpr (SPLIT) op[ocs / 2 + i] = from_f32<TO>(0.f);
     }
+    __builtin_amdgcn_wave_barrier();      // the next pixel re-stages the patch: not before every lane has blended this one
   }
 }
 
