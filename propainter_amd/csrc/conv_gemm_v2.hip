@@ -38,7 +38,9 @@ int conv_v2_dispatch(const ConvParams& p, int cfg, hipStream_t stream) {
   for (int i = 0; i < p.nsrc; ++i) uni = uni && (long long)p.N * p.H * p.W * p.src[i].cstride * 2 < (1ll << 31);
   if (cfg >= 100) { uni = false; cfg -= 100; }
   if (cfg == 0) {   // measured on MI355X with tools/bench_conv.py (profiles/r1_conv_tile_sweep.txt)
-    if (p.cout_g >= 512) cfg = 13;
+    // 256 x 256 tiles move half the LDS-DMA bytes per MFMA of 256 x 128: +7..30 % on the transformer GEMMs (profiles/r4_tile256x256.txt),
+    // same K order, so the results are bit-identical; they need at least one block per CU to pay
+    if (p.cout_g >= 512) cfg = ((p.M + 255) / 256) * ((p.cout_g + 255) / 256) * p.groups >= 256 ? 18 : 13;
     else if (p.cout_g > 64) cfg = 12;
     else if (p.cout_g > 32) cfg = 22;
     else if (p.cout_g > 16) cfg = p.groups > 1 ? 31 : 32;
@@ -54,6 +56,7 @@ int conv_v2_dispatch(const ConvParams& p, int cfg, hipStream_t stream) {
     case 15: return launch_v2<128, 128, 64, 2, 2, 3>(p, uni, stream);   // 96 KiB -> 1 block/CU
     case 16: return launch_v2<256, 128, 32, 2, 2, 4>(p, uni, stream);   // 4 waves 128x64, 96 KiB
     case 17: return launch_v2<256, 128, 64, 2, 2, 2>(p, uni, stream);   // 4 waves 128x64, 96 KiB
+    case 18: return launch_v2<256, 256, 64, 4, 2, 2>(p, uni, stream);   // 8 waves 64x128, 2 stages: 128 KiB -- half the DMA bytes per MFMA of 13
     case 20: return launch_v2<128, 64, 32, 2, 2, 4>(p, uni, stream);    // wave tile 64x32, 48 KiB -> 3 blocks/CU
     case 21: return launch_v2<256, 64, 32, 4, 1, 4>(p, uni, stream);    // wave tile 64x64, 80 KiB
     case 22: return launch_v2<256, 64, 64, 4, 1, 2>(p, uni, stream);    // 80 KiB -> 2 blocks/CU

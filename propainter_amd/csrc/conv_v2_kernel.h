@@ -43,7 +43,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N <= 4 && 
   constexpr bool B_RAGGED = (B_INST % NW) != 0;      // some waves have no weight rows to fetch: they DMA into a dummy pad
   constexpr int G = A_PER_WAVE + B_PER_WAVE;         // DMA instructions per lane per step (identical for every wave)
   constexpr int STAGE = (BM + BN) * ROWB;
-  constexpr int EPI_LD = WN + 4;                     // fp32 row stride of the epilogue staging tile
+  constexpr int EPI_WN = WN > 64 ? 64 : WN;          // wave tiles wider than 64 couts are drained in 64-cout halves (as conv_halo.h)
+  constexpr int EPI_LD = EPI_WN + 4;                 // fp32 row stride of the epilogue staging tile
   constexpr int EPI_BYTES = NW * WM * EPI_LD * 4;
   constexpr int PIPE_BYTES = S * STAGE + (B_RAGGED ? NW * 1024 : 0);
   constexpr int LDS_BYTES = PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES;
@@ -51,6 +52,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N <= 4 && 
   static_assert(A_INST % NW == 0, "A rows must split evenly over the waves");
   static_assert(S >= 2 && (S - 2) * G < 64, "pipeline depth");
   static_assert(WN % 8 == 0 || WN == 16, "epilogue");
+  static_assert(WN <= 64 || WN == 128, "wave tiles wider than 64 couts: two halves of 64");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 
   __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
 
@@ -453,7 +456,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N <= 4 && 
     }
   };
   const RowMap rowmap{m0 + wm * WM, p.M};
-  if constexpr (WN >= 16 && WN % 8 == 0) {
+  if constexpr (WN == 128) {
+    // 128-cout wave tiles (256 x 256 block tile: half the LDS-DMA bytes per MFMA of the 256 x 128 tile): two passes of 64 couts through the
+    // same wave-private staging tile (LDS operations of one wave execute in order: the second pass cannot overtake the first pass's reads)
+    char* ob = p.out + (long long)g * p.out_gstride * (p.out_f16 ? 2 : 4);
+    conv_epilogue<WM, 64, TN, 0, true, true, SPLIT>(p, acc, lds + wave * (WM * EPI_LD * 4), lane, n0 + wn * WN, g, ob, rowmap);
+    conv_epilogue<WM, 64, TN, 4, true, true, SPLIT>(p, acc, lds + wave * (WM * EPI_LD * 4), lane, n0 + wn * WN + 64, g, ob, rowmap);
+  } else if constexpr (WN >= 16 && WN % 8 == 0) {
     if (addend_in_acc) {
       ConvParams pe = p;
       pe.preadd = nullptr; pe.residual = nullptr; pe.act = act_after;

@@ -337,6 +337,36 @@ def test_a_stationary_gemm_is_bit_identical_to_the_tiled_kernel(dev, residual):
     check("ast", outs[80][0, 0], ref, 1e-2)
 
 
+@pytest.mark.parametrize("k,cin,cout", [(1, 512, 1960), (7, 40, 512)], ids=["linear_512_1960", "7x7s3_c40_512"])
+def test_256x256_tile_is_bit_identical_to_the_256x128_tile(dev, k, cin, cout):
+    """conv_v2_dispatch picks the 256 x 256 block tile (impl 18: 64 x 128 wave tiles, epilogue in two 64-cout halves) for cout >= 512
+    once a launch has 256 blocks; same K order as the 256 x 128 tile (impl 13), so the outputs must be equal -- ragged row count,
+    cout not a multiple of 256, bias, activation, residual, output written into a channel window of a wider buffer."""
+    from propainter_amd.conv import ConvLayer
+    g = torch.Generator().manual_seed(41)
+    if k == 1:
+        N, H, W, stride, pad = 1, 1, 9001, 1, 0
+    else:
+        N, H, W, stride, pad = 2, 96, 141, 3, 3
+    w = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    b = torch.randn(cout, generator=g) * 0.1
+    x = torch.randn(N, cin, H, W, generator=g)
+    layer = ConvLayer(w, b, stride=stride, padding=pad, dtype=torch.float16, device=dev)
+    OH, OW = layer.out_hw(H, W)
+    res = torch.randn(N, OH, OW, cout, generator=g).to(dev, torch.float16)
+    outs = {}
+    for impl in (13, 18):
+        layer.impl = impl
+        buf = torch.full((N, OH, OW, cout + 72), 3.0, dtype=torch.float16, device=dev)
+        layer([nhwc(x, torch.float16)], out=buf, out_choff=8, act="lrelu", act_param=0.2, residual=res)
+        torch.cuda.synchronize()
+        outs[impl] = buf
+    assert torch.equal(outs[13], outs[18])
+    assert (outs[18][..., :8] == 3.0).all() and (outs[18][..., 8 + cout:] == 3.0).all()
+    ref = F.leaky_relu(F.conv2d(x.half().float(), w.half().float(), b, stride, pad), 0.2) + res.float().cpu().permute(0, 3, 1, 2)
+    check("tile256", outs[18][..., 8:8 + cout].permute(0, 3, 1, 2), ref, 1e-2)
+
+
 def test_conv2d_output_window_and_large_m(dev):
     """writes into a channel window of a wider buffer; M not a multiple of the tile; asymmetric data (transposes)."""
     from propainter_amd.conv import ConvLayer
