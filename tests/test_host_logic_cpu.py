@@ -335,3 +335,79 @@ def test_float_blend_compositor_is_the_evaluation_scripts_composite():
     for idx in range(L):
         assert np.array_equal(c.comp[idx].numpy(), np.asarray(comp_ref[idx], dtype=np.float32)), idx
     assert (c.comp[3] != c.comp[3].floor()).any()                        # frame 3 sits in three windows: quarter levels survive
+
+
+def _load_script(name):
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", name + ".py")
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+class _RecordingRaft:
+    """Stands in for RAFT_bi in the host-logic tests: the 'flow' of a pair is (index of its first frame, index of its second frame)."""
+
+    def __init__(self):
+        self.calls = []
+
+    def __call__(self, frames, iters=20):
+        b, t = frames.shape[:2]
+        self.calls.append((t, iters))
+        idx = frames[0, :, 0, 0, 0]
+        h, w = frames.shape[-2:]
+        f = torch.stack([idx[:-1], idx[1:]], 1)[None, :, :, None, None].expand(1, t - 1, 2, h, w)
+        return f.clone(), f.flip(2).clone()
+
+
+def test_flow_scripts_chunk_a_clip_so_that_every_pair_is_computed_once():
+    """scripts/compute_flow.py (chunks share their boundary frame) and scripts/evaluate_flow_completion.py (the reference's chunks of
+    60 with one frame of overlap, evaluate_flow_completion.py:94-110): every consecutive pair exactly once, in order."""
+    cf, ev = _load_script("compute_flow"), _load_script("evaluate_flow_completion")
+    t, h, w = 11, 16, 24
+    frames = np.zeros((t, h, w, 3), np.uint8)
+    frames[:, :, :, :] = (np.arange(t) * 10)[:, None, None, None]
+    raft = _RecordingRaft()
+    ff, fb = cf.clip_flows(raft, frames, (h, w), "cpu", iters=20, chunk=4)
+    assert [c[0] for c in raft.calls] == [4, 4, 4, 2] and ff.shape == fb.shape == (t - 1, h, w, 2)
+    val = lambda i: (i * 10 / 255.0) * 2 - 1
+    for i in range(t - 1):
+        assert abs(ff[i, 0, 0, 0] - val(i)) < 1e-6 and abs(ff[i, 0, 0, 1] - val(i + 1)) < 1e-6
+        assert abs(fb[i, 0, 0, 0] - val(i + 1)) < 1e-6 and abs(fb[i, 0, 0, 1] - val(i)) < 1e-6
+    x = torch.arange(130, dtype=torch.float32)[None, :, None, None, None].expand(1, 130, 3, 8, 8)
+    raft = _RecordingRaft()
+    a, b = ev.raft_flows(raft, x, raft_iter=7)
+    assert raft.calls == [(60, 7), (61, 7), (11, 7)] and a.shape == (1, 129, 2, 8, 8)
+    assert torch.equal(a[0, :, 0, 0, 0], torch.arange(129.)) and torch.equal(a[0, :, 1, 0, 0], torch.arange(1, 130.))
+    assert torch.equal(b[0, :, 0, 0, 0], torch.arange(1, 130.))
+    raft = _RecordingRaft()
+    ev.raft_flows(raft, x[:, :60], raft_iter=20)
+    assert raft.calls == [(60, 20)]
+    assert cf.frame_stem("00012.jpg") == "00012" and cf.frame_stem("00012.png") == "00012"
+
+
+def test_flow_colour_coding_and_flow_resize():
+    """Middlebury colour wheel of the flow PNGs (55 hues; zero flow white, unknown flow black, hue by direction, saturation by the
+    magnitude relative to the frame's largest) and the loader's flow resize (displacements scale with the image, flow_util.py:6-11)."""
+    ev = _load_script("evaluate_flow_completion")
+    wheel = ev.make_colorwheel()
+    assert wheel.shape == (55, 3) and wheel.min() == 0.0 and wheel.max() == 1.0
+    assert np.allclose(wheel[0], [1, 0, 0]) and np.allclose(wheel[15], [1, 1, 0]) and np.allclose(wheel[21], [0, 1, 0])
+    assert np.allclose(wheel[25], [0, 1, 1]) and np.allclose(wheel[36], [0, 0, 1]) and np.allclose(wheel[49], [1, 0, 1])
+    flow = np.zeros((2, 3, 2), np.float32)
+    flow[0, 1] = (3.0, 0.0)
+    flow[0, 2] = (0.0, 1.5)
+    flow[1, 0] = (np.nan, 0.0)
+    flow[1, 1] = (1e9, 0.0)
+    rgb = ev.flow2rgb(flow)
+    assert rgb.shape == (2, 3, 3) and np.allclose(rgb[0, 0], 1.0) and np.allclose(rgb[1, 0], 0.0) and np.allclose(rgb[1, 1], 0.0)
+    assert rgb.min() >= 0.0 and rgb.max() <= 1.0
+    assert rgb[0, 1].min() < 0.05                      # the largest flow of the frame is fully saturated
+    assert 0.45 < rgb[0, 2].min() < 0.55               # half its magnitude: half saturated
+    assert not np.allclose(rgb[0, 1], 2 * rgb[0, 2] - 1)      # and a different hue
+    fl = torch.zeros(1, 2, 4, 6)
+    fl[:, 0], fl[:, 1] = 2.0, -1.0
+    out = ev.resize_flows(fl, 8, 18)
+    assert out.shape == (1, 2, 8, 18) and torch.allclose(out[:, 0], torch.full((1, 8, 18), 6.0)) and torch.allclose(out[:, 1], torch.full((1, 8, 18), -2.0))
+    assert ev.resize_flows(fl, 4, 6) is not None and torch.equal(ev.resize_flows(fl, 4, 6), fl)

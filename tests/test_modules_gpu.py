@@ -773,3 +773,62 @@ def test_evaluate_entry_point_prints_the_reference_report(tmp_path, capsys):
     assert txt[:2] == per_video and txt[2] == last[0]
     assert len(os.listdir(os.path.join(res["path"], "synthetic_00"))) == 12
     print("EVALUATE_REPORT", last[0])
+
+
+def _script(name):
+    import importlib.util
+    import sys
+    d = os.path.join(os.path.dirname(os.path.dirname(__file__)), "scripts")
+    if d not in sys.path:
+        sys.path.insert(0, d)
+    spec = importlib.util.spec_from_file_location(name, os.path.join(d, name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_compute_flow_and_flow_completion_entry_points(tmp_path):
+    """scripts/compute_flow.py writes the reference's .flo pairs (<cur>_<next>_f.flo / <next>_<cur>_b.flo, float16 PIEH files,
+    compute_flow.py:100-107) for two seeded clips -- chunked and unchunked RAFT agree bit for bit (batch invariance) -- and
+    scripts/evaluate_flow_completion.py reports the reference's EPE lines (evaluate_flow_completion.py:160-186), the same figure
+    whether the ground-truth flows are recomputed or read back with --load_flow (up to the files' float16 rounding)."""
+    import re
+    from propainter_amd import flow_io
+    from propainter_amd.synthetic import seeded_models, synthetic_clip
+    cf, ev = _script("compute_flow"), _script("evaluate_flow_completion")
+    root, flows = str(tmp_path / "JPEGImages"), str(tmp_path / "Flows_flo")
+    H, W, T = 128, 192, 7
+    n = cf.main(["-i", root, "-o", flows, "--height", str(H), "--width", str(W), "--synthetic", "2", "--frames", str(T), "--chunk", "4"],
+                out=lambda *_: None)
+    assert n == 2 * 2 * (T - 1)
+    names = sorted(os.listdir(os.path.join(flows, "synthetic_01")))
+    assert names[:2] == ["00000_00001_f.flo", "00001_00000_b.flo"] and len(names) == 2 * (T - 1)
+    raft = seeded_models("cuda", raft_precision="f32")[0]
+    clip = synthetic_clip(T, H, W, seed=101)
+    with torch.no_grad():
+        f4, b4 = cf.clip_flows(raft, clip, (H, W), torch.device("cuda"), chunk=4)
+        f60, b60 = cf.clip_flows(raft, clip, (H, W), torch.device("cuda"), chunk=60)
+    assert np.array_equal(f4, f60) and np.array_equal(b4, b60)
+    lf, lb = flow_io.load_clip_flows(os.path.join(flows, "synthetic_01"))
+    assert np.array_equal(lf, np.transpose(f4, (0, 3, 1, 2)).astype(np.float16).astype(np.float32))
+    assert np.array_equal(lb, np.transpose(b4, (0, 3, 1, 2)).astype(np.float16).astype(np.float32))
+    assert np.abs(f4).max() > 0.05                     # the seeded RAFT does produce a flow field
+
+    common = ["--synthetic", "2", "--frames", str(T), "--height", str(H), "--width", str(W)]
+    lines = []
+    res = ev.evaluate(ev.build_parser().parse_args(common + ["--result_root", str(tmp_path / "r1"), "--save_results"]), out=lines.append)
+    per_video = [l for l in lines if l.startswith("[")]
+    pat = re.compile(r"^\[\s*(\d+)/2\] Name: synthetic_0\d\s+\| EPE: (\d+\.\d{4}) \| Time: (\d+\.\d{4})$")
+    assert len(per_video) == 2 and all(pat.match(l) for l in per_video), per_video
+    last = [l for l in lines if l.startswith("Finish evaluation")]
+    assert len(last) == 1 and re.match(r"^Finish evaluation\.\.\. Average Frame EPE: \d+\.\d{4} \| \| Time: \d+\.\d{4}$", last[0]), last
+    assert open(os.path.join(res["path"], "synthetic_metrics.txt")).read().splitlines() == per_video + last
+    for sub in ("forward_png", "backward_png"):
+        assert len(os.listdir(os.path.join(res["path"], "synthetic_00", sub))) == T - 1
+    assert np.isfinite(res["epe"]) and res["epe"] >= 0 and res["time"] > 0
+    res2 = ev.evaluate(ev.build_parser().parse_args(common + ["--result_root", str(tmp_path / "r2"), "--load_flow", "--flow_root", flows]),
+                       out=lambda *_: None)
+    assert abs(res["epe"] - res2["epe"]) <= 2e-3 * max(1.0, res["epe"]), (res["epe"], res2["epe"])
+    res3 = ev.evaluate(ev.build_parser().parse_args(common + ["--result_root", str(tmp_path / "r3"), "--fp16"]), out=lambda *_: None)
+    assert abs(res["epe"] - res3["epe"]) <= 2e-2 * max(1.0, res["epe"]), (res["epe"], res3["epe"])
+    print("FLOW_COMPLETION_REPORT", last[0], "| load_flow", res2["epe"], "| fp16", res3["epe"])
