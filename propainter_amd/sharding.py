@@ -21,7 +21,7 @@ import os
 import numpy as np
 import torch
 
-from .pipeline import (InferenceConfig, _dev_index, compute_flows, subvideo_chunks, window_schedule)
+from .pipeline import (InferenceConfig, _dev_index, _window_streams, compute_flows, subvideo_chunks, window_schedule)
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -275,14 +275,33 @@ def sharded_clip_steps(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg: 
     done = [False] * max(0, hi - lo)
     deferred = {}                                                    # own frame with foreign contributions -> [(f, cur)]
     outbox = {}                                                      # dst rank -> [cur] in route order
-    enc_all, enc_pos = None, {}
+    enc_all, enc_pos, clip_cache = None, {}, None
     my_windows = plan.rank_windows(rank)
-    if my_windows and hasattr(model, "encode_frames"):
-        # encoder features once per frame this rank's windows actually touch (own frames + the strided references)
-        used = sorted({i for _, nb, ref in my_windows for i in nb + ref})
-        enc_pos = {g: k for k, g in enumerate(used)}
+    used = sorted({i for _, nb, ref in my_windows for i in nb + ref})      # own frames + the strided references
+    enc_pos = {g: k for k, g in enumerate(used)}
+    if len(used) >= 2 and hasattr(model, "prepare_clip") and hasattr(model, "forward_window"):
+        # The per-clip generator cache of the unsharded pass (pipeline.run_clip), over the COMPACT clip of the frames this rank's
+        # windows touch: encoder features, 1/4-resolution flows / masks and propagation side inputs once per frame / pair, the windows'
+        # feature propagation batched, the windows on the generator lanes.  The local frames of the rank's windows are one contiguous
+        # range [a0, b0) of the clip (windows every neighbor_stride frames, +-neighbor_stride locals), so they are contiguous in the
+        # compact clip as well; its other flow pairs (between references) are never read and stay zero.  Same kernels on the same
+        # values as the unsharded pass: results are identical.
+        a0, b0 = min(nb[0] for _, nb, _ in my_windows), max(nb[-1] for _, nb, _ in my_windows) + 1
+        p0 = enc_pos[a0]
+        assert used[p0:p0 + b0 - a0] == list(range(a0, b0)), "local frames of a rank's windows: one contiguous range"
+        uu = upd.take(used, device)
+        cflows = torch.zeros((2, 1, len(used) - 1, 2, H, W), dtype=pred.t.dtype, device=device)
+        if b0 - a0 > 1:
+            cflows[:, :, p0:p0 + b0 - a0 - 1] = pred.sl(a0, b0 - 1)
+        clip_cache = model.prepare_clip(uu[:, :, :3].contiguous(), (cflows[0], cflows[1]), masks_dilated.take(used, device),
+                                        uu[:, :, 3:4].contiguous())
+        if cfg.batch_propagation and hasattr(model, "propagate_windows"):
+            model.propagate_windows(clip_cache, [(enc_pos[nb[0]], len(nb)) for _, nb, _ in my_windows])
+    elif my_windows and hasattr(model, "encode_frames"):
+        # encoder features once per frame this rank's windows actually touch
         uu = upd.take(used, device)
         enc_all = model.encode_frames(uu[:, :, :3].contiguous(), masks_dilated.take(used, device), uu[:, :, 3:4].contiguous())
+    empty_ref = torch.zeros((0,), dtype=torch.long, device=device)
 
     def blend(idx, cur):
         k = idx - lo
@@ -291,13 +310,18 @@ def sharded_clip_steps(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg: 
         comp[k] = cur
         done[k] = True
 
-    for f, nb, ref in my_windows:
+    def window(nb, ref):
+        if clip_cache is not None:
+            return model.forward_window(clip_cache, enc_pos[nb[0]], len(nb),
+                                        _dev_index([enc_pos[i] for i in ref], device) if ref else empty_ref)
         ids = nb + ref
         u = upd.take(ids, device)
         kw = {} if enc_all is None else {"enc_feat": enc_all.index_select(0, _dev_index([enc_pos[i] for i in ids], device))}
         fl = pred.sl(nb[0], nb[-1])
-        out = model(u[:, :, :3].contiguous(), (fl[0], fl[1]), masks_dilated.take(ids, device), u[:, :, 3:4].contiguous(),
-                    len(nb), **kw)
+        return model(u[:, :, :3].contiguous(), (fl[0], fl[1]), masks_dilated.take(ids, device), u[:, :, 3:4].contiguous(),
+                     len(nb), **kw)
+
+    def composite(f, nb, out):
         img = (((out[0] + 1) / 2).permute(0, 2, 3, 1) * 255).to(torch.uint8)   # (:435-442) in the prediction's dtype, as pipeline.Compositor
         for i, idx in enumerate(nb):
             m = masks_dilated.sl(idx, idx + 1)[0, 0].permute(1, 2, 0).to(torch.uint8)
@@ -310,6 +334,24 @@ def sharded_clip_steps(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg: 
                 deferred.setdefault(idx, []).append((f, cur))
             else:
                 blend(idx, cur)
+
+    lanes = _window_streams(device, cfg.window_streams) if device.type == "cuda" else []
+    if len(lanes) < 2:
+        for f, nb, ref in my_windows:
+            composite(f, nb, window(nb, ref))
+    else:
+        # consecutive windows on separate HIP streams, composited afterwards in window order (as pipeline.run_clip)
+        cur_s = torch.cuda.current_stream(device)
+        for i in range(0, len(my_windows), len(lanes)):
+            group = []
+            for s_, (f, nb, ref) in zip(lanes, my_windows[i:i + len(lanes)]):
+                s_.wait_stream(cur_s)
+                with torch.cuda.stream(s_):
+                    group.append((f, nb, window(nb, ref), s_))
+            for f, nb, out, s_ in group:
+                cur_s.wait_stream(s_)
+                out.record_stream(cur_s)
+                composite(f, nb, out)
     send = {q: torch.stack(v, 0) for q, v in outbox.items()}
     recv = {src: ((len(items), H, W, 3), torch.uint8) for (src, dst), items in routes.items() if dst == rank}
     got = yield Exchange(send, recv, "blend")
@@ -417,8 +459,11 @@ class ShardedClipGraph:
         lo, comp = g.replay(exchange)                                # (after another load(): the next clip)
     """
 
-    def __init__(self, models, L, H, W, cfg, device, rank, world):
+    def __init__(self, models, L, H, W, cfg, device, rank, world, pool=None):
+        """``pool`` (optional graph memory pool handle): capture into this pool instead of a private one -- for several logical ranks of
+        ONE process whose graphs are replayed strictly in their capture order (StreamingClipGraph(share_pool=True))."""
         self.models, self.cfg, self.device, self.rank, self.world, self.L = models, cfg, torch.device(device), rank, world, L
+        self._pool = pool
         self.r0, self.r1 = ShardPlan(L, cfg, world).need_raw(rank)
         n = max(0, self.r1 - self.r0)
         self.frames = torch.zeros((n, H, W, 3), dtype=torch.uint8, device=device)
@@ -457,7 +502,7 @@ class ShardedClipGraph:
         if self._gen is None:
             self._gen = sharded_clip_steps(self.models, *self._inputs(), self.cfg, self.device, self.rank, self.world)
         g = torch.cuda.CUDAGraph()
-        pool = self.segments[0][0].pool() if self.segments else None
+        pool = self._pool if self._pool is not None else (self.segments[0][0].pool() if self.segments else None)
         prev, pipeline._index_recorder = pipeline._index_recorder, self._pinned      # the graphs own the cached index tensors they read
         ex, done = None, False
         try:
@@ -643,15 +688,21 @@ class StreamingClipGraph:
     wavefront over its segments is the deepest overlap the data flow admits.  Same kernels on the same data as ``run_clip``: the
     composited frames are bit-identical (tests/test_modules_gpu.py).
 
-    The logical ranks replay concurrently, so each owns a private graph memory pool; the fp32 correlation volumes of RAFT get
-    ``volume_gb`` (default 40 GB, the single-pass budget) split over the ranks and one RAFT stream each.
+    Memory: with ``share_pool=True`` (default) all (rank, segment) graphs are CAPTURED IN THE WAVEFRONT ORDER into ONE graph memory
+    pool and replayed in exactly that order, one launch after the other (the chained default of ``replay``): a block a segment has
+    released serves the segments captured after it, so the pass holds what is alive at one point of the pipeline -- sub-video scale --
+    instead of the sum of ``world`` private pools.  Graphs that share a pool must never overlap or change order: ``share_pool=False``
+    gives every logical rank its private pool, as the lockstep A/B order and the concurrent mode need.  The fp32 correlation volumes
+    of RAFT's exact-f32 mode get ``volume_gb`` (default 40 GB, the single-pass budget) split over the ranks; one RAFT stream each.
 
         s = StreamingClipGraph(models, L, H, W, cfg, device)         # world = number of sub-video blocks of the clip
         s.load(frames_u8, flow_masks_u8, masks_dilated_u8); s.capture()
         out_u8 = s.replay()                                           # [L, H, W, 3]; load() + replay() for the next clip
     """
 
-    def __init__(self, models, L, H, W, cfg, device, world=None, volume_gb=40.0):
+    NSEG = 5          # compute segments of sharded_clip_steps: RAFT | completion | image propagation | windows | boundary blends
+
+    def __init__(self, models, L, H, W, cfg, device, world=None, volume_gb=40.0, share_pool=True):
         import dataclasses
         self.device = torch.device(device)
         nsub = -(-L // cfg.subvideo_length)
@@ -661,7 +712,9 @@ class StreamingClipGraph:
         self.models, self.L, self.H, self.W = models, L, H, W
         self.cfg = dataclasses.replace(cfg, raft_streams=1)         # the ranks run next to each other: one RAFT lane each
         self.volume_gb = float(volume_gb)
-        self.graphs = [ShardedClipGraph(models, L, H, W, self.cfg, device, r, self.world) for r in range(self.world)]
+        self.share_pool = bool(share_pool)
+        pool = torch.cuda.graph_pool_handle() if self.share_pool else None
+        self.graphs = [ShardedClipGraph(models, L, H, W, self.cfg, device, r, self.world, pool=pool) for r in range(self.world)]
         self.streams = [torch.cuda.Stream(self.device) for _ in range(self.world)]
         self.order = None
         self._inputs = None
@@ -684,22 +737,54 @@ class StreamingClipGraph:
             run_logical_shards(self.models, *self._inputs, self.cfg, self.device, self.world)
             torch.cuda.synchronize(self.device)
             torch.cuda.empty_cache()                      # the warm-up's cached blocks go back before `world` private graph pools grow
-            got = [None] * self.world
-            while True:
-                reqs = [g.capture_next(got[r]) for r, g in enumerate(self.graphs)]
-                assert len({ex.tag if ex is not None else None for ex, _ in reqs}) == 1, "ranks must stop at the same exchange"
-                if reqs[0][0] is None:
-                    break
-                _copy_exchange(reqs)
-                got = [b for _, b in reqs]
+            if self.share_pool:
+                order = self._capture_in_wavefront_order()
+            else:
+                got = [None] * self.world
+                while True:
+                    reqs = [g.capture_next(got[r]) for r, g in enumerate(self.graphs)]
+                    assert len({ex.tag if ex is not None else None for ex, _ in reqs}) == 1, "ranks must stop at the same exchange"
+                    if reqs[0][0] is None:
+                        break
+                    _copy_exchange(reqs)
+                    got = [b for _, b in reqs]
+                order = None
         finally:
             if saved is not None:
                 raft.volume_budget_bytes = saved
         torch.cuda.synchronize(self.device)
         nseg = len(self.graphs[0].segments)
-        assert all(len(g.segments) == nseg for g in self.graphs)
+        assert nseg == self.NSEG and all(len(g.segments) == nseg for g in self.graphs)
         self.order = wavefront_order(self.world, nseg, lambda r, s: sorted(self.graphs[r].segments[s][1].recv))
+        assert order is None or order == self.order, "shared pool: the replay order must be the capture order"
         return self
+
+    def _capture_in_wavefront_order(self):
+        """Captures the (rank, segment) graphs in the order ``wavefront_order`` will issue them (same greedy rule; the sources of an
+        exchange are known once the segment in front of it has been captured), answering every exchange from the captured send
+        tensors.  Returns the order."""
+        pending = sorted((r + s, s, r) for r in range(self.world) for s in range(self.NSEG))
+        issued, order, reqs = set(), [], {}
+        while pending:
+            for i, (_, s, r) in enumerate(pending):
+                if s == 0 or ((r, s - 1) in issued and all((q, s - 1) in issued for q in reqs[(r, s - 1)][0].recv)):
+                    break
+            else:
+                raise RuntimeError("streaming schedule: no segment is ready (cyclic exchange dependencies)")
+            pending.pop(i)
+            got = None
+            if s > 0:
+                ex_prev, got = reqs[(r, s - 1)]
+                for q, (shape, dtype) in ex_prev.recv.items():
+                    t = reqs[(q, s - 1)][0].send[r]
+                    assert tuple(t.shape) == tuple(shape) and t.dtype == dtype, (ex_prev.tag, r, q, t.shape, shape)
+                    got[q].copy_(t)
+            ex, bufs = self.graphs[r].capture_next(got)
+            assert (ex is None) == (s == self.NSEG - 1), f"rank {r}: segment {s} of {self.NSEG}"
+            reqs[(r, s)] = (ex, bufs)
+            issued.add((r, s))
+            order.append((r, s))
+        return order
 
     def replay(self, lockstep=False, concurrent=None):
         """One pass over the loaded clip.  lockstep=True: segment by segment over all ranks on the current stream (the schedule of
@@ -718,6 +803,9 @@ class StreamingClipGraph:
             concurrent = os.environ.get("PP_STREAM_CONCURRENT") == "1"
         if self.order is None:
             raise RuntimeError("StreamingClipGraph.replay(): capture() first")
+        if self.share_pool and (lockstep or concurrent):
+            raise ValueError("StreamingClipGraph(share_pool=True): the graphs share one memory pool and must replay in their capture "
+                             "order, one after the other; build with share_pool=False for the lockstep / concurrent orders")
         cur = torch.cuda.current_stream(self.device)
         nseg = len(self.graphs[0].segments)
         if lockstep:

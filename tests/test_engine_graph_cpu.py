@@ -225,3 +225,39 @@ def test_split_ktable_and_weight_packing():
     ref3 = torch.relu(torch.nn.functional.conv2d(x3.permute(0, 3, 1, 2).double(), w3.double(), b3.double(), stride=2, padding=1))
     err3 = (merge_planes(y3).double() - ref3.permute(0, 2, 3, 1)).abs().max() / ref3.abs().max()
     assert err3 < 2e-6, err3
+
+
+def test_sharded_stage_d_uses_the_clip_cache(models):
+    """sharding.sharded_clip_steps with the REAL engines under the CPU emulation: stage D of a rank runs on the per-clip generator
+    cache of the COMPACT clip of the frames its windows touch (prepare_clip / propagate_windows / forward_window, as the unsharded
+    pass) -- the compact positions of local frames and references, the flow pairs copied into it and the per-rank window batches
+    must reproduce run_clip (up to the emulation's batch-size dependence: one byte on isolated pixels; the GPU tests assert equality)."""
+    from propainter_amd.pipeline import InferenceConfig, run_clip
+    from propainter_amd.sharding import run_logical_shards
+    from propainter_amd.synthetic import synthetic_clip, synthetic_mask
+    L, H, W = 13, 128, 192
+    clip = synthetic_clip(L, H, W, seed=6)
+    masks = np.repeat(synthetic_mask(H, W)[None], L, 0)
+    cfg = InferenceConfig(raft_iter=2, subvideo_length=5, neighbor_length=4, ref_stride=3, fp16=False, window_streams=1)
+    gen = models[2]
+    calls = {"prepare": [], "window": 0}
+    prep, fwd = gen.prepare_clip, gen.forward_window
+
+    def spy_prepare(frames, *a, **k):
+        calls["prepare"].append(frames.shape[1])
+        return prep(frames, *a, **k)
+
+    def spy_window(*a, **k):
+        calls["window"] += 1
+        return fwd(*a, **k)
+
+    with emulated_device_ops():
+        ref = run_clip(models, clip, masks, masks, cfg, torch.device("cpu")).clone()
+        gen.prepare_clip, gen.forward_window = spy_prepare, spy_window
+        try:
+            out = run_logical_shards(models, clip, masks, masks, cfg, torch.device("cpu"), 2)
+        finally:
+            del gen.prepare_clip, gen.forward_window
+    assert len(calls["prepare"]) == 2 and all(2 <= n <= L for n in calls["prepare"]) and calls["window"] >= 4, calls
+    d = (out.int() - ref.int()).abs()
+    assert out.shape == ref.shape and d.max() <= 1 and (d > 0).float().mean() < 1e-4, (d.max(), (d > 0).float().mean())

@@ -468,20 +468,30 @@ def test_streaming_schedule_matches_the_unsharded_pass(models):
     raft.precision = "f16x3"
     try:
         ref_a, ref_b = run_clip(models, clip_a, masks, masks, cfg, dev), run_clip(models, clip_b, masks, masks, cfg, dev)
-        sc = StreamingClipGraph(models, L, H, W, cfg, dev)
-        sc.load(clip_a, masks, masks)
-        sc.capture()
-        assert sc.world == 4 and sc.order[:6] == [(0, 0), (1, 0), (0, 1), (2, 0), (1, 1), (0, 2)]
-        out_a = sc.replay()
-        out_a2 = sc.replay()                      # a second pass over the same static buffers
-        sc.load(clip_b, masks, masks)
-        out_b = sc.replay()
-        out_b_lock = sc.replay(lockstep=True)
+        outs = {}
+        for share in (True, False):
+            # share_pool=True (default): ONE graph memory pool, graphs captured and replayed in the wavefront order;
+            # share_pool=False: a private pool per logical rank, which the lockstep A/B order needs
+            sc = StreamingClipGraph(models, L, H, W, cfg, dev, share_pool=share)
+            sc.load(clip_a, masks, masks)
+            sc.capture()
+            assert sc.world == 4 and sc.order[:6] == [(0, 0), (1, 0), (0, 1), (2, 0), (1, 1), (0, 2)]
+            outs[("a", share)] = sc.replay().clone()
+            outs[("a again", share)] = sc.replay().clone()    # a second pass over the same static buffers
+            sc.load(clip_b, masks, masks)
+            outs[("b", share)] = sc.replay().clone()
+            if share:
+                with pytest.raises(ValueError, match="share_pool"):
+                    sc.replay(lockstep=True)
+            else:
+                outs[("b lockstep", share)] = sc.replay(lockstep=True).clone()
+            del sc
     finally:
         raft.precision = None
     torch.cuda.synchronize()
-    for name, got, ref in (("a", out_a, ref_a), ("a again", out_a2, ref_a), ("b", out_b, ref_b), ("b lockstep", out_b_lock, ref_b)):
-        assert torch.equal(got, ref), f"streaming pass ({name}) differs in {(got != ref).float().mean().item():.3e} of bytes"
+    for (name, share), got in outs.items():
+        ref = ref_a if name.startswith("a") else ref_b
+        assert torch.equal(got, ref), f"streaming pass ({name}, share_pool={share}) differs in {(got != ref).float().mean().item():.3e} of bytes"
 
 
 def test_generator_nearest_interpolation_and_batch_of_two(models, sds):

@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--volume-gb", type=float, default=40.0)
     ap.add_argument("--skip-whole-pass", action="store_true")
+    ap.add_argument("--private-pools", action="store_true", help="also run the schedule with one private graph pool per logical rank + its lockstep A/B")
     args = ap.parse_args()
     hip.lib()
     dev = torch.device("cuda", 0)
@@ -64,24 +65,38 @@ def main():
 
     torch.cuda.reset_peak_memory_stats(dev)
     t0 = time.perf_counter()
-    sc = StreamingClipGraph(models, L, H, W, cfg, dev, volume_gb=args.volume_gb)
+    sc = StreamingClipGraph(models, L, H, W, cfg, dev, volume_gb=args.volume_gb)          # default: ONE graph memory pool, wavefront capture order
     sc.load(clip, masks, masks)
     sc.capture()
     rec["streaming_capture_s"] = time.perf_counter() - t0
     rec["logical_ranks"] = sc.world
     rec["issue_order_head"] = sc.order[:12]
     ms_stream, out_stream = timed(sc.replay, args.steps, dev)
-    ms_lock, out_lock = timed(lambda: sc.replay(lockstep=True), args.steps, dev)
-    out_stream, out_lock = out_stream.clone(), out_lock.clone()
+    out_stream = out_stream.clone()
     rec["streaming"] = {"ms_per_clip": ms_stream, "frames_per_s": L / ms_stream * 1e3}
-    rec["same_graphs_lockstep"] = {"ms_per_clip": ms_lock, "frames_per_s": L / ms_lock * 1e3}
-    rec["streaming_equals_lockstep"] = bool(torch.equal(out_stream, out_lock))
-    rec["streaming_peak_reserved_GB"] = torch.cuda.max_memory_reserved(dev) / 1e9
+    rec["streaming_peak_reserved_GB"] = torch.cuda.max_memory_reserved(dev) / 1e9        # incl. the eager warm-up pass of every logical rank
+    torch.cuda.empty_cache()
+    rec["streaming_reserved_steady_GB"] = torch.cuda.memory_reserved(dev) / 1e9           # what a serving loop holds: the graph pool + static buffers
     print(json.dumps(rec), file=sys.stderr, flush=True)
+    del sc
+    torch.cuda.empty_cache()
+
+    if args.private_pools:      # the same segment graphs with one private pool per logical rank: the lockstep A/B order needs them
+        torch.cuda.reset_peak_memory_stats(dev)
+        sp = StreamingClipGraph(models, L, H, W, cfg, dev, volume_gb=args.volume_gb, share_pool=False)
+        sp.load(clip, masks, masks)
+        sp.capture()
+        ms_priv, out_priv = timed(sp.replay, args.steps, dev)
+        ms_lock, out_lock = timed(lambda: sp.replay(lockstep=True), args.steps, dev)
+        rec["private_pools"] = {"ms_per_clip": ms_priv, "frames_per_s": L / ms_priv * 1e3, "peak_reserved_GB": torch.cuda.max_memory_reserved(dev) / 1e9,
+                                "equals_shared_pool": bool(torch.equal(out_priv, out_stream))}
+        rec["same_graphs_lockstep"] = {"ms_per_clip": ms_lock, "frames_per_s": L / ms_lock * 1e3}
+        rec["streaming_equals_lockstep"] = bool(torch.equal(out_priv, out_lock))
+        print(json.dumps(rec), file=sys.stderr, flush=True)
+        del sp, out_priv, out_lock
+        torch.cuda.empty_cache()
 
     if not args.skip_whole_pass:
-        del sc
-        torch.cuda.empty_cache()
         torch.cuda.reset_peak_memory_stats(dev)
         t0 = time.perf_counter()
         g = ClipGraph(models, L, H, W, cfg, dev, example=(clip, masks, masks), release_eager_pool=True)
@@ -89,6 +104,8 @@ def main():
         ms_whole, out_whole = timed(g.replay, args.steps, dev)
         rec["whole_pass"] = {"ms_per_clip": ms_whole, "frames_per_s": L / ms_whole * 1e3}
         rec["whole_pass_peak_reserved_GB"] = torch.cuda.max_memory_reserved(dev) / 1e9
+        torch.cuda.empty_cache()
+        rec["whole_pass_reserved_steady_GB"] = torch.cuda.memory_reserved(dev) / 1e9
         rec["streaming_equals_whole_pass"] = bool(torch.equal(out_stream, out_whole))
         rec["speedup_streaming_vs_whole_pass"] = ms_whole / ms_stream
     print(json.dumps(rec))
