@@ -107,6 +107,9 @@ def parse():
     ap.add_argument("--single-pass", action="store_true",
                     help="profiling aid: run exactly ONE eager pass of the clip and exit (what the rocprofv3 passes of "
                          "tools/gpu_profile.sh wrap, so that per-kernel counts are per pass)")
+    ap.add_argument("--steady-pass", action="store_true",
+                    help="profiling aid: one eager pass (engine build), a 1.5 s pause, then ONE more eager pass; "
+                         "tools/rocprof_summary.py stats keeps the kernels after the pause = a steady-state pass without setup kernels")
     ap.add_argument("--cpu-sample-frames", type=int, default=6,
                     help="frames of the CPU-oracle sample clip at the bench resolution (6 frames of 720x1280: ~2 min on 16 threads, "
                          "next to the GPU legs)")
@@ -316,9 +319,13 @@ def main():
         comp = run_clip(models, frames_dev, masks_dev, masks_dev, cfg, dev, stage_hook=stage_hook)
         host_out.copy_(comp, non_blocking=True)
 
-    if args.single_pass:
+    if args.single_pass or args.steady_pass:
         eager_step()
         torch.cuda.synchronize()
+        if args.steady_pass:       # a second, steady-state pass behind a 1.5 s pause: tools/rocprof_summary.py keeps the kernels after the pause
+            time.sleep(1.5)        # (the first pass builds the engines: ~1 200 weight-packing copies and elementwise kernels that are not per-pass work)
+            eager_step()
+            torch.cuda.synchronize()
         print(json.dumps({"single_pass": True, "height": H, "width": W, "frames": L, "raft_dtype": args.raft_dtype}))
         return
     # ---- setup (untimed, like model load in the reference protocol): one eager pass builds the engines (weight

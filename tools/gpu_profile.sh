@@ -6,7 +6,7 @@ R=$(pwd)
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp
 CMD="python $R/bench.py --single-pass --window-streams 1 --raft-streams 1 --no-cpu-baseline $BENCH_ARGS"   # windows serialised: per-launch durations are not overlapped
-timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_trace --output-format csv -- $CMD > $R/gpurun_out/prof_trace.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_trace --output-format csv -- ${CMD/--single-pass/--steady-pass} > $R/gpurun_out/prof_trace.log 2>&1
 echo "trace exit $?"
 if [ -z "$SKIP_PMC" ]; then
   timeout 900 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/pmc_fetch --output-format csv -- $CMD > $R/gpurun_out/pmc_fetch.log 2>&1

@@ -90,8 +90,22 @@ def short(name, n=110):
 def cmd_stats(root, out):
     rows = collections.OrderedDict()
     files = glob.glob(root + "/**/*kernel_trace.csv", recursive=True)
+    trace = []
     for f in files:
-        for r in csv.DictReader(open(f)):
+        trace += list(csv.DictReader(open(f)))
+    trace.sort(key=lambda r: int(r["Start_Timestamp"]))
+    # bench.py --steady-pass: engine-building pass, a 1.5 s pause, the steady-state pass.  Keep the kernels after the LAST pause of
+    # >= 1 s between two dispatches (a plain --single-pass trace has no such pause after its first kernels and is kept whole)
+    note, cut, last_end = "", 0, None
+    for i, r in enumerate(trace):
+        if last_end is not None and int(r["Start_Timestamp"]) - last_end >= 1_000_000_000 and i > len(trace) // 3:
+            cut = i
+        last_end = max(last_end or 0, int(r["End_Timestamp"]))
+    if cut:
+        note = f"; steady-state pass only: the {cut} dispatches before the marker pause (engine build + first pass) dropped"
+        trace = trace[cut:]
+    if True:
+        for r in trace:
             k = r.get("Kernel_Name", "?")
             dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3      # us
             a = rows.setdefault(k, [0, 0.0, 1e30, 0.0])
@@ -107,7 +121,7 @@ def cmd_stats(root, out):
         a[1] += v[1]
     with open(out, "w") as fo:
         fo.write(f"# rocprofv3 --kernel-trace summary ({len(files)} trace file(s), {sum(v[0] for v in rows.values())} dispatches, "
-                 f"{total / 1e3:.1f} ms of kernel time)\n\n## By kernel family (bench.py KernelProfiler classes)\n\n")
+                 f"{total / 1e3:.1f} ms of kernel time{note})\n\n## By kernel family (bench.py KernelProfiler classes)\n\n")
         fo.write("| family | calls | total ms | avg us | % |\n|---|---:|---:|---:|---:|\n")
         for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1]):
             fo.write(f"| {k} | {v[0]} | {v[1] / 1e3:.2f} | {v[1] / v[0]:.1f} | {100 * v[1] / total:.1f} |\n")
