@@ -11,9 +11,12 @@
 //     is staged ONCE (64 contiguous bytes per pixel = one full sector) and serves all 9 taps x 4 corners from LDS;
 //   * per tap (one 32-deep K step) each lane computes exactly its own MFMA A fragment: the bilinear, mask-modulated
 //     sample of 8 channels (corner weights in fp32, the 4-corner blend in packed fp16: the sample is an fp16 MFMA
-//     operand anyway) for pixel (lane & 15) and group slot (lane >> 4) -- no A tile in LDS at all; the weight
-//     fragments (128 couts x 32 k) come straight from L2 (the same 8 KB for every block of the launch), prefetched one K step
-//     ahead;
+//     operand anyway) for pixel (lane & 15) and group slot (lane >> 4) -- no A tile in LDS at all;
+//   * the weights of a tap (128 couts x 32 k = 8 KB, the same for every block of the launch) go through ONE LDS stage per block:
+//     two LDS-DMA pieces per wave, issued right after every wave has read the previous tap's fragments, land while the MFMAs of that
+//     tap and the sampling of the next one run.  (Rounds 2-3 had every wave fetch all 128 couts per lane straight from L2: 32 KB per
+//     block and tap through the texture path, the largest item of the ablations in profiles/r2_dcn_patch_kernel.txt; the stage fits
+//     since the modulation masks are staged per channel block -- 80-byte rows instead of 144-byte rows holding two blocks.)
 //   * a sample whose corners fall outside the staged patch (|offset - tile mean| >= 5) reads those corners from global
 //     memory: slower, never wrong.  Outside the image every corner contributes zero (torchvision's bilinear_interpolate).
 // 4 waves, wave tile 32 pixels x 128 couts, v_mfma_f32_16x16x32_f16, fp32 accumulation; 2 blocks per CU.
@@ -23,9 +26,23 @@ namespace pp {
 
 constexpr int DCN_TH = 8, DCN_TW = 16, DCN_R0 = 6, DCN_PH = DCN_TH + 13, DCN_PW = DCN_TW + 13;   // patch rows / columns
 constexpr int DCN_PATCH_BYTES = DCN_PH * DCN_PW * 64;
-constexpr int DCN_OSTR = 72;                                 // fp16 per pixel and stage row: 144 bytes = 9 x 16-byte units
-constexpr int DCN_OFFS_BYTES = 2 * 128 * DCN_OSTR * 2;       // one row array for (dy, dx) pairs, one for modulation masks
-constexpr int DCN_LDS = DCN_PATCH_BYTES + DCN_OFFS_BYTES + 64;
+constexpr int DCN_OSTR = 72;                                 // (dy, dx) pairs: fp16 per pixel and stage row: 144 bytes = 9 x 16-byte units
+constexpr int DCN_MSTR = 40;                                 // modulation masks: 36 fp16 (nine 8-byte units) per pixel in 80-byte rows
+constexpr int DCN_OFFS_BYTES = 128 * DCN_OSTR * 2;
+constexpr int DCN_MSKS_BYTES = 128 * DCN_MSTR * 2;
+constexpr int DCN_WST_BYTES = 128 * 64;                      // weight stage of one tap: 128 couts x 32 k, 64-byte rows, 16-byte slot ^ ((row >> 1) & 3)
+constexpr int DCN_LDS = DCN_PATCH_BYTES + DCN_OFFS_BYTES + DCN_MSKS_BYTES + DCN_WST_BYTES + 64;
+static_assert(DCN_LDS <= 80 * 1024, "two blocks per CU");
+
+typedef __attribute__((address_space(3))) void* dcn_lptr3_t;
+#if defined(__HIP_DEVICE_COMPILE__)
+// (a free function with by-value arguments: see conv_halo.h)
+static __device__ __forceinline__ void dcn_dma_weights(__amdgpu_buffer_rsrc_t r, char* dst, int voff0, int voff1, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (dcn_lptr3_t)dst, 16, voff0, soff, 0, 0);
+  // second piece from the same M0 value: the instruction offset is added to the LDS address AND to the global one (voff1 carries -1024)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (dcn_lptr3_t)dst, 16, voff1, soff, 1024, 0);
+}
+#endif
 
 // CG: channels per offset group (8 or 16).  GB = 32 / CG groups per 32-channel block.
 template <int CG>
@@ -37,10 +54,11 @@ __global__ __launch_bounds__(256, 2) void conv_dcn_patch_kernel(const ConvParams
   __shared__ __attribute__((aligned(16))) char lds[DCN_LDS];
   char* const patch = lds;
   _Float16* const offs = reinterpret_cast<_Float16*>(lds + DCN_PATCH_BYTES);          // [128][72]: 36 (dy, dx) pairs
-  _Float16* const msks = offs + 128 * DCN_OSTR;                                      // [128][72]: 72 masks
+  _Float16* const msks = reinterpret_cast<_Float16*>(lds + DCN_PATCH_BYTES + DCN_OFFS_BYTES);      // [128][40]: 36 masks
+  char* const wst = lds + DCN_PATCH_BYTES + DCN_OFFS_BYTES + DCN_MSKS_BYTES;          // [128 couts][64 B]
   constexpr int OG = DCN_OSTR / NOFF;         // channel blocks served by one staged offset row (gen 1, flow completion 2)
-  constexpr int MG = DCN_OSTR / NMSK;         // ... by one staged mask row (2 / 4)
-  float* const red = reinterpret_cast<float*>(lds + DCN_PATCH_BYTES + DCN_OFFS_BYTES);     // [4 waves][2] + shift[2]
+  constexpr int MG = 36 / NMSK;               // ... by one staged mask row (1 / 2)
+  float* const red = reinterpret_cast<float*>(lds + DCN_PATCH_BYTES + DCN_OFFS_BYTES + DCN_MSKS_BYTES + DCN_WST_BYTES);     // [4 waves][2] + shift[2]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -76,18 +94,18 @@ __global__ __launch_bounds__(256, 2) void conv_dcn_patch_kernel(const ConvParams
   const int gi = CG == 8 ? l4 : (l4 >> 1);
 
   const __amdgpu_buffer_rsrc_t rw = uniform_buffer_rsrc(p.weight, p.cout_pad * p.kchunks * 16);
-  // weight fragments: row (cout) = n0 + nt * 16 + l15, 16 bytes at k = step * 32 + l4 * 8
-  int wvoff[8];
+  // weight stage of a K step: pieces 2 * wave, 2 * wave + 1 (16 couts x 64 B each) by this wave; lane -> (row lane >> 2, physical
+  // slot lane & 3), which holds the 16 bytes at k = step * 32 + 8 * (slot ^ ((row >> 1) & 3))
+  int wdma_voff[2];
 #pragma unroll
-  for (int nt = 0; nt < 8; ++nt) {
-    int row = n0 + nt * 16 + l15;
+  for (int j = 0; j < 2; ++j) {
+    int row = n0 + (wave * 2 + j) * 16 + (lane >> 2);
     if (row >= p.cout_pad) row = p.cout_pad - 1;            // clamped rows feed accumulators that are never stored
-    wvoff[nt] = row * p.kchunks * 16 + l4 * 16;
+    wdma_voff[j] = row * p.kchunks * 16 + (((lane & 3) ^ ((lane >> 3) & 3)) << 4) - j * 1024;     // (piece 1: see dcn_dma_weights)
   }
-  auto load_w = [&](int step, u32x4 (&b)[8]) {
-#pragma unroll
-    for (int nt = 0; nt < 8; ++nt) b[nt] = __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff[nt], step * 64, 0);
-  };
+  char* const wst_wave = wst + wave * 2048;
+  // fragment nt of the lane: cout row nt * 16 + l15, k slot l4
+  const int wfrag = l15 * 64 + ((l4 ^ ((l15 >> 1) & 3)) << 4);
 
   f32x4 acc[8][2];
 #pragma unroll
@@ -96,8 +114,8 @@ __global__ __launch_bounds__(256, 2) void conv_dcn_patch_kernel(const ConvParams
     for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nblocks = p.kchunks / 36;         // 32-channel blocks (9 taps x 4 chunks each)
-  u32x4 wcur[8], wnxt[8];
-  load_w(0, wcur);
+  u32x4 wcur[8];
+  dcn_dma_weights(rw, wst_wave, wdma_voff[0], wdma_voff[1], 0);      // K step 0: lands during the first block's staging
   int shift_y = 0, shift_x = 0;
 
   for (int cb = 0; cb < nblocks; ++cb) {
@@ -134,9 +152,30 @@ __global__ __launch_bounds__(256, 2) void conv_dcn_patch_kernel(const ConvParams
         if (i < NU) *reinterpret_cast<u32x4*>(dst + (i / 9) * DCN_OSTR + (i % 9) * 8) = v[k];
       }
     };
+    // ---- masks: 72 contiguous bytes per pixel (nine 8-byte loads: a block's masks start at a multiple of 8 bytes only) hold the
+    //      masks of MG channel blocks
+    auto stage72 = [&](const int first_channel, _Float16* dst) {
+      constexpr int NU = 128 * 9, ITER = (NU + 255) / 256;
+      u32x2 v[ITER];
+#pragma unroll
+      for (int k = 0; k < ITER; ++k) {
+        const int i = tid + k * 256;
+        const int q = i / 9, u = i - q * 9;
+        const int py = ty0 + q / DCN_TW, px = tx0 + q % DCN_TW;
+        v[k] = u32x2{0, 0};
+        if (i < NU && py < p.H && px < p.W)
+          v[k] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const _Float16*>(p.dcn) +
+                                                 (img0 + (long long)py * p.W + px) * p.dcn_cstride + first_channel + u * 4);
+      }
+#pragma unroll
+      for (int k = 0; k < ITER; ++k) {
+        const int i = tid + k * 256;
+        if (i < NU) *reinterpret_cast<u32x2*>(dst + (i / 9) * DCN_MSTR + (i % 9) * 4) = v[k];
+      }
+    };
     if (!(dbg & 1)) {
       if (cb % OG == 0) stage144(2 * 9 * g0, offs);
-      if (cb % MG == 0) stage144(p.dcn_mask_off + 9 * g0, msks);
+      if (cb % MG == 0) stage72(p.dcn_mask_off + 9 * g0, msks);
     }
     __syncthreads();
     if (cb == 0) {
@@ -201,7 +240,6 @@ __global__ __launch_bounds__(256, 2) void conv_dcn_patch_kernel(const ConvParams
     for (int t = 0; t < 9; ++t) {
       const int step = cb * 9 + t;
       const bool more = step + 1 < nblocks * 9;
-      if (more && !(dbg & 8)) load_w(step + 1, wnxt);        // one K step ahead: the sampling alone is too short to cover L2
       f16x8 af[2];
       const int trow = t / 3, tcol = t - trow * 3;
 #pragma unroll
@@ -211,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void conv_dcn_patch_kernel(const ConvParams
         if (pin[mt] && !(dbg & 4)) {
           const int q = wave * 32 + mt * 16 + l15;
           const h2 dd = *reinterpret_cast<const h2*>(offs + q * DCN_OSTR + (cb % OG) * NOFF + 2 * (gi * 9 + t));
-          const float mk = (float)msks[q * DCN_OSTR + (cb % MG) * NMSK + gi * 9 + t];
+          const float mk = (float)msks[q * DCN_MSTR + (cb % MG) * NMSK + gi * 9 + t];
           const float py = (float)(oy[mt] - 1 + trow) + (float)dd[0];
           const float px = (float)(ox[mt] - 1 + tcol) + (float)dd[1];
           const float fy = floorf(py), fx = floorf(px);
@@ -255,16 +293,21 @@ __global__ __launch_bounds__(256, 2) void conv_dcn_patch_kernel(const ConvParams
 #pragma unroll
         for (int j = 0; j < 4; ++j) { af[mt][2 * j] = r2[j][0]; af[mt][2 * j + 1] = r2[j][1]; }
       }
+      // ---- this step's weights: every wave's two pieces have landed (own DMA: vmcnt, the others': barrier), the fragments go to
+      //      registers, and once every wave holds its fragments the stage is refilled with the next step's weights
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt)
+        wcur[nt] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>((const __attribute__((address_space(3))) char*)wst + nt * 1024 + wfrag);
+      __syncthreads();
+      if (more && !(dbg & 8)) dcn_dma_weights(rw, wst_wave, wdma_voff[0], wdma_voff[1], (step + 1) * 64);
       if (!(dbg & 8))
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
           acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wcur[nt]), af[mt], acc[nt][mt], 0, 0, 0);
-      if (more) {
-#pragma unroll
-        for (int nt = 0; nt < 8; ++nt) wcur[nt] = wnxt[nt];
-      }
     }
   }
 
