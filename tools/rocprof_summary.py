@@ -50,6 +50,8 @@ FAMILIES = [   # (substring of the demangled OR mangled kernel name, family)
     ("nchw_to_nhwc", "nchw_to_nhwc"),
     ("nhwc_to_nchw", "nhwc_to_nchw"),
     ("window_mask", "window_mask"),
+    ("raft_flow_taps", "raft_flow_taps"),
+    ("composite_window", "composite_window"),
 ]
 
 
