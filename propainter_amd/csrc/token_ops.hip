@@ -105,20 +105,26 @@ __global__ void depthwise_pool_kernel(const T* __restrict__ in, const float* __r
 }
 
 // Vectorised variant (C % 8 == 0, k*k*C floats of weights fit LDS): one thread per (output pixel, 8 channels), 16-byte
-// input loads, weights staged once per block in LDS as [tap][C] so a thread reads its 8 weights with two ds_read_b128.
-// Same accumulation order (bias, then taps in row-major order) as the scalar kernel: identical results.
-template <typename T>
+// input loads, weights staged once per block in LDS.  Same accumulation order (bias, then taps in row-major order) as the scalar
+// kernel: identical results.
+// K > 0: the window size at compile time (the generator's pool_layer is 4 x 4): the K * K input loads of an output are independent and
+// all in flight together -- with a run-time k the tap loop stays rolled and a thread waits for one 16-byte load at a time (56 us per
+// launch at 2.1 TB/s, profiles/r4z_rocprof_kernel_stats_720p.md).  Weight layout [tap][half][C / 8][4]: the 16 lanes of a ds_read_b128 group
+// read 16 consecutive 16-byte slots (the [tap][C] layout put a lane's two reads 32 bytes apart: 2-way conflicts, SQ_LDS_BANK_CONFLICT /
+// SQ_LDS_IDX_ACTIVE = 0.74).
+template <typename T, int K>
 __global__ __launch_bounds__(256) void depthwise_pool8_kernel(const T* __restrict__ in, const float* __restrict__ wgt,
                                                               const float* __restrict__ bias, T* __restrict__ out, int N, int H,
-                                                              int W, int C, int k) {
-  extern __shared__ float wl[];                       // [k*k][C]
-  const int kk = k * k;
+                                                              int W, int C, int k_rt) {
+  extern __shared__ float wl[];                       // [k*k][2][C / 8][4]
+  const int k = K > 0 ? K : k_rt;
+  const int kk = k * k, c8 = C / 8;
   for (int i = threadIdx.x; i < kk * C; i += blockDim.x) {
     const int c = i / kk, t = i - c * kk;
-    wl[t * C + c] = wgt[i];
+    wl[((t * 2 + ((c >> 2) & 1)) * c8 + (c >> 3)) * 4 + (c & 3)] = wgt[i];
   }
   __syncthreads();
-  const int OH = H / k, OW = W / k, c8 = C / 8;
+  const int OH = H / k, OW = W / k;
   const long long total = (long long)N * OH * OW * c8;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int cc = (int)(i % c8);
@@ -128,15 +134,28 @@ __global__ __launch_bounds__(256) void depthwise_pool8_kernel(const T* __restric
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = bias ? bias[cc * 8 + j] : 0.f;
-    for (int ky = 0; ky < k; ++ky)
-      for (int kx = 0; kx < k; ++kx) {
-        float v[8];
-        load8<T>(in + ((n * H + oy * k + ky) * (long long)W + ox * k + kx) * C + cc * 8, v);
-        const float* wp = wl + (ky * k + kx) * C + cc * 8;
-        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wp), w1 = *reinterpret_cast<const f32x4*>(wp + 4);
+    const T* base = in + ((n * H + oy * k) * (long long)W + ox * k) * C + cc * 8;
+    if constexpr (K > 0) {
+      float v[K * K][8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { acc[j] += w0[j] * v[j]; acc[4 + j] += w1[j] * v[4 + j]; }
+      for (int t = 0; t < K * K; ++t) load8<T>(base + ((t / K) * (long long)W + (t % K)) * C, v[t]);
+#pragma unroll
+      for (int t = 0; t < K * K; ++t) {
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wl + ((t * 2) * c8 + cc) * 4), w1 = *reinterpret_cast<const f32x4*>(wl + ((t * 2 + 1) * c8 + cc) * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[j] += w0[j] * v[t][j]; acc[4 + j] += w1[j] * v[t][4 + j]; }
       }
+    } else {
+      for (int ky = 0; ky < k; ++ky)
+        for (int kx = 0; kx < k; ++kx) {
+          float v[8];
+          load8<T>(base + (ky * (long long)W + kx) * C, v);
+          const int t = ky * k + kx;
+          const f32x4 w0 = *reinterpret_cast<const f32x4*>(wl + ((t * 2) * c8 + cc) * 4), w1 = *reinterpret_cast<const f32x4*>(wl + ((t * 2 + 1) * c8 + cc) * 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { acc[j] += w0[j] * v[j]; acc[4 + j] += w1[j] * v[4 + j]; }
+        }
+    }
     store8<T>(out + pix * C + cc * 8, acc);
   }
 }
@@ -430,10 +449,15 @@ extern "C" int pp_depthwise_pool(const void* in, const float* weight, const floa
   PP_REQUIRE(dtype == PP_F32 || dtype == PP_F16, PP_ERR_DTYPE, "pp_depthwise_pool: dtype %d", dtype);
   if (C % 8 == 0 && (size_t)k * k * C * sizeof(float) <= 48 * 1024 && (uintptr_t)in % 16 == 0 && (uintptr_t)out % 16 == 0) {
     int g8 = grid_for((long long)N * (H / k) * (W / k) * (C / 8));
-    if (g8 > 512) g8 = 512;                           // every block stages the weights once: keep the blocks long-lived
+    if (g8 > 768) g8 = 768;                           // every block stages the weights once: keep the blocks long-lived (3 per CU: 256 / 512 / 768 / 1024 blocks = 50 / 41 / 37 / 45 us at 720p)
     const size_t shm = (size_t)k * k * C * sizeof(float);
-    PP_DISPATCH_T(dtype, hipLaunchKernelGGL((depthwise_pool8_kernel<T>), dim3(g8), dim3(256), shm, (hipStream_t)stream, (const T*)in,
-                                            weight, bias, (T*)out, N, H, W, C, k);)
+    if (k == 4) {
+      PP_DISPATCH_T(dtype, hipLaunchKernelGGL((depthwise_pool8_kernel<T, 4>), dim3(g8), dim3(256), shm, (hipStream_t)stream, (const T*)in,
+                                              weight, bias, (T*)out, N, H, W, C, k);)
+    } else {
+      PP_DISPATCH_T(dtype, hipLaunchKernelGGL((depthwise_pool8_kernel<T, 0>), dim3(g8), dim3(256), shm, (hipStream_t)stream, (const T*)in,
+                                              weight, bias, (T*)out, N, H, W, C, k);)
+    }
     return launch_status("pp_depthwise_pool");
   }
   const int g = grid_for((long long)N * (H / k) * (W / k) * C);
