@@ -372,6 +372,12 @@ int pp_gru_gate(const void* zr, int zr_cstride, const void* h, int h_cstride, in
  * out_dtype PP_F16S (fp32 input): split-plane output, lo plane at out_cstride / 2. */
 int pp_nchw_to_nhwc(const void* in, int in_dtype, void* out, int out_dtype, int out_cstride, int out_choff, int N,
                     int C, int H, int W, float scale, void* stream);
+
+/* Encoder input packer: up to three planar sources [N,c_i,H,W] of one dtype (c0 + c1 + c2 <= 8; in1 / in2 may be NULL with c = 0) ->
+ * NHWC [N,H,W,8], missing channels zero, one launch writing whole 16-byte rows.  Replaces the reference's
+ * torch.cat([frames, masks_in, masks_updated], dim=2) in front of the Encoder (model/propainter.py:334-336). */
+int pp_pack_nhwc8(const void* in0, int c0, const void* in1, int c1, const void* in2, int c2, void* out, int N, int H, int W,
+                  int dtype, void* stream);
 int pp_nhwc_to_nchw(const void* in, int in_dtype, int in_cstride, int in_choff, void* out, int out_dtype, int N,
                     int C, int H, int W, int act, void* stream);
 

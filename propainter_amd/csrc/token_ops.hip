@@ -387,6 +387,28 @@ __global__ void nchw_to_nhwc_split_kernel(const float* __restrict__ in, _Float16
     out[(n * HW + p) * ocs + ocs / 2 + oco + c] = (_Float16)(v - (float)hi);
   }
 }
+// Up to three planar sources [N,c_i,H,W] -> ONE NHWC row of 8 channels per pixel (missing channels zero): the encoder input
+// cat(frame, mask, updated mask) of model/propainter.py:334-336.  One thread per pixel: coalesced plane reads, one 16-byte (fp16) /
+// two 16-byte (fp32) row stores -- three pp_nchw_to_nhwc calls into the same buffer write 2 of every 16 bytes each (three partial-sector
+// passes over the 236 MB buffer of a 16-frame 720p chunk: 300 us per call).
+template <typename T>
+__global__ __launch_bounds__(256) void pack_nhwc8_kernel(const T* __restrict__ a, int ca, const T* __restrict__ b, int cb, const T* __restrict__ c,
+                                                         int cc, T* __restrict__ out, long long N, int HW) {
+  const long long total = N * HW;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long n = i / HW;
+    const int p = (int)(i - n * HW);
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j < ca) v[j] = to_f32(a[(n * ca + j) * HW + p]);
+      else if (j < ca + cb) v[j] = to_f32(b[(n * cb + (j - ca)) * HW + p]);
+      else if (j < ca + cb + cc) v[j] = to_f32(c[(n * cc + (j - ca - cb)) * HW + p]);
+    }
+    store8<T>(out + i * 8, v);
+  }
+}
+
 template <typename TI, typename TO>
 __global__ void nhwc_to_nchw_kernel(const TI* __restrict__ in, int ics, int ico, TO* __restrict__ out, int N, int C, int HW,
                                     int act) {
@@ -571,6 +593,19 @@ extern "C" int pp_nchw_to_nhwc(const void* in, int in_dtype, void* out, int out_
                 hipLaunchKernelGGL((nchw_to_nhwc_kernel<TI, TO>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const TI*)in, (TO*)out,
                                    out_cstride, out_choff, N, C, H * W, scale);)
   return launch_status("pp_nchw_to_nhwc");
+}
+
+extern "C" int pp_pack_nhwc8(const void* in0, int c0, const void* in1, int c1, const void* in2, int c2, void* out, int N, int H, int W,
+                             int dtype, void* stream) {
+  PP_REQUIRE(in0 && out && N > 0 && H > 0 && W > 0 && c0 > 0 && c1 >= 0 && c2 >= 0 && c0 + c1 + c2 <= 8, PP_ERR_ARG,
+             "pp_pack_nhwc8: bad arguments (%d + %d + %d channels must be 1..8)", c0, c1, c2);
+  PP_REQUIRE((c1 == 0 || in1) && (c2 == 0 || in2), PP_ERR_ARG, "pp_pack_nhwc8: a source with channels needs a pointer");
+  PP_REQUIRE(dtype == PP_F32 || dtype == PP_F16, PP_ERR_DTYPE, "pp_pack_nhwc8: dtype %d", dtype);
+  PP_REQUIRE((uintptr_t)out % 16 == 0, PP_ERR_ALIGN, "pp_pack_nhwc8: out must be 16-byte aligned");
+  const int g = grid_for((long long)N * H * W);
+  PP_DISPATCH_T(dtype, hipLaunchKernelGGL((pack_nhwc8_kernel<T>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const T*)in0, c0, (const T*)in1, c1,
+                                          (const T*)in2, c2, (T*)out, (long long)N, H * W);)
+  return launch_status("pp_pack_nhwc8");
 }
 
 extern "C" int pp_nhwc_to_nchw(const void* in, int in_dtype, int in_cstride, int in_choff, void* out, int out_dtype, int N, int C,

@@ -316,10 +316,7 @@ class _GenEngine:
         outs = []
         for s in range(0, t, chunk):
             e = min(t, s + chunk)
-            x = torch.zeros((e - s, H, W, 8), dtype=dt, device=dev)
-            hip.nchw_to_nhwc(masked_frames[0, s:e].contiguous(), out=x, out_choff=0)
-            hip.nchw_to_nhwc(masks_in[0, s:e].contiguous(), out=x, out_choff=3)
-            hip.nchw_to_nhwc(masks_updated[0, s:e].contiguous(), out=x, out_choff=4)
+            x = hip.pack_nhwc8([v[0, s:e].to(dt).contiguous() for v in (masked_frames, masks_in, masks_updated)])      # cat(frame, mask, updated mask) (:334-336)
             outs.append(self.encode(x))
         return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
 

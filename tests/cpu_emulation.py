@@ -350,6 +350,16 @@ def _gru_gate(zr, h, h_choff, Cc, out, out_choff, q=None):
     return out
 
 
+def _pack_nhwc8(srcs, out=None):
+    x = torch.cat(list(srcs), 1)
+    N, c, H, W = x.shape
+    if out is None:
+        out = torch.empty((N, H, W, 8), dtype=x.dtype, device=x.device)
+    out.zero_()
+    out[..., :c] = x.permute(0, 2, 3, 1)
+    return out
+
+
 def _nchw_to_nhwc(x, out=None, out_choff=0, out_dtype=None, cpad=None, scale=1.0, split=False):
     N, Cc, H, W = x.shape
     if out is None:
@@ -374,7 +384,7 @@ def emulated_device_ops():
         "convex_upsample": _convex_upsample, "window_mask": _window_mask, "raft_flow_taps": _raft_flow_taps,
         "sparse_window_attention": _attention, "fold_tokens": _fold_tokens, "layernorm": _layernorm,
         "depthwise_pool": _depthwise_pool, "instance_norm": _instance_norm, "upsample2x": _upsample2x,
-        "dcn_offset_mask_act": _dcn_act, "gru_gate": _gru_gate, "nchw_to_nhwc": _nchw_to_nhwc, "nhwc_to_nchw": _nhwc_to_nchw,
+        "dcn_offset_mask_act": _dcn_act, "gru_gate": _gru_gate, "nchw_to_nhwc": _nchw_to_nhwc, "nhwc_to_nchw": _nhwc_to_nchw, "pack_nhwc8": _pack_nhwc8,
         "instance_norm_split": _instance_norm_split, "layernorm_grid": _layernorm_grid,
     }
     patches["require_gpu"] = lambda t, who: None

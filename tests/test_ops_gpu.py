@@ -367,6 +367,31 @@ def test_256x256_tile_is_bit_identical_to_the_256x128_tile(dev, k, cin, cout):
     check("tile256", outs[18][..., 8:8 + cout].permute(0, 3, 1, 2), ref, 1e-2)
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.float32], ids=["f16", "f32"])
+def test_pack_nhwc8_equals_three_window_writes(dev, dt):
+    """pp_pack_nhwc8 (the encoder input cat(frame, mask, updated mask), model/propainter.py:334-336, as one launch of whole 16-byte rows)
+    against three pp_nchw_to_nhwc channel-window writes into a zeroed buffer: identical bytes, odd sizes, one and two sources as well."""
+    from propainter_amd import hip
+    g = torch.Generator().manual_seed(9)
+    N, H, W = 3, 37, 53
+    a, b, c = (torch.randn(N, k, H, W, generator=g).to(dev, dt) for k in (3, 1, 1))
+    ref = torch.zeros(N, H, W, 8, dtype=dt, device=dev)
+    hip.nchw_to_nhwc(a, out=ref, out_choff=0)
+    hip.nchw_to_nhwc(b, out=ref, out_choff=3)
+    hip.nchw_to_nhwc(c, out=ref, out_choff=4)
+    out = torch.full((N, H, W, 8), 7.0, dtype=dt, device=dev)
+    assert hip.pack_nhwc8([a, b, c], out=out) is out
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    one = hip.pack_nhwc8([a])
+    two = hip.pack_nhwc8([b, a])
+    torch.cuda.synchronize()
+    assert torch.equal(one[..., :3], ref[..., :3]) and (one[..., 3:] == 0).all()
+    assert torch.equal(two[..., 0], ref[..., 3]) and torch.equal(two[..., 1:4], ref[..., :3]) and (two[..., 4:] == 0).all()
+    with pytest.raises(AssertionError):
+        hip.pack_nhwc8([torch.zeros(N, 5, H, W, dtype=dt, device=dev), torch.zeros(N, 4, H, W, dtype=dt, device=dev)])
+
+
 def test_conv2d_output_window_and_large_m(dev):
     """writes into a channel window of a wider buffer; M not a multiple of the tile; asymmetric data (transposes)."""
     from propainter_amd.conv import ConvLayer
