@@ -112,7 +112,7 @@ def test_batched_feature_propagation_graph(models):
     the per-window path) must give the same composite."""
     from propainter_amd.pipeline import InferenceConfig, run_clip, window_schedule
     from propainter_amd.synthetic import synthetic_clip, synthetic_mask
-    L, H, W = 14, 128, 192
+    L, H, W = 14, 128, 128
     clip = synthetic_clip(L, H, W, seed=5)
     masks = np.repeat(synthetic_mask(H, W)[None], L, 0)
     lens = [len(nb) for nb, _ in window_schedule(L, 4, 3, 80)]
@@ -235,7 +235,7 @@ def test_sharded_stage_d_uses_the_clip_cache(models):
     from propainter_amd.pipeline import InferenceConfig, run_clip
     from propainter_amd.sharding import run_logical_shards
     from propainter_amd.synthetic import synthetic_clip, synthetic_mask
-    L, H, W = 13, 128, 192
+    L, H, W = 13, 128, 128
     clip = synthetic_clip(L, H, W, seed=6)
     masks = np.repeat(synthetic_mask(H, W)[None], L, 0)
     cfg = InferenceConfig(raft_iter=1, subvideo_length=5, neighbor_length=6, ref_stride=4, fp16=False, window_streams=1)
