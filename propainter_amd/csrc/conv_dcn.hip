@@ -24,15 +24,10 @@
 
 namespace pp {
 
-constexpr int DCN_TH = 8, DCN_TW = 16, DCN_R0 = 6, DCN_PH = DCN_TH + 13, DCN_PW = DCN_TW + 13;   // patch rows / columns
-constexpr int DCN_PATCH_BYTES = DCN_PH * DCN_PW * 64;
+constexpr int DCN_TW = 16, DCN_R0 = 6, DCN_PW = DCN_TW + 13;   // tile width, patch margin, patch columns
 constexpr int DCN_OSTR = 72;                                 // (dy, dx) pairs: fp16 per pixel and stage row: 144 bytes = 9 x 16-byte units
 constexpr int DCN_MSTR = 40;                                 // modulation masks: 36 fp16 (nine 8-byte units) per pixel in 80-byte rows
-constexpr int DCN_OFFS_BYTES = 128 * DCN_OSTR * 2;
-constexpr int DCN_MSKS_BYTES = 128 * DCN_MSTR * 2;
 constexpr int DCN_WST_BYTES = 128 * 64;                      // weight stage of one tap: 128 couts x 32 k, 64-byte rows, 16-byte slot ^ ((row >> 1) & 3)
-constexpr int DCN_LDS = DCN_PATCH_BYTES + DCN_OFFS_BYTES + DCN_MSKS_BYTES + DCN_WST_BYTES + 64;
-static_assert(DCN_LDS <= 80 * 1024, "two blocks per CU");
 
 typedef __attribute__((address_space(3))) void* dcn_lptr3_t;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -45,9 +40,19 @@ static __device__ __forceinline__ void dcn_dma_weights(__amdgpu_buffer_rsrc_t r,
 #endif
 
 // CG: channels per offset group (8 or 16).  GB = 32 / CG groups per 32-channel block.
-template <int CG>
+// DCN_TH: tile rows.  8 (128 pixels, two 16-pixel M tiles per wave) is the throughput form; 4 (64 pixels, one M tile per wave) halves a
+// block's work for launches that do not fill the chip anyway: the recurrent steps of flow completion run over 2 x 90 x 160 pixels = 225
+// tiles of 128 pixels for 512 block slots -- their time is ONE block's latency.
+template <int CG, int DCN_TH>
 __global__ __launch_bounds__(256, 2) void conv_dcn_patch_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int NPX = DCN_TH * DCN_TW, MT = NPX / 64;       // pixels per tile, 16-pixel M tiles per wave
+  constexpr int DCN_PH = DCN_TH + 13;                        // patch rows
+  constexpr int DCN_PATCH_BYTES = DCN_PH * DCN_PW * 64;
+  constexpr int DCN_OFFS_BYTES = NPX * DCN_OSTR * 2;
+  constexpr int DCN_MSKS_BYTES = NPX * DCN_MSTR * 2;
+  constexpr int DCN_LDS = DCN_PATCH_BYTES + DCN_OFFS_BYTES + DCN_MSKS_BYTES + DCN_WST_BYTES + 64;
+  static_assert(DCN_LDS <= 80 * 1024 && (MT == 1 || MT == 2), "two blocks per CU");
   constexpr int GB = 32 / CG;                 // offset groups per channel block
   constexpr int NOFF = GB * 9 * 2;            // fp16 offsets per pixel and block (dy, dx interleaved)
   constexpr int NMSK = GB * 9;                // fp16 masks per pixel and block
@@ -80,12 +85,12 @@ __global__ __launch_bounds__(256, 2) void conv_dcn_patch_kernel(const ConvParams
   const int n0 = tn * 128;
   const long long img0 = (long long)n * p.H * p.W;
 
-  // the lane's two pixels (M tiles 0 / 1 of the wave): tile-local index q = wave * 32 + mt * 16 + l15
-  int oy[2], ox[2];
-  bool pin[2];
+  // the lane's pixels (M tiles of the wave): tile-local index q = (wave * MT + mt) * 16 + l15
+  int oy[MT], ox[MT];
+  bool pin[MT];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    const int q = wave * 32 + mt * 16 + l15;
+  for (int mt = 0; mt < MT; ++mt) {
+    const int q = (wave * MT + mt) * 16 + l15;
     oy[mt] = ty0 + q / DCN_TW;
     ox[mt] = tx0 + q % DCN_TW;
     pin[mt] = oy[mt] < p.H && ox[mt] < p.W;
@@ -107,11 +112,11 @@ __global__ __launch_bounds__(256, 2) void conv_dcn_patch_kernel(const ConvParams
   // fragment nt of the lane: cout row nt * 16 + l15, k slot l4
   const int wfrag = l15 * 64 + ((l4 ^ ((l15 >> 1) & 3)) << 4);
 
-  f32x4 acc[8][2];
+  f32x4 acc[8][MT];
 #pragma unroll
   for (int a = 0; a < 8; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nblocks = p.kchunks / 36;         // 32-channel blocks (9 taps x 4 chunks each)
   u32x4 wcur[8];
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void conv_dcn_patch_kernel(const ConvParams
     //      blocks and the masks of MG channel blocks; loads of a thread are issued together (a rolled loop pays one memory
     //      latency per unit: measured 42 of the kernel's 121 us with 4- and 8-byte units)
     auto stage144 = [&](const int first_channel, _Float16* dst) {
-      constexpr int NU = 128 * 9, ITER = (NU + 255) / 256;
+      constexpr int NU = NPX * 9, ITER = (NU + 255) / 256;
       u32x4 v[ITER];
 #pragma unroll
       for (int k = 0; k < ITER; ++k) {
@@ -155,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void conv_dcn_patch_kernel(const ConvParams
     // ---- masks: 72 contiguous bytes per pixel (nine 8-byte loads: a block's masks start at a multiple of 8 bytes only) hold the
     //      masks of MG channel blocks
     auto stage72 = [&](const int first_channel, _Float16* dst) {
-      constexpr int NU = 128 * 9, ITER = (NU + 255) / 256;
+      constexpr int NU = NPX * 9, ITER = (NU + 255) / 256;
       u32x2 v[ITER];
 #pragma unroll
       for (int k = 0; k < ITER; ++k) {
@@ -181,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void conv_dcn_patch_kernel(const ConvParams
     if (cb == 0) {
       // ---- mean offset of the tile (first block's groups) -> integer patch shift, once per block
       float sy = 0.f, sx = 0.f;
-      for (int i = tid; i < 128 * 36; i += 256) {            // all 36 pairs of the staged row
+      for (int i = tid; i < NPX * 36; i += 256) {            // all 36 pairs of the staged row
         const int q = i / 36, j = i - q * 36;
         sy += (float)offs[q * DCN_OSTR + 2 * j];
         sx += (float)offs[q * DCN_OSTR + 2 * j + 1];
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void conv_dcn_patch_kernel(const ConvParams
       if (lane == 0) { red[wave * 2] = sy; red[wave * 2 + 1] = sx; }
       __syncthreads();
       if (tid == 0) {
-        const float inv = 1.f / (float)(128 * 36);
+        const float inv = 1.f / (float)(NPX * 36);
         float my = (red[0] + red[2] + red[4] + red[6]) * inv, mx = (red[1] + red[3] + red[5] + red[7]) * inv;
         my = fminf(fmaxf(my, -4096.f), 4096.f);
         mx = fminf(fmaxf(mx, -4096.f), 4096.f);
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void conv_dcn_patch_kernel(const ConvParams
     //      them for every alignment of the 16 pixels (tools/lds_swizzle_check.py, tests/test_host_logic_cpu.py).
     const int py0 = ty0 - 1 - DCN_R0 + 1 + shift_y - 0, px0 = tx0 - 1 - DCN_R0 + 1 + shift_x - 0;   // = tile origin - 6 + shift
     if (!(dbg & 2)) {
-      constexpr int NC = DCN_PH * DCN_PW * 4, ITER = (NC + 255) / 256, BATCH = 5;
+      constexpr int NC = DCN_PH * DCN_PW * 4, ITER = (NC + 255) / 256, BATCH = ITER % 5 == 0 ? 5 : (ITER % 4 == 0 ? 4 : (ITER % 3 == 0 ? 3 : 1));
       static_assert(ITER % BATCH == 0, "patch chunks per thread");
 #pragma unroll 1
       for (int k0 = 0; k0 < ITER; k0 += BATCH) {
@@ -240,14 +245,14 @@ __global__ __launch_bounds__(256, 2) void conv_dcn_patch_kernel(const ConvParams
     for (int t = 0; t < 9; ++t) {
       const int step = cb * 9 + t;
       const bool more = step + 1 < nblocks * 9;
-      f16x8 af[2];
+      f16x8 af[MT];
       const int trow = t / 3, tcol = t - trow * 3;
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
+      for (int mt = 0; mt < MT; ++mt) {
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));
         h2 r2[4] = {h2{0, 0}, h2{0, 0}, h2{0, 0}, h2{0, 0}};
         if (pin[mt] && !(dbg & 4)) {
-          const int q = wave * 32 + mt * 16 + l15;
+          const int q = (wave * MT + mt) * 16 + l15;
           const h2 dd = *reinterpret_cast<const h2*>(offs + q * DCN_OSTR + (cb % OG) * NOFF + 2 * (gi * 9 + t));
           const float mk = (float)msks[q * DCN_MSTR + (cb % MG) * NMSK + gi * 9 + t];
           const float py = (float)(oy[mt] - 1 + trow) + (float)dd[0];
@@ -306,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void conv_dcn_patch_kernel(const ConvParams
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
           acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wcur[nt]), af[mt], acc[nt][mt], 0, 0, 0);
     }
   }
@@ -321,7 +326,7 @@ __global__ __launch_bounds__(256, 2) void conv_dcn_patch_kernel(const ConvParams
       bv[nt][r] = (p.bias != nullptr && co < p.cout_g) ? p.bias[co] : 0.f;          // 32 independent loads: one latency
     }
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int mt = 0; mt < MT; ++mt) {
     if (!pin[mt]) continue;
     const long long m = img0 + (long long)oy[mt] * p.W + ox[mt];
 #pragma unroll
@@ -359,10 +364,19 @@ int conv_dcn_dispatch(const ConvParams& pin_, hipStream_t stream, int dbg) {
   for (int i = 0; i < p.nsrc; ++i)
     if ((p.src[i].cstride & 7) != 0 || (p.src[i].choff & 7) != 0) return -1000;
   p.tiles_n = (p.cout_g + 127) / 128;
-  const long long nblk = (long long)p.N * ((p.H + DCN_TH - 1) / DCN_TH) * ((p.W + DCN_TW - 1) / DCN_TW) * p.tiles_n;
-  if (nblk >= (1ll << 31)) return -1000;
-  if (cin == 128) hipLaunchKernelGGL((conv_dcn_patch_kernel<8>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL((conv_dcn_patch_kernel<16>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
+  const long long tiles_x = (p.W + DCN_TW - 1) / DCN_TW;
+  const long long nblk8 = (long long)p.N * ((p.H + 7) / 8) * tiles_x * p.tiles_n, nblk4 = (long long)p.N * ((p.H + 3) / 4) * tiles_x * p.tiles_n;
+  if (nblk4 >= (1ll << 31)) return -1000;
+  // launches of at most one block per CU: 64-pixel tiles (twice the blocks, half the latency of a block); dbg 16 / 32 force 8 / 4 rows
+  const bool small = (dbg & 32) || (!(dbg & 16) && nblk8 <= 256);
+  p.tap_w = dbg & 15;
+  if (small) {
+    if (cin == 128) hipLaunchKernelGGL((conv_dcn_patch_kernel<8, 4>), dim3((unsigned)nblk4), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((conv_dcn_patch_kernel<16, 4>), dim3((unsigned)nblk4), dim3(256), 0, stream, p);
+  } else {
+    if (cin == 128) hipLaunchKernelGGL((conv_dcn_patch_kernel<8, 8>), dim3((unsigned)nblk8), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((conv_dcn_patch_kernel<16, 8>), dim3((unsigned)nblk8), dim3(256), 0, stream, p);
+  }
   return launch_status("pp_conv2d(dcn)");
 }
 

@@ -621,9 +621,9 @@ extern "C" int pp_conv2d(const pp_conv_args_t* a, void* stream) {
     PP_REQUIRE(a->impl < 10, PP_ERR_ARG, "pp_conv2d: impl %d not available for this shape", a->impl);
   }
 #if defined(PP_DIAG)
-  const bool dcn_impl = a->impl == 0 || (a->impl >= 90 && a->impl < 106);
+  const bool dcn_impl = a->impl == 0 || (a->impl >= 90 && a->impl < 138);
 #else
-  const bool dcn_impl = a->impl == 0 || a->impl == 90;
+  const bool dcn_impl = a->impl == 0 || a->impl == 90 || a->impl == 106 || a->impl == 122;      // 106 / 122: force 128- / 64-pixel tiles (conv_dcn.hip)
 #endif
   if (a->dtype == PP_F16 && deform && dcn_impl) {
     // patch-staged deformable kernel (16 offset groups of 8 / 16 channels, stride 1, 3x3)

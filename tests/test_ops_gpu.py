@@ -613,13 +613,15 @@ def test_deform_conv_patch_staged_kernel(dev, case):
             srcs.append(nhwc(x[:, o_:o_ + c], dt))
             o_ += c
     outs = {}
-    for impl in (90, 1):
+    for impl in (90, 106, 122, 1):     # 90: tile rows by launch size; 106 / 122: 128- / 64-pixel tiles forced; 1: register-staged gather
         layer.impl = impl
         if "out" in kw:
             kw["out"] = torch.full((N, H, W, 144), 2.0, dtype=dt, device=dev)
         o = layer(srcs, dcn_offmask=om, **kw)
         torch.cuda.synchronize()
         outs[impl] = o
+    # the two tile heights sample the same corners with the same arithmetic (only the staged patch differs): identical bytes
+    assert torch.equal(outs[106], outs[122]) and torch.equal(outs[90], outs[122])
     if "out" in kw:
         assert (outs[90][..., :8] == 2).all() and (outs[90][..., 136:] == 2).all()
         got90, got1 = outs[90][..., 8:136], outs[1][..., 8:136]

@@ -8,7 +8,7 @@ from propainter_amd.conv import ConvLayer
 
 dev = torch.device("cuda")
 g = torch.Generator().manual_seed(0)
-NB = 8      # batch: the GPU time must dominate the ~150 us of Python per launch
+NB = int(os.environ.get("NB", "8"))      # batch: the GPU time must dominate the ~150 us of Python per launch (NB=2: the flow-completion step shape)
 for name, cin, H, W in (("gen", [128], 180, 320), ("fc", [128, 128], 90, 160)):
     ctot = sum(cin)
     w = torch.randn(128, ctot, 3, 3, generator=g) / math.sqrt(ctot * 9)
@@ -26,7 +26,7 @@ for name, cin, H, W in (("gen", [128], 180, 320), ("fc", [128, 128], 90, 160)):
         om = torch.cat([off, torch.rand(NB, H, W, 144, generator=g)], -1).to(dev, torch.float16).contiguous()
         # 90 = patch-staged kernel, 1 = register-staged gather; 90 + flags = ablations of the patch-staged kernel
         # (1 no offset staging, 2 no patch staging, 4 no sampling, 8 no weights / MFMA: results are garbage, timing only)
-        for impl in ((90, 1, 91, 92, 94, 98, 105) if dist == 'small' else (90, 1)):
+        for impl in ((90, 106, 122, 1) if dist in ('small', 'tanh3+flow') else (90, 1)):      # 106 / 122: 128- / 64-pixel tiles forced (90: by launch size)
             layer.impl = impl
             for _ in range(3):
                 layer(srcs, dcn_offmask=om)
