@@ -113,15 +113,21 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(const float* __restric
 
 // One thread per fine output pixel pair (both flow channels): softmax over the 9 mask logits of its
 // (coarse pixel, sub-position) and convex combination of the 3x3 coarse neighbourhood of 8*flow.
+// Thread order: the 64 sub-positions of ONE coarse pixel are the 64 lanes of a wave, so every mask read of a wave is 256 contiguous
+// bytes (the mask is the large operand: 576 logits per coarse pixel against 128 output values); the output goes out as eight 32-byte
+// row pieces per wave.  (Fine-pixel raster order read the mask in 32-byte pieces of eight different rows: 3.5x the algorithmic HBM
+// bytes, profiles/r4z_hbm_traffic_720p.json.)
 template <typename TM>
 __global__ void convex_upsample_kernel(const float* __restrict__ flow, const TM* __restrict__ mask, int mcs,
                                        float* __restrict__ out, int B, int h, int w) {
   const int OW = 8 * w, OH = 8 * h;
   const long long total = (long long)B * OH * OW;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int X = (int)(i % OW), Y = (int)((i / OW) % OH);
-    const long long n = i / ((long long)OW * OH);
-    const int x = X >> 3, y = Y >> 3, sub = (Y & 7) * 8 + (X & 7);
+    const int sub = (int)(i & 63);
+    const long long cp = i >> 6;                               // coarse pixel (n, y, x)
+    const int x = (int)(cp % w), y = (int)((cp / w) % h);
+    const long long n = cp / ((long long)w * h);
+    const int X = 8 * x + (sub & 7), Y = 8 * y + (sub >> 3);
     const TM* mp = mask + ((n * h + y) * (long long)w + x) * mcs + sub;
     float lg[9], mx = -INFINITY;
 #pragma unroll
