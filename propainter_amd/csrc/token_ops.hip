@@ -276,11 +276,8 @@ __global__ void inorm_apply_split_kernel(const float* __restrict__ in, const flo
 // bilinear x2, align_corners=True: src = dst * (in-1)/(out-1).  One block per output row (n, oy) -- the row's source rows and
 // vertical weight are block-uniform -- and 32-bit index arithmetic inside the row (the grid-stride form spent its time in 64-bit
 // divisions: 2.6 TB/s on a pass that reads every input pixel four times from L1 / L2 and writes 4x its input once).
-// (POW2: C / 8 is a power of two -- 64 and 128 channels in the decoders -- so the item -> (pixel, channel chunk) split is a shift and a
-//  mask; the integer division was a fifth of the kernel's VALU work, and the kernel is not purely HBM-bound: ~130 VALU instructions per
-//  16-byte output item)
-template <typename T, bool POW2>
-__global__ __launch_bounds__(256) void upsample2x_kernel(const T* __restrict__ in, T* __restrict__ out, int N, int H, int W, int C, int cshift) {
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_kernel(const T* __restrict__ in, T* __restrict__ out, int N, int H, int W, int C) {
   const int OH = 2 * H, OW = 2 * W;
   const int cch = C / 8;
   const float sy = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
@@ -296,7 +293,7 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const T* __restrict__ i
     const T* r1 = in + ((long long)n * H + y1) * W * C;
     T* orow = out + (long long)row * OW * C;
     for (int i = threadIdx.x; i < per_row; i += 256) {
-      const int ox = POW2 ? (i >> cshift) : i / cch, cc = POW2 ? (i & (cch - 1)) : i - ox * cch;
+      const int ox = i / cch, cc = i - ox * cch;
       const float fx = sx * (float)ox;
       const int x0 = (int)fx;
       const int x1 = min(x0 + 1, W - 1);
@@ -546,16 +543,8 @@ extern "C" int pp_upsample2x(const void* in, void* out, int N, int H, int W, int
   PP_REQUIRE((long long)N * 2 * H < (1ll << 31) && (long long)2 * W * C < (1ll << 31), PP_ERR_ARG, "pp_upsample2x: %d x %d x %d x %d too large", N, H, W, C);
   const long long rows = (long long)N * 2 * H;
   const int g = (int)(rows < 256 * 64 ? rows : 256 * 64);      // one block per output row, grid-stride beyond 64 blocks per CU
-  const int cch = C / 8;
-  if ((cch & (cch - 1)) == 0) {
-    int cshift = 0;
-    while ((1 << cshift) < cch) ++cshift;
-    PP_DISPATCH_T(dtype, hipLaunchKernelGGL((upsample2x_kernel<T, true>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const T*)in, (T*)out,
-                                            N, H, W, C, cshift);)
-  } else {
-    PP_DISPATCH_T(dtype, hipLaunchKernelGGL((upsample2x_kernel<T, false>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const T*)in, (T*)out,
-                                            N, H, W, C, 0);)
-  }
+  PP_DISPATCH_T(dtype, hipLaunchKernelGGL((upsample2x_kernel<T>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const T*)in, (T*)out,
+                                          N, H, W, C);)
   return launch_status("pp_upsample2x");
 }
 
