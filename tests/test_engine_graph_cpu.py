@@ -112,7 +112,7 @@ def test_batched_feature_propagation_graph(models):
     the per-window path) must give the same composite."""
     from propainter_amd.pipeline import InferenceConfig, run_clip, window_schedule
     from propainter_amd.synthetic import synthetic_clip, synthetic_mask
-    L, H, W = 14, 128, 128
+    L, H, W = 10, 128, 128
     clip = synthetic_clip(L, H, W, seed=5)
     masks = np.repeat(synthetic_mask(H, W)[None], L, 0)
     lens = [len(nb) for nb, _ in window_schedule(L, 4, 3, 80)]
