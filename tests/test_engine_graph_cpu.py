@@ -261,3 +261,25 @@ def test_sharded_stage_d_uses_the_clip_cache(models):
     assert len(calls["prepare"]) == 2 and all(2 <= n <= L for n in calls["prepare"]) and calls["window"] >= 3, calls
     d = (out.int() - ref.int()).abs()
     assert out.shape == ref.shape and d.max() <= 1 and (d > 0).float().mean() < 1e-4, (d.max(), (d > 0).float().mean())
+
+
+@pytest.mark.parametrize("name,L,mk", [("two_frames", 2, "normal"), ("no_hole", 3, "zeros")])
+def test_edge_clips_through_the_host_path(models, name, L, mk):
+    """The shortest clip (one flow pair, one window) and a mask without any hole through run_clip under the CPU emulation vs the oracle's
+    restated driver: window schedule, per-clip cache and composite at the edges of their ranges (the GPU twin with more cases:
+    tests/test_modules_gpu.py::test_edge_clips_vs_oracle_driver)."""
+    from propainter_amd.pipeline import InferenceConfig, run_clip
+    from propainter_amd.synthetic import synthetic_clip, synthetic_mask
+    from tests.helpers import seeded_sds
+    H, W = 128, 192
+    clip = synthetic_clip(L, H, W, seed=40 + L)
+    m = synthetic_mask(H, W)
+    m = np.zeros_like(m) if mk == "zeros" else m
+    masks = np.repeat(m[None], L, 0)
+    cfg = InferenceConfig(raft_iter=2, subvideo_length=80, neighbor_length=4, ref_stride=3, fp16=False, window_streams=1)
+    with emulated_device_ops():
+        comp = run_clip(models, clip, masks, masks, cfg, torch.device("cpu")).numpy()
+    ref = np.stack(O.inpaint_video(seeded_sds(), clip, masks, masks, raft_iter=2, subvideo_length=80, neighbor_length=4, ref_stride=3))
+    d = np.abs(comp.astype(int) - ref.astype(int))
+    assert comp.shape == ref.shape and (comp[masks == 0] == clip[masks == 0]).all()
+    assert d.max() <= 1 and O.psnr(comp, ref) > 80.0, (O.psnr(comp, ref), d.max())

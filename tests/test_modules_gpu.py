@@ -842,3 +842,29 @@ def test_compute_flow_and_flow_completion_entry_points(tmp_path):
     res3 = ev.evaluate(ev.build_parser().parse_args(common + ["--result_root", str(tmp_path / "r3"), "--fp16"]), out=lambda *_: None)
     assert abs(res["epe"] - res3["epe"]) <= 2e-2 * max(1.0, res["epe"]), (res["epe"], res3["epe"])
     print("FLOW_COMPLETION_REPORT", last[0], "| load_flow", res2["epe"], "| fp16", res3["epe"])
+
+
+EDGE_CLIPS = [("two_frames", 2, "normal", 4), ("no_hole", 3, "zeros", 4), ("all_hole", 3, "ones", 4), ("five_frames_nl2", 5, "normal", 2)]
+
+
+@pytest.mark.parametrize("name,L,mk,nl", EDGE_CLIPS, ids=[c[0] for c in EDGE_CLIPS])
+def test_edge_clips_vs_oracle_driver(models, sds, name, L, mk, nl):
+    """The shortest clips the reference accepts and degenerate masks through the whole path vs the oracle's restated driver: two frames
+    (one flow pair, one window), a mask without any hole (every attention window unmasked: the persistent masked-window kernel gets an
+    empty work list; the composite must return the input bytes), a mask that is all hole (every window masked, nothing to propagate from),
+    and windows of two local frames."""
+    from propainter_amd.pipeline import InferenceConfig, run_clip
+    from propainter_amd.synthetic import synthetic_clip, synthetic_mask
+    H, W = 128, 192
+    clip = synthetic_clip(L, H, W, seed=40 + L)
+    m = synthetic_mask(H, W)
+    m = np.zeros_like(m) if mk == "zeros" else (np.full_like(m, 255) if mk == "ones" else m)
+    masks = np.repeat(m[None], L, 0)
+    cfg = InferenceConfig(raft_iter=2, subvideo_length=80, neighbor_length=nl, ref_stride=3, fp16=False)
+    comp = run_clip(models, clip, masks, masks, cfg, torch.device("cuda")).cpu().numpy()
+    ref = np.stack(O.inpaint_video(sds, clip, masks, masks, raft_iter=2, subvideo_length=80, neighbor_length=nl, ref_stride=3))
+    d = np.abs(comp.astype(int) - ref.astype(int))
+    psnr = O.psnr(comp, ref)
+    print(f"EDGE_CLIP {name}: psnr {psnr:.2f} dB, max |d| {d.max()}")
+    assert comp.shape == ref.shape and (comp[masks == 0] == clip[masks == 0]).all()
+    assert d.max() <= 1 and psnr > 80.0, (psnr, d.max())
