@@ -57,6 +57,10 @@ int conv_v2_dispatch(const ConvParams& p, int cfg, hipStream_t stream) {
     case 16: return launch_v2<256, 128, 32, 2, 2, 4>(p, uni, stream);   // 4 waves 128x64, 96 KiB
     case 17: return launch_v2<256, 128, 64, 2, 2, 2>(p, uni, stream);   // 4 waves 128x64, 96 KiB
     case 18: return launch_v2<256, 256, 64, 4, 2, 2>(p, uni, stream);   // 8 waves 64x128, 2 stages: 128 KiB -- half the DMA bytes per MFMA of 13
+    // 19 (sweep only, NOT measured yet -- compiled at the end of round 4 without GPU time left): the same block tile as 4 waves of 128 x 128,
+    // one wave per SIMD, the 256 accumulator registers in AGPRs (256 VGPRs + 256 AGPRs, no scratch inside the K loop, 784 B/lane in the
+    // epilogue): half the LDS fragment reads per MFMA of 18 (8 waves of 64 x 128 read 192 B/clk per CU at the MFMA rate, 75 % of the LDS)
+    case 19: return launch_v2<256, 256, 64, 2, 2, 2>(p, uni, stream);
     case 20: return launch_v2<128, 64, 32, 2, 2, 4>(p, uni, stream);    // wave tile 64x32, 48 KiB -> 3 blocks/CU
     case 21: return launch_v2<256, 64, 32, 4, 1, 4>(p, uni, stream);    // wave tile 64x64, 80 KiB
     case 22: return launch_v2<256, 64, 64, 4, 1, 2>(p, uni, stream);    // 80 KiB -> 2 blocks/CU

@@ -44,7 +44,7 @@ SHAPES = [
     ("gen_dec_64_cout3", 11, 720, 1280, [64], 3, (3, 3), 1, 1, 1),
     ("fc_dec_32_3x3", 16, 360, 640, [32], 32, (3, 3), 1, 1, 1),
 ]
-IMPLS = {"cout>64": [1, 112, 12, 10, 11, 13, 14, 17, 18], "cout>32": [1, 122, 22, 20, 21], "cout>16": [1, 132, 32, 30, 31], "cout<=16": [1, 142, 42, 40, 41]}
+IMPLS = {"cout>64": [1, 112, 12, 10, 11, 13, 14, 17, 18, 19], "cout>32": [1, 122, 22, 20, 21], "cout>16": [1, 132, 32, 30, 31], "cout<=16": [1, 142, 42, 40, 41]}
 
 
 def impls_for(cout_g):
