@@ -9,6 +9,9 @@ scripts/evaluate_propainter.py:100-101,181-184: decode, mask dilation and model 
     python bench.py --gpus 1 --steps 2 --warmup 1                      # 720x1280, 80 frames, fp16 (BASELINE C3)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W                         # N independent clips, one per GPU (weak scaling)
+    python bench.py --gpus N ...                                       # the same: without WORLD_SIZE in the environment bench.py
+                                                                       # re-executes itself under torch.distributed.run with N ranks
+                                                                       # (the reference's own launch is mp.spawn(nprocs=world_size), train.py:105)
     ... bench.py --gpus N --sharded --frames 320                        # BASELINE C4: ONE clip, sub-video shards over N GPUs
     ... bench.py --gpus N --sharded --height 1080 --width 1920 --frames 160 --subvideo_length 20     # BASELINE C5
 
@@ -71,7 +74,7 @@ def pmc_traffic(kernel_class, raft_dtype):
     return (best[1], best[2]) if best else (None, None)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
@@ -115,7 +118,105 @@ def parse():
                          "next to the GPU legs)")
     ap.add_argument("--cpu-timeout", type=float, default=480.0, help="hard limit of the CPU-oracle child process, seconds")
     ap.add_argument("--cpu-baseline-worker", default=None, help=argparse.SUPPRESS)
-    return ap.parse_args()
+    ap.add_argument("--no-configs", action="store_true", help="skip the short timing of BASELINE config 2 (432x240x80) reported under `configs`")
+    ap.add_argument("--no-stress", action="store_true", help="skip the stress-recipe leg (`stress`: non-tame weights / motion / border mask)")
+    return ap.parse_args(argv)
+
+
+def launch_plan(args, environ, argv, n_devices):
+    """How this invocation runs (pure: tests/test_bench_launch_cpu.py).  ``--gpus N`` IS the number of ranks of the job:
+      * WORLD_SIZE set (launched by torch.distributed.run, as the driver does for N > 1): it must equal --gpus -> ("run", world);
+      * WORLD_SIZE unset and --gpus 1 -> ("run", 1);
+      * WORLD_SIZE unset and --gpus N > 1 -> ("spawn", command): re-execute under ``python -m torch.distributed.run --nnodes=1
+        --nproc-per-node N --master-addr 127.0.0.1`` (one process per GPU over RCCL; the reference's multi-process launch is
+        ``mp.spawn(main_worker, nprocs=world_size)``, train.py:105) -- ``python bench.py --gpus 8`` used to bench ONE GPU silently.
+    Raises SystemExit with the reason when the request cannot be met (more ranks than devices, WORLD_SIZE != --gpus)."""
+    if args.gpus < 1:
+        raise SystemExit(f"--gpus {args.gpus}: need at least one rank")
+    if n_devices is not None and args.gpus > n_devices:
+        raise SystemExit(f"--gpus {args.gpus}: this node exposes {n_devices} device(s) (one rank per GPU)")
+    ws = environ.get("WORLD_SIZE")
+    if ws is not None:
+        if int(ws) != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ws}: launch with --nproc-per-node {args.gpus} (or drop WORLD_SIZE and let "
+                             f"bench.py spawn its own ranks)")
+        return "run", int(ws)
+    if args.gpus == 1:
+        return "run", 1
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(argv[0])] + list(argv[1:])
+    return "spawn", cmd
+
+
+class DeviceRuntime:
+    """What bench.py needs from the device side.  The product runtime is this class (HIP device, RCCL, hipGraphs); the CPU test harness
+    (tests/bench_cpu_harness.py) substitutes stand-in models on the CPU over gloo so that the launch / rendezvous / timing / reporting
+    path of an N-rank job is exercised end to end without a GPU -- never used by a real run."""
+    backend = "nccl"
+    graphs = True           # hipGraph capture of the pass
+    extras = True           # roofline / cpu_baseline / parity / precisions / configs / stress legs
+
+    def n_devices(self):
+        import torch
+        return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+    def device(self, local):
+        import torch
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+        torch.cuda.set_device(local)
+        return torch.device("cuda", local)
+
+    def init_library(self):
+        from propainter_amd import hip
+        hip.lib()
+
+    def models(self, dev, raft_dtype):
+        from propainter_amd.synthetic import seeded_models
+        return seeded_models(dev, raft_precision=raft_dtype)
+
+    def pin(self, t):
+        return t.pin_memory()
+
+    def sync(self):
+        import torch
+        torch.cuda.synchronize()
+
+    def event(self):
+        import torch
+        return torch.cuda.Event(enable_timing=True)
+
+    def reset_peak(self, dev):
+        import torch
+        torch.cuda.reset_peak_memory_stats(dev)
+
+    def peak_allocated(self, dev):
+        import torch
+        return torch.cuda.max_memory_allocated(dev)
+
+    def peak_reserved(self, dev):
+        import torch
+        return torch.cuda.max_memory_reserved(dev)
+
+    def reserved(self, dev):
+        import torch
+        return torch.cuda.memory_reserved(dev)
+
+    def free_bytes(self, dev):
+        import torch
+        return torch.cuda.mem_get_info(dev)[0]
+
+    def total_memory(self, dev):
+        import torch
+        return torch.cuda.get_device_properties(dev).total_memory
+
+    def empty_cache(self):
+        import torch
+        torch.cuda.empty_cache()
 
 
 def sample_clip(args):
@@ -252,36 +353,51 @@ def parity_of(got_u8, ref_u8, masks_u8, gt_u8=None):
             "bytes_off_by_more_than_1_frac_hole": float((d[hole] > 1).mean()) if hole.any() else 0.0}
 
 
-def main():
-    args = parse()
+def main(argv=None, runtime=None):
+    """argv / runtime: only the CPU test harness passes them (tests/bench_cpu_harness.py); a real run uses sys.argv and DeviceRuntime."""
+    argv = list(sys.argv) if argv is None else list(argv)
+    args = parse(argv[1:])
     if args.cpu_baseline_worker:
         _cpu_baseline_worker(args)
         return
+    rt = runtime or DeviceRuntime()
+    how, plan = launch_plan(args, os.environ, argv, rt.n_devices())
+    if how == "spawn":
+        # --gpus N without a launcher: become the launcher (one rank per GPU; rank 0 of the child job prints the JSON line)
+        sys.stderr.write(f"[bench] --gpus {args.gpus}: launching {args.gpus} ranks: {' '.join(plan)}\n")
+        sys.stderr.flush()
+        os.execv(plan[0], plan)
+    world = plan
+    import datetime
     import numpy as np
     import scipy.ndimage
     import torch
     import torch.distributed as dist
     from propainter_amd import hip
     from propainter_amd.pipeline import InferenceConfig, run_clip, window_schedule
-    from propainter_amd.synthetic import seeded_models, synthetic_clip, synthetic_mask
+    from propainter_amd.synthetic import synthetic_clip, synthetic_mask
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    dev = rt.device(local)
     cpu_job = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and rt.extras:
         cpu_job = CpuBaseline(args)           # host cores only; runs while the GPU legs below execute
+    seen_world = 1
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
-    hip.lib()
+        # a rank that dies takes the job down within the timeout instead of leaving its peers in a collective for ever
+        kw = {"device_id": dev} if rt.backend == "nccl" else {}
+        dist.init_process_group(rt.backend, timeout=datetime.timedelta(seconds=int(os.environ.get("PP_BENCH_DIST_TIMEOUT_S", "600"))), **kw)
+        one = torch.ones(1, device=dev)
+        dist.all_reduce(one)                  # the world size the collective library itself sees (RCCL over xGMI on the GPU box)
+        seen_world = int(one.item())
+        if seen_world != args.gpus or dist.get_world_size() != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus}, but the process group has {dist.get_world_size()} ranks and an all-reduce of ones gives {seen_world}")
+    rt.init_library()
 
     H, W, L = args.height, args.width, args.frames
     fp16 = not args.fp32
-    models = seeded_models(dev, raft_precision=args.raft_dtype)
+    models = rt.models(dev, args.raft_dtype)
     cfg = InferenceConfig(raft_iter=args.raft_iter, subvideo_length=args.subvideo_length,
                           neighbor_length=args.neighbor_length, ref_stride=args.ref_stride, fp16=fp16,
                           window_streams=args.window_streams, raft_streams=args.raft_streams)
@@ -296,9 +412,9 @@ def main():
         use_ranks = world > 1 and can_shard(L, cfg, world)
         if world > 1 and not use_ranks:
             raise SystemExit(f"--sharded: a {L}-frame clip does not split into sub-videos of {args.subvideo_length} over {world} ranks")
-        clip_pin, masks_pin = torch.from_numpy(clip).pin_memory(), torch.from_numpy(masks_np).pin_memory()
+        clip_pin, masks_pin = rt.pin(torch.from_numpy(clip)), rt.pin(torch.from_numpy(masks_np))
         own = ShardPlan(L, cfg, world).own[rank] if use_ranks else (0, L)
-        host_out = torch.empty((max(1, own[1] - own[0]), H, W, 3), dtype=torch.uint8).pin_memory()
+        host_out = rt.pin(torch.empty((max(1, own[1] - own[0]), H, W, 3), dtype=torch.uint8))
         frames_dev = masks_dev = None
         if not use_ranks:
             frames_dev, masks_dev = clip_pin.to(dev), masks_pin.to(dev)
@@ -307,7 +423,7 @@ def main():
         clip = synthetic_clip(L, H, W, seed=2023 + rank)
         frames_dev = torch.from_numpy(clip).to(dev)
         masks_dev = torch.from_numpy(np.repeat(m[None], L, 0)).to(dev)
-        host_out = torch.empty((L, H, W, 3), dtype=torch.uint8).pin_memory()
+        host_out = rt.pin(torch.empty((L, H, W, 3), dtype=torch.uint8))
         use_ranks = False
 
     def eager_step(stage_hook=None, cfg=cfg):
@@ -321,61 +437,76 @@ def main():
 
     if args.single_pass or args.steady_pass:
         eager_step()
-        torch.cuda.synchronize()
+        rt.sync()
         if args.steady_pass:       # a second, steady-state pass behind a 1.5 s pause: tools/rocprof_summary.py keeps the kernels after the pause
             time.sleep(1.5)        # (the first pass builds the engines: ~1 200 weight-packing copies and elementwise kernels that are not per-pass work)
             eager_step()
-            torch.cuda.synchronize()
+            rt.sync()
         print(json.dumps({"single_pass": True, "height": H, "width": W, "frames": L, "raft_dtype": args.raft_dtype}))
         return
     # ---- setup (untimed, like model load in the reference protocol): one eager pass builds the engines (weight
     # packing, K tables, window tables) and primes the allocator; by default the pass is then captured in a hipGraph
     eager_step()
     eager_step()                      # the allocator settles on the second pass (its blocks are carved during the first)
-    torch.cuda.synchronize()
-    torch.cuda.reset_peak_memory_stats(dev)
+    rt.sync()
+    rt.reset_peak(dev)
     t_e = time.perf_counter()
     eager_step()
-    torch.cuda.synchronize()
+    rt.sync()
     eager_ms = (time.perf_counter() - t_e) * 1e3
-    peak_eager = torch.cuda.max_memory_allocated(dev)
-    peak_eager_reserved = torch.cuda.max_memory_reserved(dev)      # what the caching allocator holds from the driver (all stream pools)
+    peak_eager = rt.peak_allocated(dev)
+    peak_eager_reserved = rt.peak_reserved(dev)      # what the caching allocator holds from the driver (all stream pools)
     exchange_stats.clear()
     graph = None
     capture_s = None
     sgraph = None
-    if not args.eager and use_ranks:
+    def vote(ok):
+        """all ranks or none (MIN over the ranks of a 0 / 1 flag)"""
+        t = torch.tensor([1 if ok else 0], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return int(t.item()) == 1
+
+    if not args.eager and use_ranks and rt.graphs:
         # sub-video shards: the compute segments between the four halo exchanges as hipGraphs, the exchanges stay eager RCCL
-        # point-to-point ops (sharding.ShardedClipGraph); falls back to eager submission if the capture is refused
-        from propainter_amd.sharding import ShardedClipGraph, dist_exchanger
+        # point-to-point ops (sharding.ShardedClipGraph); falls back to eager submission if the capture is refused.
+        # The capture executes its exchanges for real, in lock step with the peers: a rank that fails ALONE (out of memory) would
+        # leave them in batch_isend_irecv for ever.  So (1) the ranks vote on a memory check BEFORE anyone starts, and (2) the
+        # capture itself votes after every segment (ShardedClipGraph.capture(vote=...)): a failing rank votes 0, every rank
+        # abandons the capture at the same exchange, and the bench falls back to eager launches on all ranks.
+        from propainter_amd.sharding import CaptureAborted, ShardedClipGraph, dist_exchanger
         t_c = time.perf_counter()
-        try:
-            if torch.cuda.memory_reserved(dev) > torch.cuda.get_device_properties(dev).total_memory // 3:
-                torch.cuda.empty_cache()      # long clips / 1080p: the eager pools back to the driver before the graphs build their own
-            sgraph = ShardedClipGraph(models, L, H, W, cfg, dev, rank, world)
-            sgraph.load(clip_pin, masks_pin, masks_pin)
-            sgraph.capture(dist_exchanger(dev, None, None))
-        except Exception as e:
-            sys.stderr.write(f"[bench] sharded hipGraph capture failed on rank {rank} ({type(e).__name__}: {e}); eager launches\n")
-            sgraph = None
+        if rt.reserved(dev) > rt.total_memory(dev) // 3:
+            rt.empty_cache()                  # long clips / 1080p: the eager pools back to the driver before the graphs build their own
+        need = int(1.15 * peak_eager_reserved)           # the graphs' private pool grows to about what the eager pass reserved
+        have = rt.free_bytes(dev) + rt.reserved(dev)
+        if not vote(have >= need):
+            if have < need:
+                sys.stderr.write(f"[bench] rank {rank}: {have / 1e9:.1f} GB available for the shard graphs, ~{need / 1e9:.1f} GB needed\n")
+            sys.stderr.write(f"[bench] rank {rank}: the ranks voted against the sharded hipGraph capture (memory); eager launches\n")
+        else:
+            try:
+                sgraph = ShardedClipGraph(models, L, H, W, cfg, dev, rank, world)
+                sgraph.load(clip_pin, masks_pin, masks_pin)
+                sgraph.capture(dist_exchanger(dev, None, None), vote=vote)
+            except CaptureAborted as e:
+                sys.stderr.write(f"[bench] sharded hipGraph capture abandoned on rank {rank} ({e}); eager launches\n")
+                sgraph = None
+                rt.sync()
+                rt.empty_cache()
         capture_s = time.perf_counter() - t_c
-        ok = torch.tensor([1 if sgraph is not None else 0], device=dev)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)        # all ranks or none: the exchange pattern must match
-        if int(ok.item()) == 0:
-            sgraph = None
-    if not args.eager and not use_ranks:      # one clip per rank: the whole pass as ONE hipGraph
+    if not args.eager and not use_ranks and rt.graphs:      # one clip per rank: the whole pass as ONE hipGraph
         from propainter_amd.pipeline import ClipGraph
         t_c = time.perf_counter()
         try:
             # the graph gets a private pool as large as the eager pass's: when the eager pools already hold more than a third of the
             # device (long clips / 1080p), hand them back to the driver first
-            big = torch.cuda.memory_reserved(dev) > torch.cuda.get_device_properties(dev).total_memory // 3
+            big = rt.reserved(dev) > rt.total_memory(dev) // 3
             graph = ClipGraph(models, L, H, W, cfg, dev, example=(frames_dev, masks_dev, masks_dev), release_eager_pool=big)
-            torch.cuda.synchronize()
+            rt.sync()
         except Exception as e:       # capture refused (driver / runtime state): measure the eager submission instead of dying
             sys.stderr.write(f"[bench] hipGraph capture failed on rank {rank} ({type(e).__name__}: {e}); falling back to eager launches\n")
             graph = None
-            torch.cuda.synchronize()
+            rt.sync()
         capture_s = time.perf_counter() - t_c
 
     sgraph_x = None
@@ -395,10 +526,10 @@ def main():
         host_out.copy_(graph.replay(), non_blocking=True)
 
     def fence():
-        torch.cuda.synchronize()
+        rt.sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        rt.sync()
 
     for _ in range(args.warmup):
         step()
@@ -406,7 +537,7 @@ def main():
     exchange_stats.clear()
     # per-step markers (diagnostic only, no synchronisation inside the timed region): a HIP event after each step's
     # last launch and the host clock when the step has been fully *submitted*
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    ev = [rt.event() for _ in range(args.steps + 1)]
     host_submit = []
     ev[0].record()
     t0 = time.perf_counter()
@@ -424,7 +555,7 @@ def main():
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
     fps = (L if sharded else world * L) * args.steps / elapsed
-    peak_total = torch.cuda.max_memory_allocated(dev)
+    peak_total = rt.peak_allocated(dev)
     exch = {k: dict(v, ms_per_step=v["ms"] / args.steps, sent_bytes_per_step=v["sent_bytes"] // args.steps,
                     recv_bytes_per_step=v["recv_bytes"] // args.steps) for k, v in exchange_stats.items()} if use_ranks else None
     exch_plan = None
@@ -444,7 +575,7 @@ def main():
 
     # ---- one instrumented step: stage split + per-kernel-class HIP-event timing (not part of `value`)
     stages, kernels, roof = None, None, None
-    if rank == 0 and not args.no_profile and not use_ranks:
+    if rank == 0 and not args.no_profile and not use_ranks and rt.extras:
         marks = []
 
         stage_peaks = {}
@@ -501,7 +632,7 @@ def main():
     raft = models[0]
     submission = ("hipGraph replays of the compute segments between the halo exchanges (sharding.ShardedClipGraph)" if sgraph is not None else
                   "eager (Python launches)" if graph is None else "hipGraph replay of the whole pass (pipeline.ClipGraph)")
-    if rank == 0 and world == 1 and not args.no_precisions and not sharded:
+    if rank == 0 and world == 1 and not args.no_precisions and not sharded and rt.extras:
         raft_precisions = {args.raft_dtype: {"value": fps, "ms_per_step": ms_per_step, "timed": "headline (see value)"}}
         had_graph = graph is not None
         graph = None                      # releases the headline graph's private pool before the other engines are built
@@ -578,7 +709,8 @@ def main():
             roof["whole_pass_frac_of_f16_peak"] = roof["whole_pass_algorithmic_tflops"] / PEAK_TFLOPS["f16"]
         out = {
             "metric": "inpainted frames/sec (whole path, 80-frame window)", "value": fps, "unit": "frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "n_gpus": world, "collective_world_size": seen_world, "collective_backend": (rt.backend if world > 1 else None),
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
             # arithmetic of the timed pass: stages B-D / RAFT (the reference's --fp16 run: fp16 stages, fp32 RAFT -- inference_propainter.py:311,333-337)
             "dtype": ("f16" if fp16 else "f32") + " stages + " + {"f16x3": "f16x3 RAFT (fp32-class: 3 fp16 MFMA products per product, fp32 accumulate)",
@@ -590,7 +722,7 @@ def main():
                        "window_streams": args.window_streams, "raft_streams": args.raft_streams},
             "roofline": roof, "cpu_baseline": cpu, "parity": parity, "raft_precisions": raft_precisions,
             "memory": {"peak_allocated_GB_eager_pass": peak_eager / 1e9, "peak_reserved_GB_eager_pass": peak_eager_reserved / 1e9,
-                       "peak_allocated_GB_process": peak_total / 1e9, "peak_reserved_GB_process": torch.cuda.max_memory_reserved(dev) / 1e9,
+                       "peak_allocated_GB_process": peak_total / 1e9, "peak_reserved_GB_process": rt.peak_reserved(dev) / 1e9,
                        "note": "allocated = live tensors (torch.cuda.max_memory_allocated), reserved = what the caching allocator holds "
                                "from the driver over all stream pools (max_memory_reserved: the figure a device-memory monitor shows); the "
                                "eager pass is what a one-shot CLI run needs, the process figures add the hipGraphs' private pools; "

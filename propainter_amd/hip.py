@@ -163,11 +163,13 @@ def _stream(t):
 _side_streams = {}
 
 
-def side_streams(device, n):
-    """n side streams of `device` (created once, outside any graph capture)."""
+def side_streams(device, n, key=None):
+    """n side streams of `device` (created once, outside any graph capture).  ``key`` (optional, hashable): a private set of lanes
+    for one owner -- the logical ranks of a streaming pass captured into ONE hipGraph each get their own, so that two ranks' windows
+    are not chained through a shared lane (a false dependency in the captured graph)."""
     if n < 2:
         return []
-    key = (str(device), n)
+    key = (str(device), n, key)
     if key not in _side_streams:
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("side streams must be created by an eager pass before graph capture")

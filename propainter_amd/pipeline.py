@@ -187,9 +187,9 @@ _INDEX_CACHE_MAX = 4096
 _index_recorder = None                        # list collecting every index tensor handed out while a ClipGraph is being built
 
 
-def _window_streams(device, n):
-    """n side streams of `device` (created once, outside any graph capture)."""
-    return hip.side_streams(device, n)
+def _window_streams(device, n, key=None):
+    """n side streams of `device` (created once, outside any graph capture); ``key``: see hip.side_streams."""
+    return hip.side_streams(device, n, key)
 
 
 def _dev_index(ids, device):

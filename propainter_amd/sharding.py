@@ -201,10 +201,11 @@ def _halo(x, own, needs, rank, dim, tag):
 # the sharded pass
 # ----------------------------------------------------------------------------------------------------------------
 @torch.no_grad()
-def sharded_clip_steps(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg: InferenceConfig, device, rank, world):
+def sharded_clip_steps(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg: InferenceConfig, device, rank, world, lane_key=None):
     """Generator: rank `rank`'s part of the pass over one clip.  Inputs are the WHOLE clip (uint8 frames [L,H,W,3],
     masks [L,H,W] {0,255}; numpy or tensors, normally host-resident -- every rank reads its slice, no exchange of raw
-    input).  Yields ``Exchange`` requests; returns ``(lo, comp_u8[hi-lo,H,W,3])``, the rank's composited frames."""
+    input).  Yields ``Exchange`` requests; returns ``(lo, comp_u8[hi-lo,H,W,3])``, the rank's composited frames.
+    ``lane_key``: private generator lanes for this rank (hip.side_streams; several logical ranks captured into one hipGraph)."""
     fix_raft, fix_flow_complete, model = models
     L = len(frames_u8)
     plan = ShardPlan(L, cfg, world)
@@ -335,7 +336,7 @@ def sharded_clip_steps(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg: 
             else:
                 blend(idx, cur)
 
-    lanes = _window_streams(device, cfg.window_streams) if device.type == "cuda" else []
+    lanes = _window_streams(device, cfg.window_streams, lane_key) if device.type == "cuda" else []
     if len(lanes) < 2:
         for f, nb, ref in my_windows:
             composite(f, nb, window(nb, ref))
@@ -427,6 +428,10 @@ def run_clip_sharded(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg, de
         return stop.value
 
 
+class CaptureAborted(RuntimeError):
+    """Raised on EVERY rank when one rank's segment failed during ShardedClipGraph.capture(vote=...)."""
+
+
 class _RawSlice:
     """Stands for a whole-clip input array of which one rank reads exactly the slice [r0, r1): sharded_clip_steps only asks for the
     length, the frame shape and that slice."""
@@ -483,17 +488,44 @@ class ShardedClipGraph:
     def _inputs(self):
         return tuple(_RawSlice(t, self.r0, self.L) for t in (self.frames, self.flow_masks, self.masks_dilated))
 
-    def eager(self, exchange):
-        """One eager pass on the static inputs (builds engines, tables and cached index tensors; must precede capture())."""
+    def eager(self, exchange, vote=None):
+        """One eager pass on the static inputs (builds engines, tables and cached index tensors; must precede capture()).
+        ``vote``: see capture()."""
         gen = sharded_clip_steps(self.models, *self._inputs(), self.cfg, self.device, self.rank, self.world)
+        step = lambda got: next(gen) if got is None else gen.send(got)
+        got = None
+        while True:
+            try:
+                ex = self._voted(lambda: step(got), vote, "eager warm-up")
+            except StopIteration as stop:
+                return stop.value
+            bufs = {q: torch.empty(shape, dtype=dtype, device=self.device) for q, (shape, dtype) in ex.recv.items()}
+            exchange(ex, bufs)
+            got = bufs
+
+    def _voted(self, fn, vote, what):
+        """Runs one compute segment and -- when ``vote`` is given -- lets all ranks agree that it succeeded BEFORE any of them
+        enters the exchange behind it: a rank whose segment raised votes 0 and re-raises as CaptureAborted, its peers get 0 back and
+        raise CaptureAborted too, so nobody is left alone inside batch_isend_irecv.  StopIteration (the generator's return) passes."""
+        err, out, stop = None, None, None
         try:
-            ex = next(gen)
-            while True:
-                bufs = {q: torch.empty(shape, dtype=dtype, device=self.device) for q, (shape, dtype) in ex.recv.items()}
-                exchange(ex, bufs)
-                ex = gen.send(bufs)
-        except StopIteration as stop:
-            return stop.value
+            out = fn()
+        except StopIteration as e:
+            stop = e
+        except Exception as e:      # noqa: BLE001 -- whatever it was, the peers must hear about it
+            err = e
+        if vote is not None and not vote(err is None):
+            self.reset()
+            raise CaptureAborted(f"rank {self.rank}: {what}: " + (f"{type(err).__name__}: {err}" if err is not None else "a peer rank failed"))
+        if err is not None:
+            raise err
+        if stop is not None:
+            raise stop
+        return out
+
+    def reset(self):
+        """Drops every captured segment and the half-run generator (after an abandoned capture): the object can capture() again."""
+        self.segments, self.result, self._gen, self._pinned = [], None, None, []
 
     def capture_next(self, got):
         """Captures the next compute segment (from the answer `got` of the previous exchange -- None for the first -- to the next
@@ -520,13 +552,16 @@ class ShardedClipGraph:
         self.segments.append((g, ex, bufs))
         return ex, bufs
 
-    def capture(self, exchange):
-        """Eager warm-up pass, then the capture pass (its exchanges are executed for real: the peers capture in lockstep)."""
-        self.eager(exchange)
+    def capture(self, exchange, vote=None):
+        """Eager warm-up pass, then the capture pass (its exchanges are executed for real: the peers capture in lockstep).
+        ``vote(ok) -> bool`` (optional; e.g. an all-reduce MIN over the ranks): called by every rank after every compute segment of both
+        passes, before the exchange that follows it -- if any rank failed, ALL ranks raise ``CaptureAborted`` at the same point instead
+        of one rank raising while its peers wait in a point-to-point exchange that will never be answered."""
+        self.eager(exchange, vote)
         torch.cuda.synchronize(self.device)
         got = None
         while True:
-            ex, bufs = self.capture_next(got)
+            ex, bufs = self._voted(lambda: self.capture_next(got), vote, f"capture of segment {len(self.segments)}")
             if ex is None:
                 break
             exchange(ex, bufs)
@@ -675,6 +710,47 @@ def wavefront_order(world, nseg, sources):
     return order
 
 
+def _generator_frames(gen):
+    """The frames of a suspended generator and of every generator it drives: ``yield from`` delegates (gi_yieldfrom) and generators held
+    in a local variable -- ``@torch.no_grad()`` wraps a generator function in a driver generator whose local ``gen`` is the real one."""
+    import types
+    frames, todo, seen = [], [gen], set()
+    while todo:
+        g = todo.pop()
+        if g is None or id(g) in seen or getattr(g, "gi_frame", None) is None:
+            continue
+        seen.add(id(g))
+        frames.append(g.gi_frame)
+        todo.append(getattr(g, "gi_yieldfrom", None))
+        todo.extend(v for v in g.gi_frame.f_locals.values() if isinstance(v, types.GeneratorType))
+    return frames
+
+
+def _generator_tensors(gen):
+    """Every tensor reachable from the local variables of a suspended generator's frames: what is alive at a yield."""
+    out, seen = [], set()
+
+    def walk(v, depth=0):
+        if id(v) in seen or depth > 6:
+            return
+        seen.add(id(v))
+        if torch.is_tensor(v):
+            out.append(v)
+        elif isinstance(v, (list, tuple, set)):
+            for x in v:
+                walk(x, depth + 1)
+        elif isinstance(v, dict):
+            for x in v.values():
+                walk(x, depth + 1)
+        elif isinstance(v, Span):
+            walk(v.t, depth + 1)
+        elif hasattr(v, "__dict__") and type(v).__module__.startswith("propainter_amd"):
+            walk(vars(v), depth + 1)
+    for fr in _generator_frames(gen):
+        walk(dict(fr.f_locals))
+    return out
+
+
 class StreamingClipGraph:
     """ONE long clip on ONE GPU as a pipeline over its sub-videos: RAFT of sub-video k + 3, flow completion of k + 2 and image
     propagation of k + 1 run next to the generator windows of sub-video k (the reference walks the four stages over
@@ -702,7 +778,14 @@ class StreamingClipGraph:
 
     NSEG = 5          # compute segments of sharded_clip_steps: RAFT | completion | image propagation | windows | boundary blends
 
-    def __init__(self, models, L, H, W, cfg, device, world=None, volume_gb=40.0, share_pool=True):
+    def __init__(self, models, L, H, W, cfg, device, world=None, volume_gb=40.0, share_pool=True, single_graph=True):
+        """single_graph=True (round 5, the default): the whole wavefront as ONE hipGraph, pipelined by stage -- RAFT, flow completion and
+        image propagation of the sub-videos on three branches forked from the capture stream, the generator windows on the capture
+        stream, the exchanges as direct tensor hand-overs ordered by captured events (``_capture_single_graph``).  The overlap of the
+        schedule lives INSIDE one graph (parallel branches: the form the whole-pass ClipGraph and the generator lanes use), not in
+        concurrent launches of several graphs, which give wrong frames on ROCm 7.2 (see ``replay``).  single_graph=False: one graph per
+        (rank, segment), replayed chained (share_pool=True: one memory pool, capture order) or in the lockstep / concurrent A/B orders
+        (share_pool=False)."""
         import dataclasses
         self.device = torch.device(device)
         nsub = -(-L // cfg.subvideo_length)
@@ -712,7 +795,9 @@ class StreamingClipGraph:
         self.models, self.L, self.H, self.W = models, L, H, W
         self.cfg = dataclasses.replace(cfg, raft_streams=1)         # the ranks run next to each other: one RAFT lane each
         self.volume_gb = float(volume_gb)
-        self.share_pool = bool(share_pool)
+        self.single_graph = bool(single_graph)
+        self.share_pool = bool(share_pool) and not self.single_graph
+        self._single, self._single_out, self._single_keep = None, None, None
         pool = torch.cuda.graph_pool_handle() if self.share_pool else None
         self.graphs = [ShardedClipGraph(models, L, H, W, self.cfg, device, r, self.world, pool=pool) for r in range(self.world)]
         self.streams = [torch.cuda.Stream(self.device) for _ in range(self.world)]
@@ -737,6 +822,10 @@ class StreamingClipGraph:
             run_logical_shards(self.models, *self._inputs, self.cfg, self.device, self.world)
             torch.cuda.synchronize(self.device)
             torch.cuda.empty_cache()                      # the warm-up's cached blocks go back before `world` private graph pools grow
+            if self.single_graph:
+                self.order = self._capture_single_graph()
+                torch.cuda.synchronize(self.device)
+                return self
             if self.share_pool:
                 order = self._capture_in_wavefront_order()
             else:
@@ -786,23 +875,122 @@ class StreamingClipGraph:
             order.append((r, s))
         return order
 
+    def _capture_single_graph(self):
+        """The wavefront as ONE hipGraph, pipelined BY STAGE: the logical ranks' generators (``sharded_clip_steps``) run under a single
+        capture in ``wavefront_order`` (same greedy rule as the multi-graph capture), segment s of every rank on STAGE stream s --
+        RAFT of all sub-videos on one branch, flow completion on the next, image propagation on a third (side streams forked from the
+        capture stream), the generator windows (which fork their own lanes) and the boundary blends on the capture stream itself.  An
+        exchange is answered by handing the sender's tensors over (no copy); segment s waits for the events recorded behind the
+        segments s - 1 it reads from.  Every dependency therefore points from stage stream s - 1 to stage stream s: a stream never waits
+        for a stream that waited for it.  That shape is forced by the runtime: on ROCm 7.2 hipStreamEndCapture SEGFAULTS when two forked
+        streams depend on each other back and forth, or when a forked stream forks lanes of its own (minimal repro:
+        tools/diag_capture_edges.py, profiles/r5_streaming_single_graph.txt) -- one stream per logical rank has both.  It is also the
+        pipeline the schedule is after: RAFT of sub-video k + 3 runs next to the windows of sub-video k.
+
+        Memory safety across the stage streams: a tensor that lives across a segment boundary is allocated on one stage stream and
+        read on the next; the caching allocator would hand its block to a later allocation of the FIRST stream as soon as the generator
+        drops it.  So every tensor alive in a generator at a segment boundary stays referenced until the capture ends (no block that
+        crossed a stream is recycled inside the graph).  Returns the issue order."""
+        from . import pipeline
+        cfg, dev = self.cfg, self.device
+        _window_streams(dev, cfg.window_streams, "streaming")        # the windows' lanes exist before the capture starts
+        gens = [sharded_clip_steps(self.models, *g._inputs(), cfg, dev, r, self.world, lane_key="streaming")
+                for r, g in enumerate(self.graphs)]
+        graph = torch.cuda.CUDAGraph()
+        keep = []
+        prev_rec, pipeline._index_recorder = pipeline._index_recorder, keep
+        pending = sorted((r + s, s, r) for r in range(self.world) for s in range(self.NSEG))
+        issued, order, reqs, done, results = set(), [], {}, {}, [None] * self.world
+        side = self.streams[:3]
+        assert len(side) == 3 or self.world < 3
+        while len(side) < 3:
+            side.append(torch.cuda.Stream(dev))
+        try:
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                cur = torch.cuda.current_stream(dev)
+                stage = side + [cur, cur]
+                if os.environ.get("PP_SG_STAGES") is not None:      # diagnostic (tools/diag_stream2.py): only these stages leave the capture stream
+                    on_side = {int(v) for v in os.environ["PP_SG_STAGES"].split(",") if v != ""}
+                    stage = [side[i] if i in on_side else cur for i in range(3)] + [cur, cur]
+                    side = [st for st in side if st in stage]
+                for st in side:
+                    st.wait_stream(cur)
+                while pending:
+                    for i, (_, s, r) in enumerate(pending):
+                        if s == 0 or ((r, s - 1) in issued and all((q, s - 1) in issued for q in reqs[(r, s - 1)].recv)):
+                            break
+                    else:
+                        raise RuntimeError("streaming schedule: no segment is ready (cyclic exchange dependencies)")
+                    pending.pop(i)
+                    st = stage[s]
+                    with torch.cuda.stream(st):
+                        got = None
+                        if s > 0:
+                            got = {}
+                            if stage[s - 1] is not st:
+                                st.wait_event(done[(r, s - 1)])
+                            for q, (shape, dtype) in sorted(reqs[(r, s - 1)].recv.items()):
+                                t = reqs[(q, s - 1)].send[r]
+                                assert tuple(t.shape) == tuple(shape) and t.dtype == dtype, (reqs[(r, s - 1)].tag, r, q, t.shape, shape)
+                                if stage[s - 1] is not st:
+                                    st.wait_event(done[(q, s - 1)])
+                                got[q] = t
+                        try:
+                            ex = next(gens[r]) if s == 0 else gens[r].send(got)
+                        except StopIteration as stop:
+                            ex, results[r] = None, stop.value
+                        assert (ex is None) == (s == self.NSEG - 1), f"rank {r}: segment {s} of {self.NSEG}"
+                        reqs[(r, s)] = ex
+                        keep.append((ex, got, _generator_tensors(gens[r])))
+                        if os.environ.get("PP_SG_DEBUG") == "1":      # tools/diag_stream2.py: named stage outputs
+                            self._single_debug = getattr(self, "_single_debug", {})
+                            self._single_debug[(r, s)] = {k: (v.t if isinstance(v, Span) else v) for fr_ in _generator_frames(gens[r])
+                                                          for k, v in fr_.f_locals.items() if torch.is_tensor(v) or isinstance(v, Span)}
+                        ev = torch.cuda.Event()
+                        ev.record(st)
+                        done[(r, s)] = ev
+                    issued.add((r, s))
+                    order.append((r, s))
+                for st in side:
+                    cur.wait_stream(st)
+                out = torch.zeros((self.L, self.H, self.W, 3), dtype=torch.uint8, device=dev)
+                for lo, comp in results:
+                    out[lo:lo + comp.shape[0]] = comp
+        finally:
+            pipeline._index_recorder = prev_rec
+        self._single, self._single_out = graph, out
+        self._single_keep = [t for t in keep if torch.is_tensor(t)]      # the cached index tensors the graph reads (see pipeline._dev_index)
+        return order
+
     def replay(self, lockstep=False, concurrent=None):
         """One pass over the loaded clip.  lockstep=True: segment by segment over all ranks on the current stream (the schedule of
         run_logical_shards_graphed: the A/B reference of the streaming order).
 
-        concurrent (default: env PP_STREAM_CONCURRENT == "1", else False): let the ranks' segment graphs overlap on their streams, ordered
-        by the exchange events only -- the schedule the class was built for.  ROUND-4 FINDING (tools/diag_stream.py,
-        profiles/r4_streaming_race.txt): on ROCm 7.2 / MI355X the FIRST concurrent pass after new inputs were loaded gives wrong frames in
-        ~40 % of the runs -- the RAFT segment of a later rank (no exchange before it, inputs uploaded and the device synchronised) computes
-        on stale data; a second pass over the same inputs, the same graphs on one stream (lockstep) and a wavefront whose launches each wait
-        for the previously issued one are always right.  Neither the upload stream, nor blocking uploads, nor sender-side copies, nor a
-        kernel between the event wait and the graph launch change it: independent hipGraph launches that overlap on several streams do
-        not see each other's / the copy engine's writes reliably.  So the default keeps the wavefront ISSUE ORDER but chains the launches
-        (correct, no overlap); the overlap is opt-in and must be validated on the target runtime."""
+        concurrent (default: env PP_STREAM_CONCURRENT == "1", else False; single_graph=False only): let the ranks' segment graphs
+        overlap on their streams, ordered by the exchange events only.  UNSAFE on ROCm 7.2 / MI355X, kept for diagnosis: 10-14 of 16
+        passes give wrong frames (tools/diag_stream2.py, profiles/r5_streaming_single_graph.txt).  Round 5 narrowed it down: it is a race
+        between graph launches that are in flight at the same time, not stale input -- a second pass over the same inputs is wrong as
+        often (round 4 read "never" off a luckier box); it does not need the copy engine (inputs written by a device kernel: same rate),
+        shared module state (private engines per rank: same), forked branches inside the graphs (window_streams=1: same), memcpy
+        exchanges (kernel copies: same) nor a runtime flag (DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, GPU_MAX_HW_QUEUES=8,
+        HIP_FORCE_DEV_KERNARG=0: same); the kernels themselves are bit-exact next to unrelated load (tools/diag_noise.py) and on a
+        forked branch of one graph (tools/diag_branch.py).  The overlapped schedule therefore ships as ONE graph
+        (``single_graph=True``: 0 wrong first passes of 24, 17 % faster than the chained launches at the diagnostic size); this
+        multi-graph form stays chained by default (wavefront issue order, no overlap) and warns when the overlap is requested."""
         if concurrent is None:
             concurrent = os.environ.get("PP_STREAM_CONCURRENT") == "1"
         if self.order is None:
             raise RuntimeError("StreamingClipGraph.replay(): capture() first")
+        if self._single is not None:
+            if lockstep:
+                raise ValueError("StreamingClipGraph(single_graph=True) holds one graph: there is no lockstep order to replay")
+            self._single.replay()                         # on the current stream, behind the uploads of load()
+            return self._single_out
+        if concurrent:
+            import warnings
+            warnings.warn("StreamingClipGraph.replay(concurrent=True): overlapping launches of several hipGraphs give WRONG frames in most "
+                          "passes on ROCm 7.2 / MI355X (profiles/r5_streaming_single_graph.txt); use single_graph=True for the overlapped "
+                          "schedule", RuntimeWarning, stacklevel=2)
         if self.share_pool and (lockstep or concurrent):
             raise ValueError("StreamingClipGraph(share_pool=True): the graphs share one memory pool and must replay in their capture "
                              "order, one after the other; build with share_pool=False for the lockstep / concurrent orders")

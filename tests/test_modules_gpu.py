@@ -469,10 +469,12 @@ def test_streaming_schedule_matches_the_unsharded_pass(models):
     try:
         ref_a, ref_b = run_clip(models, clip_a, masks, masks, cfg, dev), run_clip(models, clip_b, masks, masks, cfg, dev)
         outs = {}
-        for share in (True, False):
-            # share_pool=True (default): ONE graph memory pool, graphs captured and replayed in the wavefront order;
+        for share in ("pipelined", True, False):
+            # "pipelined" (default, round 5): the wavefront as ONE hipGraph pipelined by stage -- the overlapped form;
+            # share_pool=True: one graph per (rank, segment) in ONE memory pool, captured and replayed (chained) in the wavefront order;
             # share_pool=False: a private pool per logical rank, which the lockstep A/B order needs
-            sc = StreamingClipGraph(models, L, H, W, cfg, dev, share_pool=share)
+            sc = (StreamingClipGraph(models, L, H, W, cfg, dev) if share == "pipelined"
+                  else StreamingClipGraph(models, L, H, W, cfg, dev, share_pool=share, single_graph=False))
             sc.load(clip_a, masks, masks)
             sc.capture()
             assert sc.world == 4 and sc.order[:6] == [(0, 0), (1, 0), (0, 1), (2, 0), (1, 1), (0, 2)]
@@ -480,7 +482,14 @@ def test_streaming_schedule_matches_the_unsharded_pass(models):
             outs[("a again", share)] = sc.replay().clone()    # a second pass over the same static buffers
             sc.load(clip_b, masks, masks)
             outs[("b", share)] = sc.replay().clone()
-            if share:
+            if share == "pipelined":
+                # round 4's concurrent multi-graph form failed in the FIRST pass after new inputs: alternate the clips
+                for i in range(10):
+                    sc.load(clip_a if i % 2 == 0 else clip_b, masks, masks)
+                    outs[(("a" if i % 2 == 0 else "b") + f" first pass {i}", share)] = sc.replay().clone()
+                with pytest.raises(ValueError, match="single_graph"):
+                    sc.replay(lockstep=True)
+            elif share:
                 with pytest.raises(ValueError, match="share_pool"):
                     sc.replay(lockstep=True)
             else:

@@ -13,7 +13,7 @@ dev = torch.device("cuda")
 cfg = InferenceConfig(raft_iter=3, subvideo_length=10, neighbor_length=4, ref_stride=3, fp16=True, batch_propagation=False)
 models[0].precision = "f16x3"
 refs = [run_clip(models, c, masks, masks, cfg, dev).clone() for c in clips]
-sc = StreamingClipGraph(models, L, H, W, cfg, dev, share_pool=False)      # the lockstep / concurrent orders need private pools
+sc = StreamingClipGraph(models, L, H, W, cfg, dev, share_pool=False, single_graph=False)      # the lockstep / concurrent orders need private pools
 sc.load(clips[0], masks, masks); sc.capture()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 for mode in ("wavefront", "wavefront_concurrent", "lockstep"):
