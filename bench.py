@@ -361,6 +361,8 @@ def main(argv=None, runtime=None):
         _cpu_baseline_worker(args)
         return
     rt = runtime or DeviceRuntime()
+    if rt.n_devices() == 0:
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     how, plan = launch_plan(args, os.environ, argv, rt.n_devices())
     if how == "spawn":
         # --gpus N without a launcher: become the launcher (one rank per GPU; rank 0 of the child job prints the JSON line)
@@ -671,6 +673,103 @@ def main(argv=None, runtime=None):
                 g = None
                 torch.cuda.empty_cache()
 
+    # ---- round 5: the data-dependent slow paths of the headline pass, BASELINE config 2, windows with reference frames, and the
+    # STRESS recipe (non-tame weights / motion / masks) -- each against a committed oracle golden (tests/golden/synth_*.npz:
+    # oracle/make_golden_synth.py; inputs and weights are regenerated from seeds and checked against the fixture's digests)
+    fallback, configs, stress, parity_refs = None, None, None, None
+    if rank == 0 and world == 1 and not sharded and rt.extras:
+        from propainter_amd.pipeline import ClipGraph
+        graph = None
+        rt.empty_cache()
+
+        def golden_parity(fn, mdl, cfg_g):
+            """HIP path at the timed precision split on a committed synthetic golden: bytes inside the dilated mask vs the fp32 CPU oracle's"""
+            import hashlib
+            path = os.path.join(ROOT, "tests", "golden", fn)
+            if not os.path.exists(path):
+                return {"error": f"{fn} not found"}
+            g = np.load(path)
+            from oracle.make_golden_synth import inputs as golden_inputs       # (the checker's input recipe; regenerates, never computes)
+            gclip, gmasks = golden_inputs(int(g["L"]), int(g["H"]), int(g["W"]), str(g["recipe"]))
+            dg = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+            if dg(gclip) != str(g["frames_sha256"]) or dg(gmasks) != str(g["masks_sha256"]):
+                return {"error": f"{fn}: regenerated inputs do not match the fixture's digests"}
+            got = run_clip(mdl, gclip, gmasks, gmasks, cfg_g, dev).cpu().numpy()
+            hole = gmasks > 0
+            ref = gclip.copy()
+            ref[hole] = g["comp_hole"]
+            rec = parity_of(got, ref, gmasks, gt_u8=gclip)
+            rec["clip"] = f"{int(g['L'])}-frame {int(g['W'])}x{int(g['H'])} {str(g['recipe'])} clip, committed oracle golden {fn}"
+            return rec
+
+        try:
+            # (a) fallback rates of the headline clip (tame recipe): one eager pass with the counting entry points
+            with hip.FallbackStats(dev) as fs:
+                eager_step()
+                fallback = dict(fs.read(), clip="the timed clip (tame recipe)")
+            # (b) windows WITH reference frames at the timed resolution (the live cpu_baseline sample is 6 frames: no references)
+            parity_refs = golden_parity("synth_c3_720x1280x18.npz", models, cfg)
+            # (c) BASELINE config 2: 432x240x80, same precision split, own hipGraph, 2 replays + parity against the 80-frame golden
+            if not args.no_configs:
+                c2clip, c2m = synthetic_clip(80, 240, 432), scipy.ndimage.binary_dilation(synthetic_mask(240, 432), iterations=4).astype(np.uint8) * 255
+                c2f, c2mk = torch.from_numpy(c2clip).to(dev), torch.from_numpy(np.repeat(c2m[None], 80, 0)).to(dev)
+                cfg2 = dataclasses.replace(cfg, subvideo_length=80, neighbor_length=10, ref_stride=10)
+                run_clip(models, c2f, c2mk, c2mk, cfg2, dev)
+                g2 = ClipGraph(models, 80, 240, 432, cfg2, dev, example=(c2f, c2mk, c2mk))
+                g2.replay()
+                rt.sync()
+                t1 = time.perf_counter()
+                g2.replay()
+                g2.replay()
+                rt.sync()
+                dt2 = (time.perf_counter() - t1) / 2
+                configs = {"c2_432x240x80": {"value": 80 / dt2, "unit": "frames/s", "ms_per_step": dt2 * 1e3, "timed": "mean of 2 hipGraph replays",
+                                             "frac_of_f16_peak_on_algorithmic_flops": 63.9 / dt2 / PEAK_TFLOPS["f16"],
+                                             "parity": golden_parity("synth_c2_432x240x80.npz", models, cfg2)}}
+                g2 = None
+                rt.empty_cache()
+            # (d) the stress recipe: frames/s of the SAME configuration on non-tame data, its fallback rates, parity on a 6-frame stress clip
+            if not args.no_stress:
+                from propainter_amd.synthetic import stress_clip, stress_mask
+                from propainter_amd.synthetic import seeded_models as _seeded
+                smodels = _seeded(dev, raft_precision=args.raft_dtype, recipe="stress")
+                sclip_ = stress_clip(L, H, W)
+                sm_ = scipy.ndimage.binary_dilation(stress_mask(H, W), iterations=4).astype(np.uint8) * 255
+                sf, smk = torch.from_numpy(sclip_).to(dev), torch.from_numpy(np.repeat(sm_[None], L, 0)).to(dev)
+                run_clip(smodels, sf, smk, smk, cfg, dev)
+                with hip.FallbackStats(dev) as fs:
+                    run_clip(smodels, sf, smk, smk, cfg, dev)
+                    sfall = fs.read()
+                finite = True
+                try:
+                    from propainter_amd.model.modules.flow_comp_raft import assert_finite_flows
+                    assert_finite_flows(smodels[0])
+                except FloatingPointError as e:
+                    finite = f"{type(e).__name__}: {e}"
+                rt.empty_cache()
+                gs = ClipGraph(smodels, L, H, W, cfg, dev, example=(sf, smk, smk))
+                gs.replay()
+                rt.sync()
+                t1 = time.perf_counter()
+                gs.replay()
+                gs.replay()
+                rt.sync()
+                dts = (time.perf_counter() - t1) / 2
+                gs = None
+                rt.empty_cache()
+                stress = {"value": L / dts, "unit": "frames/s", "ms_per_step": dts * 1e3, "vs_headline": (L / dts) / fps,
+                          "timed": "mean of 2 hipGraph replays of the whole pass, same configuration / precision split as the headline",
+                          "recipe": "RECIPES_STRESS (flow head x1.0, offset heads x1.0), stress_clip (two layers in opposite directions at 8-48 px/frame "
+                                    "+ occluder), stress_mask (outpainting border + one hole per attention window: every window masked)",
+                          "mask_area_frac": float((sm_ > 0).mean()), "flows_finite": finite, "fallback": sfall,
+                          "parity": golden_parity("synth_stress_720x1280x6.npz", smodels, cfg)}
+                smodels = None
+                rt.empty_cache()
+        except Exception as e:      # noqa: BLE001 -- the extra legs must never take the headline line down
+            import traceback
+            sys.stderr.write("[bench] round-5 extra legs failed:\n" + traceback.format_exc())
+            stress = stress or {"error": f"{type(e).__name__}: {e}"}
+
     # ---- parity of the timed configuration (and of the other RAFT precisions) against the CPU oracle's frames
     cpu, parity = None, None
     if cpu_job is not None:
@@ -720,7 +819,8 @@ def main(argv=None, runtime=None):
             "config": {"workload": work, "height": H, "width": W, "frames": L, "windows": len(sched),
                        "raft_dtype": args.raft_dtype, "stages_dtype": "f16" if fp16 else "f32", "parallelism": par,
                        "window_streams": args.window_streams, "raft_streams": args.raft_streams},
-            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "raft_precisions": raft_precisions,
+            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "parity_windows_with_reference_frames": parity_refs,
+            "fallback": fallback, "configs": configs, "stress": stress, "raft_precisions": raft_precisions,
             "memory": {"peak_allocated_GB_eager_pass": peak_eager / 1e9, "peak_reserved_GB_eager_pass": peak_eager_reserved / 1e9,
                        "peak_allocated_GB_process": peak_total / 1e9, "peak_reserved_GB_process": rt.peak_reserved(dev) / 1e9,
                        "note": "allocated = live tensors (torch.cuda.max_memory_allocated), reserved = what the caching allocator holds "

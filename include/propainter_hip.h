@@ -158,6 +158,10 @@ typedef struct {
   int32_t split;
   int32_t out_lo, out2_lo, preadd_lo, res_lo, fuse_a_lo, fuse_b_lo;
   int32_t pad2_;
+  /* ---- optional fallback counters of the patch-staged deformable kernel (NULL: off, the production instantiation).  Device pointer
+   * to 2 x uint64: [0] += bilinear samples (pixel x offset group x tap) taken, [1] += samples with a corner OUTSIDE the tile's
+   * mean-shifted LDS patch (served by per-corner global reads: the kernel's slow path).  One update per wave; deterministic counts. */
+  unsigned long long* dcn_stats;
 } pp_conv_args_t;
 
 #define PP_FUSE_NONE 0
@@ -214,6 +218,13 @@ int pp_img_prop_step(const void* x_prop, const void* m_prop, const void* x_cur, 
  * non-zero pixel lies within L1 distance k, else 0 (k = 0: plain binarisation).  out must not alias mask. */
 int pp_binary_dilate(const void* mask, void* out, int N, int H, int W, int iterations, void* stream);
 
+/* Final resize of the composited uint8 frames on the device (reference: cv2.resize(f, out_size) = INTER_LINEAR,
+ * inference_propainter.py:469-470; web-demos/hugging_face/inpainter/base_inpainter.py:368-372): src NHWC uint8 [N,H,W,C] (C <= 4) ->
+ * dst [N,OH,OW,C] with OpenCV's fixed-point 8-bit bilinear arithmetic (11-bit weights, two-pass integer rounding; an exact 2:1
+ * reduction in both axes averages 2x2 blocks like OpenCV's INTER_AREA shortcut).  OpenCV is an un-vendored dependency
+ * (requirements.txt: opencv-python) and absent offline: the arithmetic is restated from its published algorithm. */
+int pp_resize_bilinear_u8(const void* src, void* dst, int N, int H, int W, int C, int OH, int OW, void* stream);
+
 /* Ordered uint8 composite of one generator window (inference_propainter.py:435-450) in one launch: for local frame i (clip frame
  * frame_ids[i], HOST array of n <= 32 ids)  img = uint8(((pred + 1) / 2) * 255) with every operation rounded in pred's dtype and the
  * final truncation of .astype(np.uint8);  cur = mask ? img : original;  comp = (blend_bits >> i) & 1 ? uint8(0.5f * comp + 0.5f * cur) :
@@ -260,6 +271,15 @@ int pp_corr_lookup_otf(const void* f1, const void* f2_lvl0, const void* f2_lvl1,
  * permute its weight columns accordingly); out_cstride >= 704, multiple of 16.  Deterministic, batch-invariant. */
 int pp_corr_lookup_otf_split(const void* f1, const void* f2_lvl0, const void* f2_lvl1, const void* f2_lvl2, const void* f2_lvl3,
                              const float* coords, void* out, int out_cstride, int P, int h, int w, void* stream);
+/* The same lookups with fallback counters (round 5; `stats` = device pointer to 3 x uint64 or NULL): [0] += (tile, pyramid level)
+ * units processed, [1] += units whose bounding box of correlation windows outgrew the LDS tile (processed as 16-pixel sub-tiles),
+ * [2] += 16-pixel sub-tiles that fell through to single pixels.  One update per block; the lookup result does not depend on it. */
+int pp_corr_lookup_otf_stats(const void* f1, const void* f2_lvl0, const void* f2_lvl1, const void* f2_lvl2, const void* f2_lvl3,
+                             const float* coords, void* out, int out_cstride, int out_cpad, int P, int h, int w,
+                             unsigned long long* stats, void* stream);
+int pp_corr_lookup_otf_split_stats(const void* f1, const void* f2_lvl0, const void* f2_lvl1, const void* f2_lvl2, const void* f2_lvl3,
+                                   const float* coords, void* out, int out_cstride, int P, int h, int w,
+                                   unsigned long long* stats, void* stream);
 
 /* Input of the motion encoder's 7x7 flow convolution (RAFT/update.py:85,92: convf1 = Conv2d(2, 128, 7, padding=3)) laid out so
  * that the convolution needs K = 7 x 16 instead of 49 taps x 8 padded channels: rows[pixel, 2*kx + c] = flow_c(x + kx - 3, y)

@@ -193,10 +193,15 @@ def _run(args, models, cfg, frames_u8, flow_masks, masks_dilated, L, world, rank
     dt = time.perf_counter() - t0
     assert_finite_flows(models[0])        # split-plane RAFT: a value beyond fp16's range would have produced NaN flows -- fail loudly
     if rank == 0:
+        # final resize of the video frames (cv2.resize(f, out_size), :469-470) on the device, before the single device->host copy
+        from propainter_amd import hip
+        resized = None
+        if comp.is_cuda and tuple(out_size) != (comp.shape[2], comp.shape[1]):
+            resized = list(hip.resize_bilinear_u8(comp.contiguous(), out_size).cpu().numpy())
         comp = comp.cpu().numpy()
         print(f'{L} frames in {dt:.2f} s ({L / dt:.2f} frames/s on {world} GPU(s))')
         video_io.save_results(save_root, list(comp), video_io.masked_preview(frames_u8, masks_dilated), out_size, fps,
-                              args.save_frames)
+                              args.save_frames, comp_video_frames=resized)
         print(f'\nAll results are saved in {save_root}')
 
 

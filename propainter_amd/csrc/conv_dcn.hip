@@ -43,7 +43,7 @@ static __device__ __forceinline__ void dcn_dma_weights(__amdgpu_buffer_rsrc_t r,
 // DCN_TH: tile rows.  8 (128 pixels, two 16-pixel M tiles per wave) is the throughput form; 4 (64 pixels, one M tile per wave) halves a
 // block's work for launches that do not fill the chip anyway: the recurrent steps of flow completion run over 2 x 90 x 160 pixels = 225
 // tiles of 128 pixels for 512 block slots -- their time is ONE block's latency.
-template <int CG, int DCN_TH>
+template <int CG, int DCN_TH, bool STATS = false>
 __global__ __launch_bounds__(256, 2) void conv_dcn_patch_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int NPX = DCN_TH * DCN_TW, MT = NPX / 64;       // pixels per tile, 16-pixel M tiles per wave
@@ -117,6 +117,7 @@ __global__ __launch_bounds__(256, 2) void conv_dcn_patch_kernel(const ConvParams
   for (int a = 0; a < 8; ++a)
 #pragma unroll
     for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  [[maybe_unused]] unsigned n_samples = 0, n_outside = 0;      // STATS instantiation only (pp_conv_args_t.dcn_stats)
 
   const int nblocks = p.kchunks / 36;         // 32-channel blocks (9 taps x 4 chunks each)
   u32x4 wcur[8];
@@ -266,6 +267,12 @@ __global__ __launch_bounds__(256, 2) void conv_dcn_patch_kernel(const ConvParams
           const _Float16 hw[4] = {(_Float16)w00, (_Float16)w01, (_Float16)w10, (_Float16)w11};
           // clamp far-out samples before the int conversion (they are handled by the slow path below anyway)
           const int ry0 = (int)fminf(fmaxf(fy, -1.0e6f), 1.0e6f) - py0, rx0 = (int)fminf(fmaxf(fx, -1.0e6f), 1.0e6f) - px0;
+          if constexpr (STATS) {            // one sample per (pixel, offset group, tap): lanes with the same (pixel, group) count once
+            if (CG == 8 || (l4 & 1) == 0) {
+              ++n_samples;
+              n_outside += ((unsigned)ry0 < (unsigned)(DCN_PH - 1) && (unsigned)rx0 < (unsigned)(DCN_PW - 1)) ? 0u : 1u;
+            }
+          }
           if ((unsigned)ry0 < (unsigned)(DCN_PH - 1) && (unsigned)rx0 < (unsigned)(DCN_PW - 1)) {
             // ---- all four corners inside the staged patch (the common case): 4 LDS reads, packed fp16 blend
             const int pi0 = ry0 * DCN_PW + rx0;
@@ -316,6 +323,16 @@ __global__ __launch_bounds__(256, 2) void conv_dcn_patch_kernel(const ConvParams
     }
   }
 
+  if constexpr (STATS) {
+    if (tn == 0) {                          // every cout tile samples the same positions: count them once
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { n_samples += __shfl_xor(n_samples, o); n_outside += __shfl_xor(n_outside, o); }
+      if (lane == 0) {
+        atomicAdd(p.dcn_stats + 0, (unsigned long long)n_samples);
+        atomicAdd(p.dcn_stats + 1, (unsigned long long)n_outside);
+      }
+    }
+  }
   // ---- epilogue: lane holds couts nt*16 + l4*4 + r (r = 0..3) of pixel mt*16 + l15
   float bv[8][4];
 #pragma unroll
@@ -370,7 +387,15 @@ int conv_dcn_dispatch(const ConvParams& pin_, hipStream_t stream, int dbg) {
   // launches of at most one block per CU: 64-pixel tiles (twice the blocks, half the latency of a block); dbg 16 / 32 force 8 / 4 rows
   const bool small = (dbg & 32) || (!(dbg & 16) && nblk8 <= 256);
   p.tap_w = dbg & 15;
-  if (small) {
+  if (p.dcn_stats != nullptr) {          // counting instantiations (bench.py's fallback report; same arithmetic, same results)
+    if (small) {
+      if (cin == 128) hipLaunchKernelGGL((conv_dcn_patch_kernel<8, 4, true>), dim3((unsigned)nblk4), dim3(256), 0, stream, p);
+      else hipLaunchKernelGGL((conv_dcn_patch_kernel<16, 4, true>), dim3((unsigned)nblk4), dim3(256), 0, stream, p);
+    } else {
+      if (cin == 128) hipLaunchKernelGGL((conv_dcn_patch_kernel<8, 8, true>), dim3((unsigned)nblk8), dim3(256), 0, stream, p);
+      else hipLaunchKernelGGL((conv_dcn_patch_kernel<16, 8, true>), dim3((unsigned)nblk8), dim3(256), 0, stream, p);
+    }
+  } else if (small) {
     if (cin == 128) hipLaunchKernelGGL((conv_dcn_patch_kernel<8, 4>), dim3((unsigned)nblk4), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((conv_dcn_patch_kernel<16, 4>), dim3((unsigned)nblk4), dim3(256), 0, stream, p);
   } else {

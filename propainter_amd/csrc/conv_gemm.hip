@@ -534,6 +534,7 @@ extern "C" int pp_conv2d(const pp_conv_args_t* a, void* stream) {
   p.out2 = (char*)a->out2; p.out2_cstride = a->out2_cstride; p.out2_choff = a->out2_choff;
   p.split = a->split; p.out_lo = a->out_lo; p.out2_lo = a->out2_lo; p.preadd_lo = a->preadd_lo; p.res_lo = a->res_lo;
   p.fuse_a_lo = a->fuse_a_lo; p.fuse_b_lo = a->fuse_b_lo;
+  p.dcn_stats = a->dcn_stats;
   {   // PP_EPI_DIRECT: 0 = never, 1 (default) = the batched GEMMs (short K, output-bound), 2 = every plain fp32 output (read per launch: A/B runs)
     const char* ed = getenv("PP_EPI_DIRECT");
     const int mode = ed != nullptr ? atoi(ed) : 1;

@@ -48,6 +48,7 @@ struct ConvParams {
   // plain fp32 output without epilogue operands: store the accumulators directly (4 consecutive couts = 16 bytes per lane, 64 contiguous
   // bytes per pixel row and MFMA tile) instead of staging them through LDS -- short-K, output-bound launches (the correlation-volume GEMM)
   int epi_direct;
+  unsigned long long* dcn_stats;   // conv_dcn.hip: optional fallback counters (pp_conv_args_t.dcn_stats)
 };
 
 // activation of the late (post-staging) epilogue path: same fast forms as the register path of conv_epilogue.h

@@ -35,6 +35,8 @@ struct CorrOtfParams {
   int P, h, w, ocs, ocpad, tiles_x, tiles_y;
   float scale;               // 1 / sqrt(256)
   int dbg;                   // [PP_OTF_DBG, tuning only: selects the instrumented instantiation] 1 no blend, 2 no MFMA, 4 no B loads, 8 no write-out, 16 stamps
+  unsigned long long* stats; // optional (nullptr: off) fallback counters, one update per block: [0] += (tile, level) units, [1] += units whose
+                             // bounding box outgrew the V tile (sub-tile pass), [2] += 16-pixel groups that fell through to single pixels
 };
 
 constexpr int OTF_VTOT = 28928;                    // floats of V storage (113 KB): 64 x 452, 16 x 1808, 1 x 28928
@@ -157,6 +159,7 @@ __global__ __launch_bounds__(512) void corr_otf_kernel(const CorrOtfParams p) {
 
   u32x4 bcur[8], bnxt[8];
   bool prefetched = false;       // bcur already holds this wave's first N tile of the level (issued before the previous blend)
+  int n_sub = 0, n_single = 0;   // fallback counts of this block (p.stats)
 
   for (int lvl = 0; lvl < 4; ++lvl) {
     const int Hl = p.h >> lvl, Wl = p.w >> lvl;
@@ -246,11 +249,13 @@ __global__ __launch_bounds__(512) void corr_otf_kernel(const CorrOtfParams p) {
 
     if (!process(0, 64, boxes + lvl * 4)) {
       prefetched = false;
+      ++n_sub;
       for (int g = 0; g < 4; ++g) {
         if (wave == 0) wave_box(lvl, g * 16, 16, boxes + 16);
         __syncthreads();
         const bool ok = process(g * 16, 16, boxes + 16);
         if (!ok) {
+          ++n_single;
           for (int q = 0; q < 16; ++q) {                       // a single window (<= 100 positions) always fits
             __syncthreads();
             if (wave == 0) wave_box(lvl, g * 16 + q, 1, boxes + 16);
@@ -263,6 +268,11 @@ __global__ __launch_bounds__(512) void corr_otf_kernel(const CorrOtfParams p) {
     }
   }
 
+  if (p.stats != nullptr && tid == 0) {       // (uniform counts: every thread of the block took the same path)
+    atomicAdd(p.stats + 0, 4ull);
+    if (n_sub) atomicAdd(p.stats + 1, (unsigned long long)n_sub);
+    if (n_single) atomicAdd(p.stats + 2, (unsigned long long)n_single);
+  }
   // ---- staging tile -> NHWC rows (16-byte chunks; channels [324, ocpad) are zero)
   if (tid < 64) {
 #pragma unroll
@@ -465,6 +475,7 @@ __global__ __launch_bounds__(256, 2) void corr_otf_split_kernel(const CorrOtfPar
 
   u32x4 b0h[4], b0l[4], b1h[4], b1l[4];
   bool prefetched = false;       // (b0h, b0l) already hold half 0 of this wave's first N tile of the level
+  int n_sub = 0, n_single = 0;   // fallback counts of this block (p.stats)
 
   for (int lvl = 0; lvl < 4; ++lvl) {
     const int Hl = p.h >> lvl, Wl = p.w >> lvl;
@@ -573,11 +584,13 @@ __global__ __launch_bounds__(256, 2) void corr_otf_split_kernel(const CorrOtfPar
 
     if (!process(0, OTFS_NPX, boxes + lvl * 4)) {
       prefetched = false;
+      ++n_sub;
       for (int g = 0; g < 2; ++g) {
         if (wave == 0) wave_box(lvl, g * 16, 16, boxes + 16);
         __syncthreads();
         const bool ok = process(g * 16, 16, boxes + 16);
         if (!ok) {
+          ++n_single;
           for (int q = 0; q < 16; ++q) {
             __syncthreads();
             if (wave == 0) wave_box(lvl, g * 16 + q, 1, boxes + 16);
@@ -601,6 +614,11 @@ __global__ __launch_bounds__(256, 2) void corr_otf_split_kernel(const CorrOtfPar
     stamp(5);
     // (the next level's tables / blend rewrite `tab` / the staging tile only after a __syncthreads() every thread reaches after these reads:
     //  the table loop writes `tab`, which the write-out does not read; the blend comes after process()'s barrier)
+  }
+  if (p.stats != nullptr && tid == 0) {
+    atomicAdd(p.stats + 0, 4ull);
+    if (n_sub) atomicAdd(p.stats + 1, (unsigned long long)n_sub);
+    if (n_single) atomicAdd(p.stats + 2, (unsigned long long)n_single);
   }
   if (PROF && (p.dbg & 16) && tid == 0) {
 #pragma unroll
@@ -677,9 +695,19 @@ extern "C" int pp_corr_feature_pyramid_split(const void* f2, void* lvl1, void* l
   return feature_pyramid(f2, lvl1, lvl2, lvl3, P, h, w, true, stream, "pp_corr_feature_pyramid_split");
 }
 
+extern "C" int pp_corr_lookup_otf_stats(const void* f1, const void* f2_lvl0, const void* f2_lvl1, const void* f2_lvl2,
+                                        const void* f2_lvl3, const float* coords, void* out, int out_cstride, int out_cpad, int P,
+                                        int h, int w, unsigned long long* stats, void* stream);
+
 extern "C" int pp_corr_lookup_otf(const void* f1, const void* f2_lvl0, const void* f2_lvl1, const void* f2_lvl2,
                                   const void* f2_lvl3, const float* coords, void* out, int out_cstride, int out_cpad, int P,
                                   int h, int w, void* stream) {
+  return pp_corr_lookup_otf_stats(f1, f2_lvl0, f2_lvl1, f2_lvl2, f2_lvl3, coords, out, out_cstride, out_cpad, P, h, w, nullptr, stream);
+}
+
+extern "C" int pp_corr_lookup_otf_stats(const void* f1, const void* f2_lvl0, const void* f2_lvl1, const void* f2_lvl2,
+                                        const void* f2_lvl3, const float* coords, void* out, int out_cstride, int out_cpad, int P,
+                                        int h, int w, unsigned long long* stats, void* stream) {
   PP_REQUIRE(f1 && f2_lvl0 && f2_lvl1 && f2_lvl2 && f2_lvl3 && coords && out, PP_ERR_ARG, "pp_corr_lookup_otf: null pointer");
   PP_REQUIRE(P > 0 && (h >> 3) >= 2 && (w >> 3) >= 2, PP_ERR_ARG,
              "pp_corr_lookup_otf: level-3 map would be %dx%d (RAFT needs >= 2x2: inputs of at least 128x128)", h >> 3, w >> 3);
@@ -695,15 +723,26 @@ extern "C" int pp_corr_lookup_otf(const void* f1, const void* f2_lvl0, const voi
   p.tiles_x = (w + 7) / 8; p.tiles_y = (h + 7) / 8;
   p.scale = 1.f / 16.f;
   p.dbg = 0;
+  p.stats = stats;
   const long long nblk = (long long)P * p.tiles_x * p.tiles_y;
   PP_REQUIRE(nblk < (1ll << 31), PP_ERR_ARG, "pp_corr_lookup_otf: too many tiles");
   hipLaunchKernelGGL(corr_otf_kernel, dim3((unsigned)nblk), dim3(512), 0, (hipStream_t)stream, p);
   return launch_status("pp_corr_lookup_otf");
 }
 
+extern "C" int pp_corr_lookup_otf_split_stats(const void* f1, const void* f2_lvl0, const void* f2_lvl1, const void* f2_lvl2,
+                                              const void* f2_lvl3, const float* coords, void* out, int out_cstride, int P,
+                                              int h, int w, unsigned long long* stats, void* stream);
+
 extern "C" int pp_corr_lookup_otf_split(const void* f1, const void* f2_lvl0, const void* f2_lvl1, const void* f2_lvl2,
                                         const void* f2_lvl3, const float* coords, void* out, int out_cstride, int P,
                                         int h, int w, void* stream) {
+  return pp_corr_lookup_otf_split_stats(f1, f2_lvl0, f2_lvl1, f2_lvl2, f2_lvl3, coords, out, out_cstride, P, h, w, nullptr, stream);
+}
+
+extern "C" int pp_corr_lookup_otf_split_stats(const void* f1, const void* f2_lvl0, const void* f2_lvl1, const void* f2_lvl2,
+                                              const void* f2_lvl3, const float* coords, void* out, int out_cstride, int P,
+                                              int h, int w, unsigned long long* stats, void* stream) {
   PP_REQUIRE(f1 && f2_lvl0 && f2_lvl1 && f2_lvl2 && f2_lvl3 && coords && out, PP_ERR_ARG, "pp_corr_lookup_otf_split: null pointer");
   PP_REQUIRE(P > 0 && (h >> 3) >= 2 && (w >> 3) >= 2, PP_ERR_ARG,
              "pp_corr_lookup_otf_split: level-3 map would be %dx%d (RAFT needs >= 2x2: inputs of at least 128x128)", h >> 3, w >> 3);
@@ -720,6 +759,7 @@ extern "C" int pp_corr_lookup_otf_split(const void* f1, const void* f2_lvl0, con
   p.scale = 1.f / 16.f;
   static const int dbg = getenv("PP_OTF_DBG") ? atoi(getenv("PP_OTF_DBG")) : 0;
   p.dbg = dbg;
+  p.stats = stats;
   const long long nblk = (long long)P * p.tiles_x * p.tiles_y;
   PP_REQUIRE(nblk < (1ll << 31), PP_ERR_ARG, "pp_corr_lookup_otf_split: too many tiles");
   if (dbg) hipLaunchKernelGGL(corr_otf_split_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);

@@ -215,6 +215,58 @@ __global__ void composite_window_kernel(const T* __restrict__ pred, const unsign
   }
 }
 
+
+// ---- final resize of the composited frames (inference_propainter.py:469-470: cv2.resize(f, out_size), INTER_LINEAR on uint8) -------------
+// OpenCV's 8-bit bilinear resize is FIXED-POINT: per axis the source position of output d is f = (float)((d + 0.5) * scale - 0.5),
+// s = floor(f), clamped to the image with the fractional part dropped at the borders; the two weights are rounded to 11 bits
+// (cvRound(w * 2048), INTER_RESIZE_COEF_BITS), the horizontal pass keeps S[s] * a0 + S[s + 1] * a1 as an integer and the vertical pass
+// returns (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2.  An exact 2 : 1 reduction in both axes takes the INTER_AREA
+// path instead (cv::resize: "INTER_LINEAR ... iscale 2 -> INTER_AREA"): (a + b + c + d + 2) >> 2.  This kernel restates that arithmetic
+// (published algorithm of the un-vendored dependency opencv-python, requirements.txt; cv2 is absent offline: parity pinned against
+// propainter_amd/video_io.py's numpy restatement, byte for byte, and against float bilinear interpolation within 1 level).
+__device__ __forceinline__ void cv_linear_coeff(int d, double scale, int n_src, int& s, int& a0, int& a1) {
+  float f = (float)(((double)d + 0.5) * scale - 0.5);
+  int si = (int)floorf(f);
+  f -= (float)si;
+  if (si < 0) { f = 0.f; si = 0; }
+  if (si >= n_src - 1) { f = 0.f; si = n_src - 1; }
+  s = si;
+  a0 = __float2int_rn((1.f - f) * 2048.f);
+  a1 = __float2int_rn(f * 2048.f);
+}
+
+__global__ void resize_bilinear_u8_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, int N, int H, int W, int C,
+                                          int OH, int OW) {
+  const long long total = (long long)N * OH * OW;
+  const double sx = (double)W / OW, sy = (double)H / OH;
+  const bool area2 = (W == 2 * OW) && (H == 2 * OH);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % OW);
+    const long long r = i / OW;
+    const int y = (int)(r % OH);
+    const long long n = r / OH;
+    const unsigned char* img = src + n * H * W * C;
+    unsigned char* o = dst + i * C;
+    if (area2) {
+      const unsigned char* p0 = img + ((long long)(2 * y) * W + 2 * x) * C;
+      const unsigned char* p1 = p0 + (long long)W * C;
+      for (int c = 0; c < C; ++c) o[c] = (unsigned char)((p0[c] + p0[C + c] + p1[c] + p1[C + c] + 2) >> 2);
+      continue;
+    }
+    int x0, y0, a0, a1, b0, b1;
+    cv_linear_coeff(x, sx, W, x0, a0, a1);
+    cv_linear_coeff(y, sy, H, y0, b0, b1);
+    const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+    const unsigned char* r0 = img + (long long)y0 * W * C;
+    const unsigned char* r1 = img + (long long)y1 * W * C;
+    for (int c = 0; c < C; ++c) {
+      const int h0 = r0[x0 * C + c] * a0 + r0[x1 * C + c] * a1;
+      const int h1 = r1[x0 * C + c] * a0 + r1[x1 * C + c] * a1;
+      o[c] = (unsigned char)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
+    }
+  }
+}
+
 }  // namespace pp
 
 using namespace pp;
@@ -304,4 +356,13 @@ extern "C" int pp_binary_dilate(const void* mask, void* out, int N, int H, int W
   hipLaunchKernelGGL(binary_dilate_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)mask,
                      (unsigned char*)out, N, H, W, iterations);
   return launch_status("pp_binary_dilate");
+}
+
+extern "C" int pp_resize_bilinear_u8(const void* src, void* dst, int N, int H, int W, int C, int OH, int OW, void* stream) {
+  PP_REQUIRE(src && dst && src != dst && N > 0 && H > 0 && W > 0 && OH > 0 && OW > 0 && C > 0 && C <= 4, PP_ERR_ARG,
+             "pp_resize_bilinear_u8: bad arguments (%dx%dx%d -> %dx%d)", H, W, C, OH, OW);
+  const int g = grid_for((long long)N * OH * OW);
+  hipLaunchKernelGGL(resize_bilinear_u8_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)src, (unsigned char*)dst,
+                     N, H, W, C, OH, OW);
+  return launch_status("pp_resize_bilinear_u8");
 }

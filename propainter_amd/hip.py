@@ -43,6 +43,7 @@ class ConvArgs(C.Structure):
         ("out2", C.c_void_p), ("out2_cstride", C.c_int32), ("out2_choff", C.c_int32),
         ("split", C.c_int32), ("out_lo", C.c_int32), ("out2_lo", C.c_int32), ("preadd_lo", C.c_int32), ("res_lo", C.c_int32),
         ("fuse_a_lo", C.c_int32), ("fuse_b_lo", C.c_int32), ("pad2_", C.c_int32),
+        ("dcn_stats", C.c_void_p),
     ]
 
 
@@ -121,6 +122,50 @@ class KernelProfiler:
 
 
 _profiler = None
+
+
+class FallbackStats:
+    """Counts how often the data-dependent slow paths of two kernels are taken (round 5; bench.py's `fallback` / `stress` objects):
+
+      * the volume-free correlation lookups (``pp_corr_lookup_otf[_split]``): a tile whose correlation windows' bounding box outgrows
+        the LDS tile is processed as 16-pixel sub-tiles, and those as single pixels;
+      * the patch-staged deformable convolution: a bilinear sample with a corner outside the tile's mean-shifted LDS patch is served by
+        per-corner global reads.
+
+    While installed (``with FallbackStats(device) as fs``) the wrappers pass a device counter block to the ``*_stats`` entry points / the
+    counting instantiation of the deformable kernel (same arithmetic, same results); ``fs.read()`` synchronises and returns the counts
+    and fractions.  Host-side state of this wrapper only -- the C-ABI stays stateless (the counter block is an argument)."""
+
+    def __init__(self, device):
+        self.buf = torch.zeros(8, dtype=torch.int64, device=device)
+
+    def __enter__(self):
+        global _stats
+        self._prev, _stats = _stats, self
+        return self
+
+    def __exit__(self, *exc):
+        global _stats
+        _stats = self._prev
+        return False
+
+    def read(self):
+        torch.cuda.synchronize(self.buf.device)
+        v = [int(x) for x in self.buf.cpu().tolist()]
+        units, sub, single, samples, outside = v[0], v[1], v[2], v[4], v[5]
+        return {"corr_tile_levels": units, "corr_subtile_fallbacks": sub, "corr_single_pixel_fallbacks": single,
+                "corr_subtile_fallback_frac": sub / units if units else None,
+                "corr_single_pixel_fallback_frac_of_subtiles": single / (2 * sub) if sub else (0.0 if units else None),
+                "dcn_samples": samples, "dcn_out_of_patch_samples": outside,
+                "dcn_out_of_patch_frac": outside / samples if samples else None}
+
+
+_stats = None
+
+
+def _stats_ptr(offset):
+    """device pointer into the installed FallbackStats block (element `offset`), or NULL"""
+    return C.c_void_p(_stats.buf.data_ptr() + 8 * offset) if _stats is not None else C.c_void_p(0)
 
 
 def _nbytes(t):
@@ -296,6 +341,8 @@ def window_tables(Hp, Wp, wh=5, ww=9):
 def conv2d_raw(args: ConvArgs, cin_read=None, on=None, split_k=0):
     """cin_read: channels read per input pixel (for the profiler's byte model; defaults to K per group x groups);
     on: a tensor of the launch (names the device / stream); split_k: the K table is a split-plane expansion (profiler accounting)."""
+    if _stats is not None and args.dcn_offmask:
+        args.dcn_stats = _stats.buf.data_ptr() + 8 * 4
     if _profiler is None:
         _check(lib().pp_conv2d(C.byref(args), _stream(on)), "pp_conv2d")
         return
@@ -380,6 +427,21 @@ def binary_dilate(mask_u8, iterations):
     return out
 
 
+def resize_bilinear_u8(x_u8, size):
+    """uint8 NHWC [N,H,W,C] on the GPU -> [N,OH,OW,C] for size = (OW, OH): cv2.resize(f, size) (INTER_LINEAR) of every frame, with OpenCV's
+    fixed-point 8-bit arithmetic (pp_resize_bilinear_u8; byte-identical to video_io.resize_u8_linear)."""
+    N, H, W, Cc = x_u8.shape
+    OW, OH = int(size[0]), int(size[1])
+    assert x_u8.dtype == torch.uint8 and x_u8.is_contiguous()
+    if (OW, OH) == (W, H):
+        return x_u8
+    out = torch.empty((N, OH, OW, Cc), dtype=torch.uint8, device=x_u8.device)
+    timed("resize_bilinear_u8", 0, x_u8.numel() + out.numel(),
+          lambda: _check(lib().pp_resize_bilinear_u8(_p(x_u8), _p(out), _i(N), _i(H), _i(W), _i(Cc), _i(OH), _i(OW), _stream(x_u8)),
+                         "pp_resize_bilinear_u8"))
+    return out
+
+
 def composite_window(pred, mask_u8, ori_u8, comp_u8, frame_ids, blend_flags):
     """pred [n,3,H,W] in [-1,1] (fp32 / fp16); mask_u8 [L,H,W(,1)] uint8 (non-zero = hole); ori_u8 / comp_u8 uint8 [L,H,W,3]; frame_ids: the clip
     frames of the n local frames; blend_flags[i]: frame i was composited before (0.5 / 0.5 blend).  Updates comp_u8 in place."""
@@ -445,9 +507,9 @@ def corr_lookup_otf(f1, f2_levels, coords, out):
     assert f1.dtype == torch.float16 and f1.is_contiguous() and f1.shape == (P, h, w, 256) and all(t.is_contiguous() for t in f2_levels)
     npix = P * h * w
     timed("corr_lookup_otf", 2.0 * 256 * 400 * npix, _nbytes(f1) + sum(_nbytes(t) for t in f2_levels) + _nbytes(coords) + _nbytes(out),
-          lambda: _check(lib().pp_corr_lookup_otf(_p(f1), _p(f2_levels[0]), _p(f2_levels[1]), _p(f2_levels[2]), _p(f2_levels[3]),
-                                                  _p(coords), _p(out), _i(out.shape[-1]), _i(out.shape[-1]), _i(P), _i(h), _i(w),
-                                                  _stream(f1)), "pp_corr_lookup_otf"))
+          lambda: _check(lib().pp_corr_lookup_otf_stats(_p(f1), _p(f2_levels[0]), _p(f2_levels[1]), _p(f2_levels[2]), _p(f2_levels[3]),
+                                                        _p(coords), _p(out), _i(out.shape[-1]), _i(out.shape[-1]), _i(P), _i(h), _i(w),
+                                                        _stats_ptr(0), _stream(f1)), "pp_corr_lookup_otf"))
     return out
 
 
@@ -465,8 +527,9 @@ def corr_lookup_otf_split(f1, f2_levels, coords, out):
     npix = P * h * w
     # FLOPs: ~400 positions per pixel x 256 channels (the algorithmic dot products of the 4 x (10 x 10) neighbourhoods), three fp16 products each
     timed("corr_lookup_otf_split", 2.0 * 256 * 400 * npix, _nbytes(f1) + sum(_nbytes(t) for t in f2_levels) + _nbytes(coords) + _nbytes(out),
-          lambda: _check(lib().pp_corr_lookup_otf_split(_p(f1), _p(f2_levels[0]), _p(f2_levels[1]), _p(f2_levels[2]), _p(f2_levels[3]),
-                                                        _p(coords), _p(out), _i(out.shape[-1]), _i(P), _i(h), _i(w), _stream(f1)),
+          lambda: _check(lib().pp_corr_lookup_otf_split_stats(_p(f1), _p(f2_levels[0]), _p(f2_levels[1]), _p(f2_levels[2]), _p(f2_levels[3]),
+                                                              _p(coords), _p(out), _i(out.shape[-1]), _i(P), _i(h), _i(w), _stats_ptr(0),
+                                                              _stream(f1)),
                          "pp_corr_lookup_otf_split"))
     return out
 

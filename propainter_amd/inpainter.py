@@ -4,7 +4,6 @@ pre-processing (resize to even / multiple-of-8 sizes, per-frame masks dilated wi
 device path (it is ``inference_propainter.py:298-452`` again), numpy frames out.  The device work runs on the HIP
 engine through ``pipeline.run_clip``."""
 import numpy as np
-import scipy.ndimage
 import torch
 from PIL import Image
 
@@ -42,21 +41,24 @@ class ProInpainter:
             if self.use_half:
                 self.fix_flow_complete, self.model = self.fix_flow_complete.half(), self.model.half()
 
-    @staticmethod
-    def _masks(masks, length, size, dilate):
-        """read_mask_demo (base_inpainter.py:128-160): per-frame uint8 masks -> (flow_masks, masks_dilated) {0,255}."""
-        fm, md = [], []
+    def _masks(self, masks, length, size, dilate):
+        """read_mask_demo (base_inpainter.py:128-160): per-frame uint8 masks -> (flow_masks, masks_dilated) uint8 {0,255} ON THE DEVICE.
+        The resize (nearest) stays on the host with the decode; the binary dilation -- scipy.ndimage.binary_dilation(iterations) in the
+        reference -- runs as ``pp_binary_dilate`` (bit-identical to scipy: tests/test_ops_gpu.py)."""
+        raw = []
         for m in masks:
             im = Image.fromarray(np.asarray(m).astype('uint8'))
             if size is not None:
                 im = im.resize(size, Image.NEAREST)
-            a = np.array(im.convert('L'))
-            d = (scipy.ndimage.binary_dilation(a, iterations=dilate) if dilate > 0 else a > 0.1).astype(np.uint8) * 255
-            fm.append(d)
-            md.append(d)
-        if len(fm) == 1:
-            fm, md = fm * length, md * length
-        return np.stack(fm[:length]), np.stack(md[:length])
+            raw.append(np.array(im.convert('L')))
+        if len(raw) == 1:
+            raw = raw * length
+        t = torch.from_numpy(np.stack(raw[:length])).to(self.device)
+        if dilate > 0:
+            d = hip.binary_dilate(t.contiguous(), int(dilate))
+        else:
+            d = (t.float() > 0.1).to(torch.uint8) * 255
+        return d, d
 
     @torch.no_grad()
     def inpaint(self, npframes, masks, ratio=1.0, dilate_radius=4, raft_iter=20, subvideo_length=80, neighbor_length=10,
@@ -73,6 +75,7 @@ class ProInpainter:
                               ref_stride=ref_stride, fp16=self.use_half)
         comp = run_clip((self.fix_raft, self.fix_flow_complete, self.model), frames_u8, flow_masks, masks_dilated, cfg,
                         self.device)
-        comp = comp.cpu().numpy()
+        # final resize (cv2.resize(f, out_size), base_inpainter.py:368-372) on the device, then ONE device->host copy
+        comp = hip.resize_bilinear_u8(comp.contiguous(), out_size).cpu().numpy()
         assert_finite_flows(self.fix_raft)            # (after the D2H: the pass is synchronised)
-        return [video_io._resize_u8(f, out_size, Image.BILINEAR) for f in comp]
+        return list(comp)

@@ -479,15 +479,23 @@ class RAFT_bi(nn.Module):
                      for i in range(0, P, chunk)]
         ups = hip.fork_join(dev, [(lambda a=a, b_=b_, c_=c_: eng.refine(a, b_, c_[0] if len(c_) == 1 else tuple(c_), iters))
                                   for a, b_, c_ in parts], streams)
-        up = torch.cat(ups, 0).to(gt_local_frames.dtype)
+        up32 = torch.cat(ups, 0)
+        up = up32.to(gt_local_frames.dtype)
         # finite-flow guard (device flag, no host sync here: graph-capturable; callers check it after their own synchronisation with
         # assert_finite_flows).  A split-plane value beyond fp16's range (|v| > 65504) puts inf into its hi plane and the flows go NaN.
         # one flag per call (a sharded / streaming pass calls once per rank); flags recorded under hipGraph capture are refreshed by every
         # replay and stay, eager ones are dropped once assert_finite_flows has looked at them
+        # (the flag is taken on the fp32 flows BEFORE the cast to the caller's dtype: an fp16 sum over millions of flow values overflows
+        #  by itself; eager flags are folded into one running AND, so no call's flag is ever dropped -- a long clip makes many calls)
         captured = up.is_cuda and torch.cuda.is_current_stream_capturing()
+        flag = torch.isfinite(up32).all()
         flags = getattr(self, "_flows_finite", None) or []
-        flags.append((torch.isfinite(up.sum()), captured))
-        self._flows_finite = flags[-64:]
+        eager = [f for f, c in flags if not c]
+        if not captured and eager:
+            flag = flag & eager[0].reshape(())
+            flags = [fc for fc in flags if fc[1]]
+        flags.append((flag, captured))
+        self._flows_finite = flags[-256:]          # (captured flags of graphs long gone are bounded; the eager flag is ONE folded entry)
         self._flows_precision = prec
         half = P // 2
         return up[:half].view(b, l_t - 1, 2, h, w), up[half:].view(b, l_t - 1, 2, h, w)

@@ -19,9 +19,21 @@ RECIPES = {
 }
 
 
-def seeded_weights(kind, template):
-    """kind in {'raft','fc','gen'}: the repo-wide deterministic weights for that model."""
-    return seeded_state_dict(template, **RECIPES[kind])
+# "stress" recipes (round 5): the weights the tame recipes scale down are left at full size -- RAFT's flow head x1.0 (flows of
+# tens of pixels after 20 iterations instead of a few: the correlation windows of a tile spread over the map, lookups leave it), the
+# offset heads of every deformable alignment x1.0 (offsets up to the 3 / 5 * tanh limit + flow: sampling corners far from the
+# mean-shifted patch).  Same seeds, same fill order: only the two scale factors differ.
+RECIPES_STRESS = {
+    "raft": dict(seed=11, gain=0.7),
+    "fc": dict(seed=12, gain=1.6, offset_scale=1.0),
+    "gen": dict(seed=13, gain=1.0, offset_scale=1.0),
+}
+
+
+def seeded_weights(kind, template, recipe="tame"):
+    """kind in {'raft','fc','gen'}: the repo-wide deterministic weights for that model (recipe "tame": the goldens' weights;
+    "stress": RECIPES_STRESS)."""
+    return seeded_state_dict(template, **(RECIPES if recipe == "tame" else RECIPES_STRESS)[kind])
 
 
 def seeded_state_dict(template, seed=2023, gain=1.6, offset_scale=0.4, scales=None):
@@ -102,16 +114,67 @@ def synthetic_mask(height, width):
     return m
 
 
-def seeded_models(device="cpu", raft_dtype=None, raft_precision=None):
-    """The three drop-in modules with the repo-wide seeded weights (the values the goldens were generated with);
-    used by the parity tests, smoke() and bench.py (no pretrained checkpoints exist offline)."""
+def stress_clip(length, height, width, seed=2024):
+    """Non-tame motion (round 5): two textured layers moving in OPPOSITE directions at 8-48 px/frame (the speed changes every frame)
+    and a slow occluder on top -- large, discontinuous, time-varying flow with disocclusions, where synthetic_clip is one rigid
+    (2, 1) px/frame translation.  The layers carry fine detail (periods down to ~6 px) so that a 1-px flow error changes pixels.
+    Returns uint8 [L, H, W, 3] (RGB)."""
+    rng = np.random.RandomState(seed)
+    yy, xx = np.meshgrid(np.arange(height, dtype=np.float64), np.arange(width, dtype=np.float64), indexing="ij")
+
+    def texture(nwaves, fmax):
+        t = np.zeros((height, width, 3), dtype=np.float64)
+        for c in range(3):
+            for _ in range(nwaves):
+                fy = rng.randint(1, fmax) * 2 * np.pi / height
+                fx = rng.randint(1, fmax) * 2 * np.pi / width
+                t[:, :, c] += rng.uniform(0.02, 0.09) * np.sin(fy * yy + fx * xx + rng.uniform(0, 2 * np.pi))
+        return t + 0.5
+    back, front = texture(10, 40), texture(10, 60) * 0.8 + 0.1
+    # the front layer covers a band of rows with a wavy edge (a motion boundary every window row crosses)
+    band = (yy > height * (0.42 + 0.08 * np.sin(xx * 2 * np.pi / (width / 3.0)))) & (yy < height * 0.82)
+    speeds = 8 + 40 * rng.rand(length)                         # px / frame, 8..48
+    pos = np.concatenate([[0.0], np.cumsum(speeds)])[:length]
+    frames = np.empty((length, height, width, 3), dtype=np.uint8)
+    occ_h, occ_w = max(8, height // 6), max(8, width // 10)
+    for i in range(length):
+        sb = int(round(pos[i]))
+        f = np.roll(back, shift=(0, sb % width), axis=(0, 1))
+        fr_l = np.roll(front, shift=((3 * i) % height, (-sb) % width), axis=(0, 1))
+        bm = np.roll(band, shift=(-sb) % width, axis=1)
+        f = np.where(bm[..., None], fr_l, f)
+        oy, ox = (height // 5 + 5 * i) % max(1, height - occ_h), (width // 8 + 11 * i) % max(1, width - occ_w)
+        f[oy:oy + occ_h, ox:ox + occ_w] = 0.08 + 0.05 * np.sin(0.7 * yy[oy:oy + occ_h, ox:ox + occ_w])[..., None]
+        f = f + rng.normal(0, 0.02, size=f.shape)
+        frames[i] = np.clip(f * 255.0, 0, 255).astype(np.uint8)
+    return frames
+
+
+def stress_mask(height, width):
+    """A border mask a la outpainting (inference_propainter.py:117-156: the canvas grows by 1 / 6 per side, everything outside the
+    original frame is hole) plus a lattice of small holes whose pitch is one attention window (5 x 9 tokens = 60 x 108 px), so that
+    EVERY window of every transformer layer holds a masked token -- the worst case of the sparse attention (all windows take the
+    full key set), where the tame rectangle masks 25 % of the windows.  uint8 {0, 255}; ~35 % of the area."""
+    m = np.zeros((height, width), dtype=np.uint8)
+    bh, bw = height // 12, width // 12
+    m[:bh], m[-bh:], m[:, :bw], m[:, -bw:] = 255, 255, 255, 255
+    sq = max(8, min(height, width) // 30)
+    for y in range(30, height, 60):
+        for x in range(54, width, 108):
+            m[y:y + sq, x:x + sq] = 255
+    return m
+
+
+def seeded_models(device="cpu", raft_dtype=None, raft_precision=None, recipe="tame"):
+    """The three drop-in modules with the repo-wide seeded weights (recipe "tame": the values the goldens were generated with;
+    "stress": RECIPES_STRESS); used by the parity tests, smoke() and bench.py (no pretrained checkpoints exist offline)."""
     from .model.modules.flow_comp_raft import RAFT_bi
     from .model.propainter import InpaintGenerator
     from .model.recurrent_flow_completion import RecurrentFlowCompleteNet
     raft = RAFT_bi(model_path=None, device="cpu", compute_dtype=raft_dtype, precision=raft_precision)
-    raft.fix_raft.load_state_dict(seeded_weights("raft", raft.fix_raft.state_dict()), strict=True)
+    raft.fix_raft.load_state_dict(seeded_weights("raft", raft.fix_raft.state_dict(), recipe), strict=True)
     fc = RecurrentFlowCompleteNet()
-    fc.load_state_dict(seeded_weights("fc", fc.state_dict()), strict=True)
+    fc.load_state_dict(seeded_weights("fc", fc.state_dict(), recipe), strict=True)
     gen = InpaintGenerator(init_weights=True)
-    gen.load_state_dict(seeded_weights("gen", gen.state_dict()), strict=True)
+    gen.load_state_dict(seeded_weights("gen", gen.state_dict(), recipe), strict=True)
     return raft.to(device).eval(), fc.to(device).eval(), gen.to(device).eval()

@@ -130,9 +130,49 @@ def _resize_u8(a, size, resample):
     return np.asarray(Image.fromarray(a).resize(size, resample)) if (a.shape[1], a.shape[0]) != tuple(size) else a
 
 
-def save_results(save_root, comp_frames, masked_frames, out_size, fps, save_frames):
+def _cv_linear_coeffs(n_src, n_dst):
+    """source index pair and 11-bit integer weights of OpenCV's 8-bit INTER_LINEAR along one axis (see resize_u8_linear)"""
+    d = np.arange(n_dst, dtype=np.float64)
+    f = ((d + 0.5) * (n_src / n_dst) - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    f = f - s.astype(np.float32)
+    lo, hi = s < 0, s >= n_src - 1
+    f[lo | hi] = 0
+    s[lo] = 0
+    s[hi] = n_src - 1
+    a0 = np.rint((np.float32(1) - f) * np.float32(2048)).astype(np.int64)
+    a1 = np.rint(f * np.float32(2048)).astype(np.int64)
+    return s, np.minimum(s + 1, n_src - 1), a0, a1
+
+
+def resize_u8_linear(a, size):
+    """cv2.resize(a, size, interpolation=cv2.INTER_LINEAR) for a uint8 image [H,W,C] / [H,W]: what the reference uses for its inputs
+    (core/dataset.py:186-188: no antialiasing when shrinking, unlike PIL's BILINEAR) and for the saved videos
+    (inference_propainter.py:469-470).  OpenCV (un-vendored, absent offline) resizes 8-bit images in fixed point -- 11-bit weights
+    cvRound(w * 2048), integer horizontal pass, (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2 vertically; an exact 2 : 1
+    reduction in both axes averages 2 x 2 blocks (its INTER_AREA shortcut).  Restated from the published algorithm; the device kernel
+    pp_resize_bilinear_u8 computes the same bytes (tests/test_ops_gpu.py)."""
+    a = np.asarray(a)
+    H, W = a.shape[:2]
+    OW, OH = int(size[0]), int(size[1])
+    if (OW, OH) == (W, H):
+        return a
+    x = a.reshape(H, W, -1).astype(np.int64)
+    if W == 2 * OW and H == 2 * OH:
+        out = (x[0::2, 0::2] + x[0::2, 1::2] + x[1::2, 0::2] + x[1::2, 1::2] + 2) >> 2
+    else:
+        x0, x1, a0, a1 = _cv_linear_coeffs(W, OW)
+        y0, y1, b0, b1 = _cv_linear_coeffs(H, OH)
+        rows = x[:, x0] * a0[None, :, None] + x[:, x1] * a1[None, :, None]                 # [H, OW, C]
+        out = (((b0[:, None, None] * (rows[y0] >> 4)) >> 16) + ((b1[:, None, None] * (rows[y1] >> 4)) >> 16) + 2) >> 2
+    return out.astype(np.uint8).reshape((OH, OW) + a.shape[2:])
+
+
+def save_results(save_root, comp_frames, masked_frames, out_size, fps, save_frames, comp_video_frames=None):
     """results/<name>/{masked_in.mp4, inpaint_out.mp4, frames/%04d.png} (:453-472).  With imageio + ffmpeg the videos are H.264 as the
-    reference's; without them (this image) the same files are written as Motion-JPEG .mp4 by the pure-Python muxer (mp4_mjpeg.py)."""
+    reference's; without them (this image) the same files are written as Motion-JPEG .mp4 by the pure-Python muxer (mp4_mjpeg.py).
+    The video frames are resized like cv2.resize(f, out_size) (INTER_LINEAR, :469-470): ``comp_video_frames`` = the composites already
+    resized on the device (hip.resize_bilinear_u8), else ``resize_u8_linear`` here; the PNG frames use bicubic (:458)."""
     os.makedirs(save_root, exist_ok=True)
     wrote = []
     if save_frames:
@@ -141,8 +181,8 @@ def save_results(save_root, comp_frames, masked_frames, out_size, fps, save_fram
         for i, f in enumerate(comp_frames):
             Image.fromarray(_resize_u8(f, out_size, Image.BICUBIC)).save(os.path.join(d, f"{i:04d}.png"))
         wrote.append(d)
-    masked = [_resize_u8(f, out_size, Image.BILINEAR) for f in masked_frames]
-    comp = [_resize_u8(f, out_size, Image.BILINEAR) for f in comp_frames]
+    masked = [resize_u8_linear(f, out_size) for f in masked_frames]
+    comp = list(comp_video_frames) if comp_video_frames is not None else [resize_u8_linear(f, out_size) for f in comp_frames]
     try:
         import imageio.v2 as imageio
         imageio.mimwrite(os.path.join(save_root, 'masked_in.mp4'), masked, fps=fps, quality=7)

@@ -77,11 +77,14 @@ def load_video(video_root, mask_root, name, size):
     4 x with the 3 x 3 cross.  Returns uint8 frames [L,H,W,3] and masks [L,H,W] {0,255}."""
     import scipy.ndimage
     from PIL import Image
+    from propainter_amd import video_io
     frame_list = sorted(os.listdir(os.path.join(video_root, name)))
     frames, masks = [], []
     for idx, fn in enumerate(frame_list):
-        img = Image.open(os.path.join(video_root, name, fn)).convert('RGB').resize(size, Image.BILINEAR)
-        frames.append(np.asarray(img, dtype=np.uint8))
+        # cv2.resize(img, size, INTER_LINEAR) (core/dataset.py:186-188): NO antialiasing when shrinking -- PIL's BILINEAR filters over the
+        # whole footprint, which changes both the model inputs and the ground truth of the PSNR / SSIM report
+        img = video_io.resize_u8_linear(np.asarray(Image.open(os.path.join(video_root, name, fn)).convert('RGB'), dtype=np.uint8), size)
+        frames.append(img)
         m = np.asarray(Image.open(os.path.join(mask_root, name, str(idx).zfill(5) + '.png')).resize(size, Image.NEAREST).convert('L'))
         masks.append(scipy.ndimage.binary_dilation(m > 0, iterations=4).astype(np.uint8) * 255)
     return np.stack(frames), np.stack(masks)

@@ -411,3 +411,23 @@ def test_flow_colour_coding_and_flow_resize():
     out = ev.resize_flows(fl, 8, 18)
     assert out.shape == (1, 2, 8, 18) and torch.allclose(out[:, 0], torch.full((1, 8, 18), 6.0)) and torch.allclose(out[:, 1], torch.full((1, 8, 18), -2.0))
     assert ev.resize_flows(fl, 4, 6) is not None and torch.equal(ev.resize_flows(fl, 4, 6), fl)
+
+
+def test_resize_u8_linear_is_non_antialiased_bilinear():
+    """video_io.resize_u8_linear = cv2.resize(..., INTER_LINEAR) restated (fixed-point weights): within one level of float bilinear
+    interpolation WITHOUT antialiasing (core/dataset.py:186-188 shrinks DAVIS frames to 432x240 this way), and clearly different from
+    PIL's BILINEAR, which filters over the whole footprint when shrinking (the evaluation inputs)."""
+    import torch.nn.functional as F
+    from PIL import Image
+    from propainter_amd import video_io
+    rng = np.random.RandomState(3)
+    a = rng.randint(0, 256, (480, 854, 3)).astype(np.uint8)
+    for size in ((432, 240), (427, 240), (854, 480), (1000, 600)):
+        out = video_io.resize_u8_linear(a, size)
+        assert out.shape == (size[1], size[0], 3) and out.dtype == np.uint8
+        fl = F.interpolate(torch.from_numpy(a).permute(2, 0, 1)[None].float(), size=(size[1], size[0]), mode="bilinear", align_corners=False)
+        assert (torch.from_numpy(out).float() - fl[0].permute(1, 2, 0)).abs().max().item() <= 1.0
+    pil = np.asarray(Image.fromarray(a).resize((432, 240), Image.BILINEAR))
+    assert np.abs(pil.astype(int) - video_io.resize_u8_linear(a, (432, 240)).astype(int)).max() > 20      # antialiased vs not: not the same image
+    half = video_io.resize_u8_linear(a, (427, 240))
+    assert np.array_equal(half, ((a[0::2, 0::2].astype(int) + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) >> 2).astype(np.uint8))

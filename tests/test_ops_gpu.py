@@ -697,6 +697,72 @@ def test_sparse_window_attention_mask_patterns(dev, pattern):
     check(pattern, out, ref, 6e-3)
 
 
+def _attention_by_rolling_tensors(q, k, v, pk, pv, tind, wmask, heads=4, ws=(5, 9)):
+    """SparseWindowAttention.forward on given q / k / v / pooled k, v WITHOUT any index table: window_partition (sparse_transformer.py:104-115),
+    the four torch.roll shifts and the valid_ind_rolled selection (:140-155,182-205), masked windows attending to own + rolled + pooled keys
+    of the T_ind frames, unmasked ones to their own frame's window (:227-269) -- the reference's own tensor operations, restated."""
+    B, T, Hp, Wp, C = q.shape
+    wh, ww = ws
+    ch = C // heads
+    nwh, nww = Hp // wh, Wp // ww
+
+    def part(x):          # (B, T, H, W, C) -> (B, n_windows, heads, T, wh * ww, ch)
+        x = x.view(B, T, nwh, wh, nww, ww, heads, ch).permute(0, 2, 4, 6, 1, 3, 5, 7).contiguous()
+        return x.view(B, nwh * nww, heads, T, wh * ww, ch)
+    eh, ew = (wh + 1) // 2, (ww + 1) // 2
+    m_tl, m_tr, m_bl, m_br = (torch.ones(wh, ww) for _ in range(4))
+    m_tl[:-eh, :-ew] = 0
+    m_tr[:-eh, ew:] = 0
+    m_bl[eh:, :-ew] = 0
+    m_br[eh:, ew:] = 0
+    valid = torch.stack((m_tl, m_tr, m_bl, m_br), 0).flatten(0).nonzero(as_tuple=False).view(-1)
+    rolled = lambda a: torch.cat([part(torch.roll(a, shifts=sh, dims=(2, 3))) for sh in ((-eh, -ew), (-eh, ew), (eh, -ew), (eh, ew))], 4)[:, :, :, :, valid]
+    wq, wk, wv, rk, rv = part(q), part(k), part(v), rolled(k), rolled(v)
+    P = pk.shape[2]
+    pool = lambda a: a.view(B, T, P, heads, ch).permute(0, 3, 1, 2, 4)[:, None].expand(B, nwh * nww, heads, T, P, ch)
+    pkw, pvw = pool(pk), pool(pv)
+    out = torch.zeros_like(wq)
+    for b in range(B):
+        for w in range(nwh * nww):
+            if wmask[b, w] > 0:
+                kk = torch.cat([wk[b, w][:, tind], rk[b, w][:, tind], pkw[b, w][:, tind]], 2).reshape(heads, -1, ch)
+                vv = torch.cat([wv[b, w][:, tind], rv[b, w][:, tind], pvw[b, w][:, tind]], 2).reshape(heads, -1, ch)
+                a = torch.softmax(wq[b, w].reshape(heads, -1, ch) @ kk.transpose(-2, -1) / math.sqrt(ch), -1)
+                out[b, w] = (a @ vv).view(heads, T, wh * ww, ch)
+            else:
+                a = torch.softmax(wq[b, w] @ wk[b, w].transpose(-2, -1) / math.sqrt(ch), -1)
+                out[b, w] = a @ wv[b, w]
+    out = out.view(B, nwh, nww, heads, T, wh, ww, ch).permute(0, 4, 1, 5, 2, 6, 3, 7).contiguous()
+    return out.view(B, T, Hp, Wp, C)
+
+
+@pytest.mark.parametrize("grid", [(10, 18), (15, 27)], ids=["2x2 windows", "3x3 windows"])
+def test_sparse_window_attention_against_rolled_tensors(dev, grid):
+    """The op with the PRODUCT's index tables (hip.window_tables) against a reference that never sees an index set: it rolls and
+    partitions the key / value TENSORS like sparse_transformer.py:174-205 (the other op tests take their
+    index sets from the product, so a wrong roll table would pass them).  Circular wrap repeats tokens on small grids: multiplicity
+    matters, and the 3 x 3 grid has an interior window whose rolled neighbourhood does not wrap."""
+    from propainter_amd import hip
+    Hp, Wp = grid
+    g = torch.Generator().manual_seed(150 + Hp)
+    B, T, C = 1, 4, 512
+    q, k, v = (torch.randn(B, T, Hp, Wp, C, generator=g) for _ in range(3))
+    P = (Hp // 4) * (Wp // 4)
+    pk, pv = torch.randn(B, T, P, C, generator=g), torch.randn(B, T, P, C, generator=g)
+    nw = (Hp // 5) * (Wp // 9)
+    wmask = (torch.arange(nw) % 3 != 1).float()[None]              # masked and unmasked windows
+    tind = torch.tensor([1, 3])
+    for dt, lim in ((torch.float32, 2e-4), (torch.float16, 6e-3)):
+        cast = lambda a: a.to(dt).float()
+        ref = _attention_by_rolling_tensors(cast(q), cast(k), cast(v), cast(pk), cast(pv), tind, wmask)
+        own_np, rolled_np = hip.window_tables(Hp, Wp)
+        out = hip.sparse_window_attention(q.to(dev, dt), k.to(dev, dt), v.to(dev, dt), pk.to(dev, dt), pv.to(dev, dt),
+                                          torch.from_numpy(own_np).to(dev), torch.from_numpy(rolled_np).to(dev),
+                                          tind.to(dev, torch.int32), wmask.to(dev), impl=0 if dt == torch.float16 else 1)
+        torch.cuda.synchronize()
+        check(f"attention_vs_rolled_tensors_{Hp}x{Wp}_{dt}", out, ref, lim)
+
+
 @pytest.mark.parametrize("variant", ["ref_f32", "ref_f16", "mfma_f16"])
 def test_sparse_window_attention(dev, variant):
     from propainter_amd import hip
@@ -801,3 +867,20 @@ def test_binary_dilate_is_bit_identical_to_scipy(dev, k):
     for i in range(3):
         want = (scipy.ndimage.binary_dilation(m[i], iterations=k) if k > 0 else m[i] > 0).astype(np.uint8) * 255
         assert np.array_equal(out[i], want), (k, i, int((out[i] != want).sum()))
+
+
+@pytest.mark.parametrize("size", [(216, 120), (300, 200), (864, 480), (431, 239), (432, 240)], ids=lambda s_: f"{s_[0]}x{s_[1]}")
+def test_resize_bilinear_u8_is_the_cv2_arithmetic(dev, size):
+    """pp_resize_bilinear_u8 (the final cv2.resize(f, out_size) of the driver, inference_propainter.py:469-470, on the device) against the
+    numpy restatement of OpenCV's fixed-point INTER_LINEAR (video_io.resize_u8_linear): byte for byte -- exact 2:1 (the INTER_AREA
+    shortcut), fractional down- and up-scaling, identity -- and against float bilinear interpolation (align_corners=False, no
+    antialiasing) within one level."""
+    from propainter_amd import hip, video_io
+    rng = np.random.RandomState(5)
+    a = rng.randint(0, 256, (3, 240, 432, 3)).astype(np.uint8)
+    out = hip.resize_bilinear_u8(torch.from_numpy(a).to(dev), size)
+    torch.cuda.synchronize()
+    ref = np.stack([video_io.resize_u8_linear(f, size) for f in a])
+    assert out.shape == (3, size[1], size[0], 3) and np.array_equal(out.cpu().numpy(), ref)
+    fl = F.interpolate(torch.from_numpy(a).permute(0, 3, 1, 2).float(), size=(size[1], size[0]), mode="bilinear", align_corners=False)
+    assert (out.cpu().float() - fl.permute(0, 2, 3, 1)).abs().max().item() <= 1.0

@@ -1,0 +1,311 @@
+"""Parity on NON-TAME data.  The repo-wide "tame" recipe scales RAFT's flow head by 0.15 and every offset head
+by 0.4 and moves one rigid texture by (2, 1) px per frame: flows stay within ~2 cells of the 1/8 map, deformable offsets near the tile
+mean, 25 % of the attention windows masked -- the best case of the data-dependent kernels.  Here: the STRESS recipe
+(propainter_amd/synthetic.py: RECIPES_STRESS, stress_clip, stress_mask) -- flow / offset heads at full size, two layers moving in
+opposite directions at 8-48 px/frame + an occluder, an outpainting border + one hole per attention window (every window masked) --
+through RAFT, flow completion and the generator at 720x1280 against the CPU oracle under the SAME limits as the tame tests, the
+other time dilations of the transformer, the fallback counters, and two committed oracle goldens (oracle/make_golden_synth.py)."""
+import hashlib
+import math
+import os
+
+import numpy as np
+import pytest
+import scipy.ndimage
+import torch
+
+from oracle import propainter_oracle as O
+from tests.helpers import load_golden, report, seeded_models
+from tests.test_headline_shapes_gpu import RTOL, rel_check
+from tests.test_modules_gpu import RAFT_720P_EPE_LIMIT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def stress_models():
+    assert torch.cuda.is_available()
+    return seeded_models("cuda", recipe="stress")
+
+
+@pytest.fixture(scope="module")
+def stress_sds():
+    raft, fc, gen = seeded_models("cpu", recipe="stress")
+    return {"raft": {k: v.float() for k, v in raft.fix_raft.state_dict().items()},
+            "fc": {k: v.float() for k, v in fc.state_dict().items()},
+            "gen": {k: v.float() for k, v in gen.state_dict().items()}}
+
+
+def _threads():
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+
+
+def test_raft_720p_endpoint_error_stress(stress_models, stress_sds):
+    """RAFT at 720x1280, 20 iterations, flow head x1.0 on two frames of the stress clip (layers 8-48 px apart in opposite directions): the
+    flows reach tens of pixels, the 9x9x4 correlation windows of a tile spread over the map (sub-tile fallbacks of the volume-free lookup)
+    and leave it (zero taps).  Limits: see below (the tame ones for exact fp32 and for f16x3's maximum)."""
+    from propainter_amd import hip
+    from propainter_amd.synthetic import stress_clip
+    H, W, iters = 720, 1280, 20
+    fr = torch.from_numpy(stress_clip(2, H, W)).permute(0, 3, 1, 2).float().div(255)[None] * 2 - 1
+    raft = stress_models[0]
+    _threads()
+    with torch.no_grad():
+        ref_f, ref_b = O.raft_bi(stress_sds["raft"], fr, iters=iters)
+    msgs, bad = [], []
+    # measured on MI355X (profiles/r5_stress_parity.txt): flows up to 114 px (mean |flow| 38 px; tame clip: 17 / 4 px); f32 mean 2.2e-5 /
+    # max 1.6e-4 px -- inside the TAME limits; f16x3 mean 8.5e-5 / max 4.1e-4 px: its error is relative to the value (22 significand
+    # bits), so it grows with the flows (2.2e-6 of the mean flow here, 5e-6 on the tame clip) -- max inside the tame limit, mean 1.2x
+    # over it.  Limits: the tame ones for f32; 2x the stress measurement for f16x3's mean.  north_star's bar is 1e-3.
+    limits = {"f32": RAFT_720P_EPE_LIMIT["f32"], "f16x3": (1.7e-4, RAFT_720P_EPE_LIMIT["f16x3"][1])}
+    for prec in ("f32", "f16x3"):
+        lim_mean, lim_max = limits[prec]
+        raft.precision = prec
+        try:
+            with hip.FallbackStats(torch.device("cuda")) as fs:
+                ff, fb = raft(fr.cuda(), iters=iters)
+                st = fs.read()
+        finally:
+            raft.precision = None
+        epe = torch.cat([(ff.cpu() - ref_f).pow(2).sum(2).sqrt().flatten(), (fb.cpu() - ref_b).pow(2).sum(2).sqrt().flatten()])
+        msgs.append(f"RAFT_720P_EPE_STRESS {prec}: mean {epe.mean():.3e} p99 {epe.quantile(0.99):.3e} max {epe.max():.3e} px "
+                    f"(flow range {ref_f.abs().max():.1f} px, mean |flow| {ref_f.abs().mean():.1f} px; sub-tile fallbacks "
+                    f"{st['corr_subtile_fallback_frac']}, single-pixel {st['corr_single_pixel_fallback_frac_of_subtiles']})")
+        if not (epe.mean() < lim_mean and epe.max() < lim_max):
+            bad.append(msgs[-1])
+    print("\n".join(msgs))
+    assert ref_f.abs().max() > 30, "the stress recipe must produce large flows"
+    assert not bad, bad
+
+
+def _stress_mask_t(t, H, W):
+    from propainter_amd.synthetic import stress_mask
+    m = scipy.ndimage.binary_dilation(stress_mask(H, W), iterations=4).astype(np.float32)
+    return torch.from_numpy(m)[None, None, None].repeat(1, t, 1, 1, 1)
+
+
+_fc_stress = {}
+
+
+def _fc_stress_case(stress_sds):
+    if not _fc_stress:
+        H, W, t = 720, 1280, 6
+        gq = torch.Generator().manual_seed(4100)
+        base = torch.zeros(1, t, 2, H, W)
+        base[:, :, 0, : H // 2] = 40.0
+        base[:, :, 0, H // 2:] = -40.0
+        fl = (base + torch.randn(1, t, 2, H, W, generator=gq) * 6, -base + torch.randn(1, t, 2, H, W, generator=gq) * 6)
+        m = _stress_mask_t(t + 1, H, W)
+        _threads()
+        with torch.no_grad():
+            ref32 = O.fc_forward_bidirect(stress_sds["fc"], fl, m)
+            ref64 = O.fc_forward_bidirect({k: v.double() for k, v in stress_sds["fc"].items()}, (fl[0].double(), fl[1].double()), m.double())
+        _fc_stress.update(fl=fl, m=m, ref32=ref32, ref64=ref64)
+    return _fc_stress
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16], ids=["f32", "f16"])
+def test_flow_completion_chunk_720p_stress(stress_models, stress_sds, dt):
+    """Stage B at 720x1280 with the offset heads at full size, flows of +-40 px with a motion boundary, and the border + lattice mask.
+    With these weights flow completion is ILL-CONDITIONED: the fp32 oracle itself is 1.7e-3 of the output range away from the same
+    oracle in fp64 at 240x432, and a 1e-7 relative perturbation of the input flows moves the fp64 result by up to 1e-2 px (tame recipe:
+    5.8e-6 / 2e-5; profiles/r5_stress_parity.txt) -- offsets of up to 5 cells sample steep feature fields through 12 second-order
+    recurrent steps.  north_star's "1e-3 of range in fp32" therefore cannot be asked of ANY fp32 implementation here; what can be asked:
+    the fp32 engine is as close to the fp64 oracle as the fp32 oracle is (same error class, factor 4), and the fp16 engine's MEAN error
+    stays small (limit 2e-2 of the range = 2.3x the measured 8.8e-3)."""
+    from propainter_amd import hip
+    c = _fc_stress_case(stress_sds)
+    fl, m = c["fl"], c["m"]
+    with hip.FallbackStats(torch.device("cuda")) as fs:
+        (pf, pb), _ = stress_models[1].forward_bidirect_flow((fl[0].cuda().to(dt), fl[1].cuda().to(dt)), m.cuda().to(dt))
+        st = fs.read()
+    name = "f32" if dt == torch.float32 else "f16"
+    rng = c["ref64"][0].abs().max().item()
+    for tag, got, r32, r64 in (("fwd", pf, c["ref32"][0], c["ref64"][0]), ("bwd", pb, c["ref32"][1], c["ref64"][1])):
+        e_or = (r32.double() - r64).abs()
+        e_en = (got.detach().cpu().double() - r64).abs()
+        print(f"STRESS fc720_{name}_{tag}: engine vs fp64 oracle max {e_en.max():.3e} mean {e_en.mean():.3e} p99 {e_en.flatten()[::97].quantile(0.99):.3e}; "
+              f"fp32 oracle vs fp64 oracle max {e_or.max():.3e} mean {e_or.mean():.3e} (range {rng:.1f}); "
+              f"deformable samples outside the staged patch {st['dcn_out_of_patch_frac']}")
+        assert torch.isfinite(got).all()
+        if dt == torch.float32:
+            assert e_en.mean() <= 4 * e_or.mean() + 1e-6 * rng and e_en.max() <= 4 * e_or.max() + 1e-3 * rng, (tag, e_en.max(), e_or.max())
+        else:
+            assert e_en.mean() <= 2e-2 * rng, (tag, e_en.mean())
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16], ids=["f32", "f16"])
+def test_generator_window_720p_stress(stress_models, stress_sds, dt):
+    """Stage D at 720x1280 on the stress recipe: EVERY attention window masked (all 144 windows take the full key set of every layer: own +
+    rolled + pooled keys of the dilation phase), offset heads at full size on flows of +-12 px at 1/4 resolution (deformable corners far
+    from the mean-shifted patch), same tolerances as the tame window."""
+    from propainter_amd import hip
+    H, W, tt, lt = 720, 1280, 8, 5
+    gq = torch.Generator().manual_seed(4200)
+    fr = torch.rand(1, tt, 3, H, W, generator=gq) * 2 - 1
+    mk = _stress_mask_t(tt, H, W)
+    mu = mk.clone()
+    mu[..., : H // 3, :] = 0                                           # image propagation filled the top third
+    base = torch.zeros(1, lt - 1, 2, H, W)
+    base[:, :, 0, : H // 2], base[:, :, 0, H // 2:] = 48.0, -48.0
+    gfl = (base + torch.randn(1, lt - 1, 2, H, W, generator=gq) * 4, -base + torch.randn(1, lt - 1, 2, H, W, generator=gq) * 4)
+    _threads()
+    with torch.no_grad():
+        ref = O.generator_forward(stress_sds["gen"], fr * (1 - mk), gfl, mk, mu, lt)
+    with hip.FallbackStats(torch.device("cuda")) as fs:
+        out = stress_models[2]((fr * (1 - mk)).cuda().to(dt), (gfl[0].cuda().to(dt), gfl[1].cuda().to(dt)), mk.cuda().to(dt), mu.cuda().to(dt), lt)
+        st = fs.read()
+    name = "f32" if dt == torch.float32 else "f16"
+    print(f"STRESS gen720_{name}: deformable samples outside the staged patch {st['dcn_out_of_patch_frac']}")
+    assert out.shape == ref.shape == (1, lt, 3, H, W)
+    rel_check(f"gen720_stress_{name}", out, ref, RTOL[dt]["gen"])
+
+
+@pytest.mark.parametrize("t_dilation", [1, 4, 3])
+def test_generator_other_time_dilations(t_dilation):
+    """InpaintGenerator.forward(t_dilation=...) (model/propainter.py:319, sparse_transformer.py:339: T_ind = arange(i % t_dilation, T,
+    t_dilation)): every test so far used the default 2.  fp32 engine against the oracle at the generator golden's size; a dilation
+    that does not divide the 8 blocks is refused exactly like the reference does (sparse_transformer.py:337: assert self.depths % t_dilation == 0)."""
+    models = seeded_models("cuda")
+    if t_dilation == 3:
+        z = torch.zeros(1, 4, 3, 64, 96, device="cuda")
+        with pytest.raises(AssertionError, match="t_dilation"):
+            models[2](z, (z[:, :1, :2], z[:, :1, :2]), z[:, :, :1], z[:, :, :1], 2, t_dilation=3)
+        return
+    raft, fc, gen = seeded_models("cpu")
+    sd = {k: v.float() for k, v in gen.state_dict().items()}
+    gq = torch.Generator().manual_seed(4300 + t_dilation)
+    H, W, tt, lt = 64, 96, 7, 3
+    fr = torch.rand(1, tt, 3, H, W, generator=gq) * 2 - 1
+    mk = torch.zeros(1, tt, 1, H, W)
+    mk[..., 10:50, 20:80] = 1
+    mu = torch.zeros(1, tt, 1, H, W)
+    mu[..., 20:40, 30:70] = 1
+    fl = (torch.randn(1, lt - 1, 2, H, W, generator=gq) * 2, torch.randn(1, lt - 1, 2, H, W, generator=gq) * 2)
+    with torch.no_grad():
+        ref = O.generator_forward(sd, fr * (1 - mk), fl, mk, mu, lt, t_dilation=t_dilation)
+    out = models[2]((fr * (1 - mk)).cuda(), (fl[0].cuda(), fl[1].cuda()), mk.cuda(), mu.cuda(), lt, t_dilation=t_dilation)
+    torch.cuda.synchronize()
+    rel_check(f"gen_t_dilation_{t_dilation}", out, ref, 1e-3)
+
+
+def test_fallback_counters_count_and_do_not_change_results():
+    """hip.FallbackStats: (a) the volume-free lookups count (tile, level) units, sub-tile and single-pixel fallbacks -- coordinates that
+    scatter a tile's windows over the whole map must trigger them, a smooth field must not; (b) the deformable kernel counts samples and
+    samples with a corner outside the staged patch -- offsets of +-40 px around the tile mean must trigger them, zero offsets must not;
+    in both cases the counting launch returns the bytes of the plain launch."""
+    from propainter_amd import hip
+    from propainter_amd.conv import ConvLayer
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(4400)
+    P, h, w = 2, 32, 48
+    f1, f2 = (torch.randn(P, h, w, 256, generator=g).half().to(dev) for _ in range(2))
+    lv = hip.corr_feature_pyramid(f2)
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+    smooth = (torch.stack([xs, ys], -1)[None].expand(P, h, w, 2) + 1.3).contiguous().to(dev)
+    scattered = (torch.rand(P, h, w, 2, generator=g) * torch.tensor([w - 1.0, h - 1.0])).contiguous().to(dev)
+    for name, coords, expect in (("smooth", smooth, False), ("scattered", scattered, True)):
+        plain = hip.corr_lookup_otf(f1, lv, coords, torch.empty((P, h, w, 328), dtype=torch.float16, device=dev)).clone()
+        with hip.FallbackStats(dev) as fs:
+            counted = hip.corr_lookup_otf(f1, lv, coords, torch.empty((P, h, w, 328), dtype=torch.float16, device=dev))
+            st = fs.read()
+        assert torch.equal(plain, counted)
+        assert st["corr_tile_levels"] == P * (h // 8) * (w // 8) * 4, st
+        assert (st["corr_subtile_fallbacks"] > 0) == expect, (name, st)
+    f1s, f2s = (torch.cat([t, torch.zeros_like(t)], -1).contiguous() for t in (f1, f2))
+    lvs = [f2s] + hip.corr_feature_pyramid_split(f2s)
+    with hip.FallbackStats(dev) as fs:
+        hip.corr_lookup_otf_split(f1s, lvs, scattered, torch.empty((P, h, w, 8 * hip.OTF_SPLIT_LEVEL_CHANNELS), dtype=torch.float16, device=dev))
+        st = fs.read()
+    assert st["corr_tile_levels"] == P * (h // 4) * (w // 8) * 4 and st["corr_subtile_fallbacks"] > 0, st
+    # deformable kernel
+    N, H, W, C = 1, 40, 64, 128
+    x = torch.randn(N, H, W, C, generator=g).half().to(dev)
+    wt, b = torch.randn(128, C, 3, 3, generator=g) / 34, torch.randn(128, generator=g) * 0.1
+    layer = ConvLayer(wt, b, padding=1, src_channels=[C], dcn_groups=16, dtype=torch.float16, device=dev)
+    for name, mag, expect in (("zero offsets", 0.0, False), ("offsets +-40 px", 40.0, True)):
+        om = torch.cat([(torch.rand(N, H, W, 288, generator=g) * 2 - 1) * mag, torch.rand(N, H, W, 144, generator=g)], -1).half().to(dev)
+        plain = layer([x], dcn_offmask=om).clone()
+        with hip.FallbackStats(dev) as fs:
+            counted = layer([x], dcn_offmask=om)
+            st = fs.read()
+        assert torch.equal(plain, counted), name
+        assert st["dcn_samples"] == N * H * W * 16 * 9, (name, st)
+        assert (st["dcn_out_of_patch_samples"] > 0) == expect, (name, st)
+
+
+def _golden_case(fn, recipe):
+    from oracle.make_golden_synth import inputs
+    g = load_golden(fn)
+    L, H, W = int(g["L"]), int(g["H"]), int(g["W"])
+    clip, masks = inputs(L, H, W, recipe)
+    dg = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    assert dg(clip) == str(g["frames_sha256"]) and dg(masks) == str(g["masks_sha256"]), "regenerated inputs differ from the fixture's"
+    ref = clip.copy()
+    ref[masks > 0] = g["comp_hole"]
+    kw = dict(raft_iter=int(g["raft_iter"]), subvideo_length=int(g["subvideo_length"]), neighbor_length=int(g["neighbor_length"]),
+              ref_stride=int(g["ref_stride"]))
+    return clip, masks, ref, kw
+
+
+def _end_to_end(models, fn, recipe, floors):
+    """whole path on a committed hole-only golden: fp32 stages + exact-f32 RAFT, and the timed split (fp16 stages + f16x3 RAFT)"""
+    from propainter_amd.pipeline import InferenceConfig, run_clip
+    clip, masks, ref, kw = _golden_case(fn, recipe)
+    hole = np.broadcast_to((masks > 0)[..., None], clip.shape)
+    raft = models[0]
+    out = {}
+    for name, fp16, prec in (("f32", False, "f32"), ("timed_split", True, "f16x3")):
+        raft.precision = prec
+        try:
+            got = run_clip(models, clip, masks, masks, InferenceConfig(fp16=fp16, **kw), torch.device("cuda")).cpu().numpy()
+        finally:
+            raft.precision = None
+        d = np.abs(got.astype(np.int16) - ref.astype(np.int16))
+        assert np.array_equal(got[~hole], clip[~hole])
+        mse = float((d[hole].astype(np.float64) ** 2).mean())
+        psnr_hole = float("inf") if mse == 0 else 20 * math.log10(255.0 / math.sqrt(mse))
+        out[name] = (psnr_hole, int(d.max()), float((d[hole] > 1).mean()))
+        print(f"STRESS_E2E {fn} {name}: hole PSNR {psnr_hole:.2f} dB, max |d| {int(d.max())}, hole bytes off by > 1: {(d[hole] > 1).mean():.2e}, "
+              f"off by >= 1: {(d[hole] > 0).mean():.3f}")
+    for name, (floor_db, max_abs) in floors.items():
+        assert out[name][0] >= floor_db and out[name][1] <= max_abs, (name, out[name])
+
+
+def test_config2_80_frames_end_to_end_vs_committed_golden():
+    """BASELINE config 2 AS STATED: the synthetic 432x240 clip, 80 frames (16 windows with reference frames, image propagation over the
+    whole clip), against the fp32 CPU oracle's bytes (7 CPU-minutes, committed hole-only: tests/golden/synth_c2_432x240x80.npz).  The
+    parity leg of bench.py can only afford a 6-frame clip; this is the full-length schedule."""
+    # floors: 3 dB under the values measured on MI355X (printed as STRESS_E2E lines)
+    _end_to_end(seeded_models("cuda"), "synth_c2_432x240x80.npz", "tame", {"f32": (80.0, 1), "timed_split": (55.0, 2)})
+
+
+def test_stress_clip_end_to_end_vs_committed_golden(stress_models):
+    """The whole path on the stress recipe (240x432, 12 frames: full-size flow / offset heads, opposite-moving layers, every attention
+    window masked) against the fp32 CPU oracle's bytes.  Large flows and saturated offsets feed the discontinuous nearest warps of image
+    propagation, so the fp16 split is allowed isolated larger byte errors; the floors are 3 dB under the measured values."""
+    # measured on MI355X (profiles/r5_stress_parity.txt): fp32 56.14 dB (max |d| 4, 0.28 % of the hole bytes off by more than 1), timed
+    # split 54.77 dB (max |d| 4, 0.52 %): the ill-conditioned flow completion (see test_flow_completion_chunk_720p_stress) moves completed
+    # flows by fractions of a pixel, which the nearest warps of image propagation turn into isolated byte errors.  Floors 3 dB under.
+    _end_to_end(stress_models, "synth_stress_240x432x12.npz", "stress", {"f32": (53.1, 16), "timed_split": (51.7, 16)})
+
+
+def test_documented_limits_raise_loudly():
+    """Where the engine is NARROWER than the reference it must say so instead of returning something else (missing #4):
+      * RAFT below 128 px: the reference's level-3 correlation map is 1 px wide and its bilinear_sampler divides by W - 1 = 0
+        (RAFT/utils/utils.py:61-62: NaN flows); the engine raises ValueError;
+      * more than 64 key frames in one dilation phase of a window (t > 64 * t_dilation): the attention kernel's key-frame table has
+        64 entries; the reference has no such limit (sparse_transformer.py:337-342) -- RuntimeError naming n_tind;
+      * a window of ONE frame: layer 1's T_ind = arange(1, 1, 2) is empty (the reference attends to zero keys there); RuntimeError."""
+    from propainter_amd import hip
+    models = seeded_models("cuda")
+    with pytest.raises(ValueError, match="128"):
+        models[0](torch.zeros(1, 2, 3, 120, 192, device="cuda"), iters=2)
+    Hp, Wp, C = 5, 9, 512
+    own_np, rolled_np = hip.window_tables(Hp, Wp)
+    own, rolled = torch.from_numpy(own_np).cuda(), torch.from_numpy(rolled_np).cuda()
+    for T, tind in ((66, torch.arange(0, 66, dtype=torch.int32)), (1, torch.zeros(0, dtype=torch.int32))):
+        q = torch.zeros(1, T, Hp, Wp, C, dtype=torch.float16, device="cuda")
+        pk = torch.zeros(1, T, 2, C, dtype=torch.float16, device="cuda")
+        with pytest.raises(RuntimeError, match="n_tind|pointer"):
+            hip.sparse_window_attention(q, q, q, pk, pk, own, rolled, tind.cuda(), torch.ones(1, 1, device="cuda"))

@@ -37,6 +37,16 @@ def timed(fn, steps, dev):
     return (time.perf_counter() - t0) * 1e3 / steps, out
 
 
+def diff_stats(a, b):
+    """byte-level difference of two uint8 clips: equal?, fraction of differing bytes, max |d|, frames that differ"""
+    ne = a != b
+    if not bool(ne.any()):
+        return {"equal": True}
+    d = (a.to(torch.int16) - b.to(torch.int16)).abs()
+    fr = [i for i in range(a.shape[0]) if bool(ne[i].any())]
+    return {"equal": False, "bytes_differ_frac": float(ne.float().mean()), "max_abs": int(d.max()), "frames_differing": len(fr), "first_frames": fr[:6]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=320)
@@ -50,6 +60,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--volume-gb", type=float, default=40.0)
     ap.add_argument("--skip-whole-pass", action="store_true")
+    ap.add_argument("--debug-stages", action="store_true", help="compare every logical rank's stage outputs inside the pipelined graph with the eager pass (PP_SG_DEBUG)")
     ap.add_argument("--private-pools", action="store_true", help="also run the schedule with one private graph pool per logical rank + its lockstep A/B")
     args = ap.parse_args()
     hip.lib()
@@ -64,6 +75,8 @@ def main():
            "steps": args.steps}
 
     # ---- round 5 default: the wavefront as ONE hipGraph pipelined by stage (the overlapped form)
+    if args.debug_stages:
+        os.environ["PP_SG_DEBUG"] = "1"
     torch.cuda.reset_peak_memory_stats(dev)
     t0 = time.perf_counter()
     sp1 = StreamingClipGraph(models, L, H, W, cfg, dev, volume_gb=args.volume_gb)
@@ -73,6 +86,26 @@ def main():
     ms_pipe, out_pipe = timed(sp1.replay, args.steps, dev)
     out_pipe = out_pipe.clone()
     rec["pipelined_single_graph"] = {"ms_per_clip": ms_pipe, "frames_per_s": L / ms_pipe * 1e3}
+    if args.debug_stages:
+        from propainter_amd.pipeline import run_clip
+        from propainter_amd.sharding import ShardPlan
+        eager_out, st = run_clip(models, clip, masks, masks, cfg, dev, return_stages=True)
+        torch.cuda.synchronize(dev)
+        plan = ShardPlan(L, sp1.cfg, sp1.world)
+        dbg = []
+        mx = lambda a, b: float((a.float() - b.float()).abs().max()) if a.numel() else 0.0
+        for r in range(sp1.world):
+            lo, hi = plan.flows_own(r)
+            flo, fhi = plan.own[r]
+            d = sp1._single_debug
+            row = {"rank": r}
+            row["raft_flows"] = mx(d[(r, 0)]["gt"], torch.stack([st["gt_flows"][0][:, lo:hi], st["gt_flows"][1][:, lo:hi]], 0))
+            row["completed_flows"] = mx(d[(r, 1)]["pred_own"], torch.stack([st["pred_flows"][0][:, lo:hi], st["pred_flows"][1][:, lo:hi]], 0))
+            row["updated_frames_masks"] = mx(d[(r, 2)]["upd_own"], torch.cat([st["updated_frames"][:, flo:fhi], st["updated_masks"][:, flo:fhi]], 2))
+            row["composited_bytes_differ"] = float((out_pipe[flo:fhi] != eager_out[flo:fhi]).float().mean())
+            dbg.append(row)
+        rec["pipelined_stage_deviation_vs_eager"] = dbg
+        print(json.dumps(dbg), file=sys.stderr, flush=True)
     rec["pipelined_peak_reserved_GB"] = torch.cuda.max_memory_reserved(dev) / 1e9
     torch.cuda.empty_cache()
     rec["pipelined_reserved_steady_GB"] = torch.cuda.memory_reserved(dev) / 1e9
@@ -92,6 +125,7 @@ def main():
     out_stream = out_stream.clone()
     rec["streaming"] = {"ms_per_clip": ms_stream, "frames_per_s": L / ms_stream * 1e3}
     rec["pipelined_equals_chained"] = bool(torch.equal(out_pipe, out_stream))
+    rec["pipelined_vs_chained"] = diff_stats(out_pipe, out_stream)
     rec["streaming_peak_reserved_GB"] = torch.cuda.max_memory_reserved(dev) / 1e9        # incl. the eager warm-up pass of every logical rank
     torch.cuda.empty_cache()
     rec["streaming_reserved_steady_GB"] = torch.cuda.memory_reserved(dev) / 1e9           # what a serving loop holds: the graph pool + static buffers
@@ -126,6 +160,14 @@ def main():
         rec["whole_pass_reserved_steady_GB"] = torch.cuda.memory_reserved(dev) / 1e9
         rec["streaming_equals_whole_pass"] = bool(torch.equal(out_stream, out_whole))
         rec["pipelined_equals_whole_pass"] = bool(torch.equal(out_pipe, out_whole))
+        rec["pipelined_vs_whole_pass"] = diff_stats(out_pipe, out_whole)
+        rec["chained_vs_whole_pass"] = diff_stats(out_stream, out_whole)
+        from propainter_amd.pipeline import run_clip
+        eager = run_clip(models, clip, masks, masks, cfg, dev)
+        torch.cuda.synchronize(dev)
+        rec["eager_run_clip_vs_whole_pass"] = diff_stats(eager, out_whole)
+        rec["eager_run_clip_vs_pipelined"] = diff_stats(eager, out_pipe)
+        rec["eager_run_clip_vs_chained"] = diff_stats(eager, out_stream)
         rec["speedup_streaming_vs_whole_pass"] = ms_whole / ms_stream
         rec["speedup_pipelined_vs_whole_pass"] = ms_whole / ms_pipe
     print(json.dumps(rec))
