@@ -496,16 +496,27 @@ __global__ __launch_bounds__(64) void window_mask_kernel(const T* __restrict__ m
   const int b = i / nW, w = i % nW;
   const int y0 = (w / nww) * wh, x0 = (w % nww) * ww;
   const int lane = threadIdx.x, wsz = wh * ww;
-  const bool on = lane < wsz;
-  const int y = on ? lane / ww : 0, x = on ? lane % ww : 0;
-  const T* mp = mask + ((long long)b * Lt * Hp + y0 + y) * Wp + x0 + x;
   float s = 0.f;
+  if (wsz <= 64) {                       // the model's 5 x 9 window: one position per lane
+    const bool on = lane < wsz;
+    const int y = on ? lane / ww : 0, x = on ? lane % ww : 0;
+    const T* mp = mask + ((long long)b * Lt * Hp + y0 + y) * Wp + x0 + x;
 #pragma unroll 4
-  for (int t = 0; t < Lt; ++t) {
-    float mx = on ? to_f32(mp[(long long)t * Hp * Wp]) : -INFINITY;
+    for (int t = 0; t < Lt; ++t) {
+      float mx = on ? to_f32(mp[(long long)t * Hp * Wp]) : -INFINITY;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    s += mx;
+      for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+      s += mx;
+    }
+  } else {                               // any window size: the lanes loop over the positions
+    for (int t = 0; t < Lt; ++t) {
+      float mx = -INFINITY;
+      for (int q = lane; q < wsz; q += 64)
+        mx = fmaxf(mx, to_f32(mask[(((long long)b * Lt + t) * Hp + y0 + q / ww) * Wp + x0 + q % ww]));
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+      s += mx;
+    }
   }
   if (lane == 0) wmask[i] = s;
 }
@@ -555,7 +566,7 @@ extern "C" int pp_window_tables(int Hp, int Wp, int wh, int ww, int32_t* own, in
 
 extern "C" int pp_window_mask(const void* mask, float* wmask, int B, int Lt, int Hp, int Wp, int wh, int ww, int dtype,
                               void* stream) {
-  PP_REQUIRE(mask && wmask && B > 0 && Lt > 0 && wh > 0 && ww > 0 && wh * ww <= 64 && Hp % wh == 0 && Wp % ww == 0, PP_ERR_ARG,
+  PP_REQUIRE(mask && wmask && B > 0 && Lt > 0 && wh > 0 && ww > 0 && Hp % wh == 0 && Wp % ww == 0, PP_ERR_ARG,
              "pp_window_mask: bad arguments (window %d x %d: at most 64 positions)", wh, ww);
   PP_REQUIRE(dtype == PP_F32 || dtype == PP_F16, PP_ERR_DTYPE, "pp_window_mask: dtype %d", dtype);
   const int n = B * (Hp / wh) * (Wp / ww);

@@ -218,20 +218,24 @@ class _GenEngine:
         return out5 if batched else out5.view(t, h, w, c)
 
     def propagate_windows(self, clip, windows):
-        """Feature propagation of ALL generator windows of a clip up front, windows of equal length batched (engine extension; the
+        """PLANS the feature propagation of all generator windows of a clip, windows of equal length batched (engine extension; the
         reference runs it inside every window's forward, model/propainter.py:345-349).  windows: [(first local frame, l_t), ...].
         A window's propagation is a chain of ~170 launches over ONE 1/4-resolution frame each (57 600 pixels at 720p: ~450 blocks for
         512 slots -- a single generation of blocks, all prologue and epilogue); the windows are independent, so the 14 full-length
-        windows of an 80-frame clip run as ONE chain of launches over 14 frames each.  Results land in clip['prop'][(first, l_t)] =
-        (fused [l_t,B,h,w,128], k): forward_window copies its frames out.  Bit-identical to the per-window chain (see
-        feature_propagation); groups whose first frames are no arithmetic progression stay on the per-window path."""
+        windows of an 80-frame clip run as ONE chain of launches over 14 frames each.  Bit-identical to the per-window chain (see
+        feature_propagation); groups whose first frames are no arithmetic progression stay on the per-window path.
+
+        ROLLING (round 5, ADVICE medium): a group of windows is propagated when its first window is about to run (``ensure_propagated``,
+        called by the pass on its main stream before the window is handed to a lane; ``forward_window`` does it itself for callers that
+        do not) and its fused tensor is dropped when its last window has been consumed (``release_window``) -- the pass holds ONE
+        group's results (<= ~2.5 GB + the chain's temporaries) instead of every window's: round 4 kept ~2.2x the encoder cache alive
+        until the end of the pass (35 GB or more for a 500-frame 1080p clip)."""
         enc = clip["enc"]
-        dev = enc.device
         h, w = enc.shape[1], enc.shape[2]
         by_len = {}
         for first, l_t in windows:
             by_len.setdefault(l_t, []).append(first)
-        clip["prop"] = {}
+        clip["prop"], clip["prop_plan"], clip["prop_groups"], clip["prop_left"] = {}, {}, [], {}
         for l_t, firsts in by_len.items():
             firsts = sorted(set(firsts))
             step = firsts[1] - firsts[0] if len(firsts) > 1 else 1
@@ -243,19 +247,44 @@ class _GenEngine:
             bmax = max(2, min(len(firsts), int(self.prop_batch_bytes // per_window)))
             for b0 in range(0, len(firsts), bmax):
                 group = firsts[b0:b0 + bmax]
-                B = len(group)
-                if B < 2:
+                if len(group) < 2:
                     continue                  # a single left-over window: per-window path
-                # frame index of (step j, window k) = group[0] + step * k + j -- built on the device (capturable: no host copy)
-                base = torch.arange(B, device=dev) * step + group[0]
-                idx = (torch.arange(l_t, device=dev)[:, None] + base[None, :]).reshape(-1)
-                idxp = (torch.arange(l_t - 1, device=dev)[:, None] + base[None, :]).reshape(-1)
-                g5 = lambda src, ix, n: src.index_select(0, ix).view(n, B, h, w, src.shape[-1])
-                fused = self.feature_propagation(g5(enc, idx, l_t), None, None, None, clip["interpolation"],
-                                                 rows=(g5(clip["aux_b"], idxp, l_t - 1), g5(clip["aux_f"], idxp, l_t - 1), g5(clip["mk8"], idx, l_t)))
-                for k, first in enumerate(group):
-                    clip["prop"][(first, l_t)] = (fused, k)
+                gid = len(clip["prop_groups"])
+                clip["prop_groups"].append((l_t, group, step))
+                clip["prop_left"][gid] = len(group)
+                for first in group:
+                    clip["prop_plan"][(first, l_t)] = gid
         return clip
+
+    def ensure_propagated(self, clip, first, l_t):
+        """Runs the batched propagation of the group the window (first, l_t) belongs to, on the CURRENT stream, unless it is there already."""
+        gid = clip.get("prop_plan", {}).get((first, l_t))
+        if gid is None or (first, l_t) in clip["prop"] or clip["prop_left"].get(gid, 0) <= 0:
+            return
+        enc = clip["enc"]
+        dev = enc.device
+        h, w = enc.shape[1], enc.shape[2]
+        l_t, group, step = clip["prop_groups"][gid]
+        B = len(group)
+        # frame index of (step j, window k) = group[0] + step * k + j -- built on the device (capturable: no host copy)
+        base = torch.arange(B, device=dev) * step + group[0]
+        idx = (torch.arange(l_t, device=dev)[:, None] + base[None, :]).reshape(-1)
+        idxp = (torch.arange(l_t - 1, device=dev)[:, None] + base[None, :]).reshape(-1)
+        g5 = lambda src, ix, n: src.index_select(0, ix).view(n, B, h, w, src.shape[-1])
+        fused = self.feature_propagation(g5(enc, idx, l_t), None, None, None, clip["interpolation"],
+                                         rows=(g5(clip["aux_b"], idxp, l_t - 1), g5(clip["aux_f"], idxp, l_t - 1), g5(clip["mk8"], idx, l_t)))
+        for k, f in enumerate(group):
+            clip["prop"][(f, l_t)] = (fused, k)
+
+    def release_window(self, clip, first, l_t):
+        """The window (first, l_t) has read its propagated frames: when it was the last one of its group, the group's tensor goes."""
+        gid = clip.get("prop_plan", {}).get((first, l_t))
+        if gid is None or (first, l_t) not in clip.get("prop", {}):
+            return
+        clip["prop_left"][gid] -= 1
+        if clip["prop_left"][gid] <= 0:
+            for f in clip["prop_groups"][gid][1]:
+                clip["prop"].pop((f, l_t), None)
 
     # ------------------------------------------------------------------ transformer
     def _window_tables(self, Hp, Wp):
@@ -385,8 +414,9 @@ class _GenEngine:
         n_ref = int(ref_index.numel())
         encw = torch.empty((l_t + n_ref, h, w, 128), dtype=self.dtype, device=enc.device)
         a, b = first, first + l_t
+        self.ensure_propagated(clip, first, l_t)      # (no-op when the pass did it on its main stream, or when the window is not batched)
         done = clip.get("prop", {}).get((first, l_t))
-        if done is not None:          # propagated up front with the other windows of its length (propagate_windows)
+        if done is not None:          # propagated with the other windows of its group (propagate_windows)
             encw[:l_t].copy_(done[0][:, done[1]])
         else:
             self.feature_propagation(enc[a:b], None, None, None, clip["interpolation"],
@@ -515,6 +545,18 @@ class InpaintGenerator(nn.Module):
         import contextlib
         with (torch.cuda.device(enc.device) if enc.is_cuda else contextlib.nullcontext()):
             return self._get_engine(enc.dtype, enc.device).propagate_windows(clip, [(int(f), int(n)) for f, n in windows])
+
+    @torch.no_grad()
+    def ensure_propagated(self, clip, first, num_local_frames):
+        """Engine extension: see _GenEngine.ensure_propagated (call on the stream the clip cache was prepared on)."""
+        enc = clip["enc"]
+        import contextlib
+        with (torch.cuda.device(enc.device) if enc.is_cuda else contextlib.nullcontext()):
+            self._get_engine(enc.dtype, enc.device).ensure_propagated(clip, int(first), int(num_local_frames))
+
+    def release_window(self, clip, first, num_local_frames):
+        enc = clip["enc"]
+        self._get_engine(enc.dtype, enc.device).release_window(clip, int(first), int(num_local_frames))
 
     @hip.on_input_device
     @torch.no_grad()

@@ -273,10 +273,17 @@ def run_clip(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg: InferenceC
         # engine extension: the windows' feature propagation up front, windows of equal length batched -- one chain of launches over
         # ~14 frames each instead of 14 chains over one frame each (single-generation grids); same results
         model.propagate_windows(clip_cache, [(nb[0], len(nb)) for nb, _ in sched])
+    # (rolling batched propagation: a group of windows is propagated on THIS stream right before its first window is issued, and its
+    #  fused tensor is dropped once its last window has been composited -- InpaintGenerator.ensure_propagated / release_window)
+    rolling = clip_cache is not None and "prop_plan" in clip_cache
+    ensure = (lambda nb: model.ensure_propagated(clip_cache, nb[0], len(nb))) if rolling else (lambda nb: None)
+    release = (lambda nb: model.release_window(clip_cache, nb[0], len(nb))) if rolling else (lambda nb: None)
     lanes = _window_streams(device, cfg.window_streams) if device.type == "cuda" else []
     if len(lanes) < 2:
         for nb, ref in sched:
+            ensure(nb)
             comp.add(nb, window(nb, ref)[0])
+            release(nb)
     else:
         # The windows are independent until the ordered blend: consecutive windows run on separate HIP streams (forked from
         # and joined to the current stream, so a hipGraph capture records parallel branches), which lets one window's
@@ -286,6 +293,8 @@ def run_clip(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg: InferenceC
         cur = torch.cuda.current_stream(device)
         for i in range(0, len(sched), len(lanes)):
             group = []
+            for nb, ref in sched[i:i + len(lanes)]:
+                ensure(nb)                        # on the pass's stream: the lanes fork behind it
             for s_, (nb, ref) in zip(lanes, sched[i:i + len(lanes)]):
                 s_.wait_stream(cur)
                 with torch.cuda.stream(s_):
@@ -294,6 +303,8 @@ def run_clip(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg: InferenceC
                 cur.wait_stream(s_)
                 pred.record_stream(cur)
                 comp.add(nb, pred[0])
+            for nb, _, _ in group:
+                release(nb)                       # every lane of the group has joined: a finished propagation group can go
     mark('generator')
     if return_stages:
         return comp.comp, dict(gt_flows=gt_flows_bi, pred_flows=pred_flows_bi, updated_frames=updated_frames,

@@ -336,15 +336,22 @@ def sharded_clip_steps(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg: 
             else:
                 blend(idx, cur)
 
+    rolling = clip_cache is not None and "prop_plan" in clip_cache      # rolling batched propagation (pipeline.run_clip)
+    ensure = (lambda nb: model.ensure_propagated(clip_cache, enc_pos[nb[0]], len(nb))) if rolling else (lambda nb: None)
+    release = (lambda nb: model.release_window(clip_cache, enc_pos[nb[0]], len(nb))) if rolling else (lambda nb: None)
     lanes = _window_streams(device, cfg.window_streams, lane_key) if device.type == "cuda" else []
     if len(lanes) < 2:
         for f, nb, ref in my_windows:
+            ensure(nb)
             composite(f, nb, window(nb, ref))
+            release(nb)
     else:
         # consecutive windows on separate HIP streams, composited afterwards in window order (as pipeline.run_clip)
         cur_s = torch.cuda.current_stream(device)
         for i in range(0, len(my_windows), len(lanes)):
             group = []
+            for f, nb, ref in my_windows[i:i + len(lanes)]:
+                ensure(nb)
             for s_, (f, nb, ref) in zip(lanes, my_windows[i:i + len(lanes)]):
                 s_.wait_stream(cur_s)
                 with torch.cuda.stream(s_):
@@ -353,6 +360,8 @@ def sharded_clip_steps(models, frames_u8, flow_masks_u8, masks_dilated_u8, cfg: 
                 cur_s.wait_stream(s_)
                 out.record_stream(cur_s)
                 composite(f, nb, out)
+            for f, nb, out, s_ in group:
+                release(nb)
     send = {q: torch.stack(v, 0) for q, v in outbox.items()}
     recv = {src: ((len(items), H, W, 3), torch.uint8) for (src, dst), items in routes.items() if dst == rank}
     got = yield Exchange(send, recv, "blend")

@@ -25,24 +25,30 @@ def read_frames(path):
     """Image folder or video file -> (list of RGB PIL images, fps or None, (w, h), name) (:52-71)."""
     if path.endswith(VIDEO_EXT):
         name = os.path.basename(path)[:-4]
-        frames = None
+        frames, first_error = None, None
         try:
             import imageio.v2 as imageio
             rd = imageio.get_reader(path)
             fps = rd.get_meta_data().get('fps')
             frames = [Image.fromarray(np.asarray(f)[..., :3]) for f in rd]
-        except ImportError:
+        except Exception as e:      # noqa: BLE001 -- imageio missing, or importable without its ffmpeg plugin / binary (RuntimeError, IOError, ...)
+            first_error, frames = e, None
             try:
                 import torchvision
                 v, _, info = torchvision.io.read_video(filename=path, pts_unit='sec')
                 frames, fps = [Image.fromarray(f) for f in v.numpy()], info['video_fps']
-            except (ImportError, AttributeError):      # (no torchvision, or one without the video reader)
-                pass
-        if frames is None:
+            except Exception:       # noqa: BLE001 -- no torchvision, or one without a working video reader
+                frames = None
+        if not frames:
             # neither imageio(+ffmpeg) nor torchvision.io: the pure-Python path reads JPEG-coded .mp4 / .mov tracks (what save_results
             # writes in such an image, and what `ffmpeg -c:v mjpeg` writes); other codecs raise, naming the codec and the remedy
             from . import mp4_mjpeg
-            frames, fps = mp4_mjpeg.read_mp4(path)
+            try:
+                frames, fps = mp4_mjpeg.read_mp4(path)
+            except Exception:       # noqa: BLE001
+                if first_error is not None and not isinstance(first_error, ImportError):
+                    raise first_error         # a decoder WAS there and failed: its message is the useful one
+                raise
     else:
         name = os.path.basename(os.path.normpath(path))
         files = sorted(f for f in os.listdir(path) if f.endswith(IMAGE_EXT))

@@ -852,6 +852,10 @@ def test_elementwise_ops(dev, dt):
     torch.cuda.synchronize()
     ref = F.max_pool2d(mask, (5, 9), (5, 9)).view(1, 3, -1).sum(1)
     assert torch.equal(wm.cpu(), ref)
+    big = (torch.rand(2, 3, 20, 36, generator=g) > 0.99).float()          # windows of 10 x 12 = 120 positions (> one wave: the generic path)
+    wm2 = hip.window_mask(big.to(dev, dt), 10, 12)
+    torch.cuda.synchronize()
+    assert torch.equal(wm2.cpu(), F.max_pool2d(big, (10, 12), (10, 12)).view(2, 3, -1).sum(1))
 
 
 @pytest.mark.parametrize("k", [0, 1, 4, 7])
