@@ -319,13 +319,16 @@ class CpuBaseline:
                units["prop_steps"] * per_unit["prop_step_s"] + units["gen_window_frames"] * per_unit["gen_window_frame_s"])
         return ({"value": L / est, "unit": "frames/s", "cores": cores, "kind": "port",
                  "sample": f"CPU oracle fp32 (oracle/propainter_oracle.py), whole path on a {Ls}-frame {W}x{H} synthetic clip, measured at "
-                           f"this size on {cores} threads ({self.avail} available) while the GPU legs of this bench ran: {dt:.1f} s "
+                           f"this size on {cores} threads ({self.avail} available) UNDER CONTENTION -- the GPU legs of this bench (their host threads, graph "
+                           f"captures, H2D copies) ran on the same cores at the same time, and the 6-frame generator windows under-state what an "
+                           f"18-frame window costs the CPU: {dt:.1f} s "
                            f"(RAFT {tm['raft_s']:.1f} s / {tm['raft_pair_directions']} pair-directions, flow completion {tm['fc_s']:.1f} s / "
                            f"{tm['fc_flows']} flows, image propagation {tm['prop_s']:.1f} s / {tm['prop_steps']} steps, generator "
                            f"{tm['gen_s']:.1f} s / {tm['gen_windows']} windows of {tm['gen_window_frames'] // max(1, tm['gen_windows'])} frames); "
                            f"value = {L} frames / (unit counts of the {L}-frame clip x these per-unit costs) = {est:.0f} s -- EXTRAPOLATED "
                            f"in clip length only; the generator's per-frame cost grows with the window length (attention), so longer "
                            f"windows (17 frames on average here) would cost the CPU more, not less",
+                 "contention": "measured while the GPU legs of the same bench run used the host (a reported baseline, not a target)",
                  "measured_sample_seconds": dt, "measured_sample_fps": Ls / dt, "per_unit_seconds": per_unit, "unit_counts": units,
                  "estimated_clip_seconds": est}, frames)
 

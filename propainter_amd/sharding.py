@@ -787,10 +787,12 @@ class StreamingClipGraph:
 
     NSEG = 5          # compute segments of sharded_clip_steps: RAFT | completion | image propagation | windows | boundary blends
 
-    def __init__(self, models, L, H, W, cfg, device, world=None, volume_gb=40.0, share_pool=True, single_graph=True):
-        """single_graph=True (round 5, the default): the whole wavefront as ONE hipGraph, pipelined by stage -- RAFT, flow completion and
-        image propagation of the sub-videos on three branches forked from the capture stream, the generator windows on the capture
-        stream, the exchanges as direct tensor hand-overs ordered by captured events (``_capture_single_graph``).  The overlap of the
+    def __init__(self, models, L, H, W, cfg, device, world=None, volume_gb=40.0, share_pool=True, single_graph=True, validate=3):
+        """single_graph=True (round 5, the default): the whole wavefront as ONE hipGraph, pipelined by stage -- RAFT and image
+        propagation of the sub-videos on two branches forked from the capture stream, flow completion, the generator windows and the
+        boundary blends on the capture stream, the exchanges as direct tensor hand-overs ordered by captured events
+        (``_capture_single_graph``); ``validate`` replays of the captured graph are compared bit for bit with the eager pass at capture
+        time, and a graph that does not reproduce it is replaced by the chained per-segment graphs (with a warning).  The overlap of the
         schedule lives INSIDE one graph (parallel branches: the form the whole-pass ClipGraph and the generator lanes use), not in
         concurrent launches of several graphs, which give wrong frames on ROCm 7.2 (see ``replay``).  single_graph=False: one graph per
         (rank, segment), replayed chained (share_pool=True: one memory pool, capture order) or in the lockstep / concurrent A/B orders
@@ -805,6 +807,7 @@ class StreamingClipGraph:
         self.cfg = dataclasses.replace(cfg, raft_streams=1)         # the ranks run next to each other: one RAFT lane each
         self.volume_gb = float(volume_gb)
         self.single_graph = bool(single_graph)
+        self.validate = int(validate)       # single_graph: replays checked bit for bit against the eager warm-up pass at capture time (0: off)
         self.share_pool = bool(share_pool) and not self.single_graph
         self._single, self._single_out, self._single_keep = None, None, None
         pool = torch.cuda.graph_pool_handle() if self.share_pool else None
@@ -828,12 +831,29 @@ class StreamingClipGraph:
         if saved is not None:
             raft.volume_budget_bytes = self.volume_gb * 1e9 / self.world
         try:
-            run_logical_shards(self.models, *self._inputs, self.cfg, self.device, self.world)
+            warm = run_logical_shards(self.models, *self._inputs, self.cfg, self.device, self.world)
             torch.cuda.synchronize(self.device)
+            warm = warm.cpu()                             # the eager pass's bytes: what the captured graph must reproduce (validate)
             torch.cuda.empty_cache()                      # the warm-up's cached blocks go back before `world` private graph pools grow
             if self.single_graph:
                 self.order = self._capture_single_graph()
                 torch.cuda.synchronize(self.device)
+                if self.validate and not self._validate_single_graph(warm):
+                    import warnings
+                    warnings.warn("StreamingClipGraph: the stage-pipelined hipGraph did not reproduce the eager pass bit for bit in "
+                                  f"{self.validate} replays on this runtime; falling back to chained launches of per-segment graphs "
+                                  "(same frames, no overlap)", RuntimeWarning)
+                    self._single, self._single_out, self._single_keep = None, None, None
+                    torch.cuda.empty_cache()
+                    self.single_graph, self.share_pool = False, True
+                    pool = torch.cuda.graph_pool_handle()
+                    self.graphs = [ShardedClipGraph(self.models, self.L, self.H, self.W, self.cfg, self.device, r, self.world, pool=pool)
+                                   for r in range(self.world)]
+                    self.load(*self._inputs)
+                    order = self._capture_in_wavefront_order()
+                    torch.cuda.synchronize(self.device)
+                    self.order = wavefront_order(self.world, self.NSEG, lambda r, s_: sorted(self.graphs[r].segments[s_][1].recv))
+                    assert order == self.order
                 return self
             if self.share_pool:
                 order = self._capture_in_wavefront_order()
@@ -884,11 +904,22 @@ class StreamingClipGraph:
             order.append((r, s))
         return order
 
+    def _validate_single_graph(self, expected_cpu):
+        """The captured graph replayed ``self.validate`` times on the capture clip: every replay must give the eager pass's bytes.
+        (A capture whose branches race is otherwise silent: the frames are plausible, a byte off here and there.)"""
+        for _ in range(int(self.validate)):
+            self._single.replay()
+            torch.cuda.synchronize(self.device)
+            if not torch.equal(self._single_out.cpu(), expected_cpu):
+                return False
+        return True
+
     def _capture_single_graph(self):
         """The wavefront as ONE hipGraph, pipelined BY STAGE: the logical ranks' generators (``sharded_clip_steps``) run under a single
         capture in ``wavefront_order`` (same greedy rule as the multi-graph capture), segment s of every rank on STAGE stream s --
-        RAFT of all sub-videos on one branch, flow completion on the next, image propagation on a third (side streams forked from the
-        capture stream), the generator windows (which fork their own lanes) and the boundary blends on the capture stream itself.  An
+        RAFT of all sub-videos on one branch, image propagation on another (side streams forked from the capture stream), flow
+        completion, the generator windows (which fork their own lanes) and the boundary blends on the capture stream itself (see the
+        stage map below for why flow completion is not on a branch of its own).  An
         exchange is answered by handing the sender's tensors over (no copy); segment s waits for the events recorded behind the
         segments s - 1 it reads from.  Every dependency therefore points from stage stream s - 1 to stage stream s: a stream never waits
         for a stream that waited for it.  That shape is forced by the runtime: on ROCm 7.2 hipStreamEndCapture SEGFAULTS when two forked
@@ -917,11 +948,15 @@ class StreamingClipGraph:
         try:
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 cur = torch.cuda.current_stream(dev)
-                stage = side + [cur, cur]
-                if os.environ.get("PP_SG_STAGES") is not None:      # diagnostic (tools/diag_stream2.py): only these stages leave the capture stream
-                    on_side = {int(v) for v in os.environ["PP_SG_STAGES"].split(",") if v != ""}
-                    stage = [side[i] if i in on_side else cur for i in range(3)] + [cur, cur]
-                    side = [st for st in side if st in stage]
+                # which stages leave the capture stream: RAFT (0) and image propagation (2) on branches of their own, flow completion (1)
+                # with the windows on the capture stream.  MEASURED at BASELINE config 4 (720x1280x320, profiles/r5_streaming_single_graph.txt):
+                # with flow completion on a third branch the LAST sub-video's completed flows differed from replay to replay (max 0.025 px,
+                # +-1 byte in 0.2 % of that sub-video's bytes; smaller clips never showed it, the kernels are bit-stable next to unrelated
+                # load, lanes on / off made no difference); with this map every stage of every rank equals the eager pass and the pass is
+                # 2 % faster (flow completion is latency-bound and overlaps the windows' tail either way).  PP_SG_STAGES overrides (diagnosis).
+                on_side = {int(v) for v in os.environ.get("PP_SG_STAGES", "0,2").split(",") if v != ""}
+                stage = [side[i] if i in on_side else cur for i in range(3)] + [cur, cur]
+                side = [st for st in side if st in stage]
                 for st in side:
                     st.wait_stream(cur)
                 while pending:

@@ -89,7 +89,7 @@ _fc_stress = {}
 
 def _fc_stress_case(stress_sds):
     if not _fc_stress:
-        H, W, t = 720, 1280, 6
+        H, W, t = 720, 1280, 3            # (3 flows x 2 directions: the oracle runs twice, fp32 and fp64 -- ~40 s of host time)
         gq = torch.Generator().manual_seed(4100)
         base = torch.zeros(1, t, 2, H, W)
         base[:, :, 0, : H // 2] = 40.0
@@ -140,7 +140,7 @@ def test_generator_window_720p_stress(stress_models, stress_sds, dt):
     rolled + pooled keys of the dilation phase), offset heads at full size on flows of +-12 px at 1/4 resolution (deformable corners far
     from the mean-shifted patch), same tolerances as the tame window."""
     from propainter_amd import hip
-    H, W, tt, lt = 720, 1280, 8, 5
+    H, W, tt, lt = 720, 1280, 6, 3
     gq = torch.Generator().manual_seed(4200)
     fr = torch.rand(1, tt, 3, H, W, generator=gq) * 2 - 1
     mk = _stress_mask_t(tt, H, W)
@@ -277,7 +277,8 @@ def test_config2_80_frames_end_to_end_vs_committed_golden():
     whole clip), against the fp32 CPU oracle's bytes (7 CPU-minutes, committed hole-only: tests/golden/synth_c2_432x240x80.npz).  The
     parity leg of bench.py can only afford a 6-frame clip; this is the full-length schedule."""
     # floors: 3 dB under the values measured on MI355X (printed as STRESS_E2E lines)
-    _end_to_end(seeded_models("cuda"), "synth_c2_432x240x80.npz", "tame", {"f32": (80.0, 1), "timed_split": (55.0, 2)})
+    # measured on MI355X (profiles/r5_stress_parity.txt): fp32 87.75 dB, timed split 59.08 dB, max |d| 1 byte in both (8 % of the hole bytes off by one)
+    _end_to_end(seeded_models("cuda"), "synth_c2_432x240x80.npz", "tame", {"f32": (84.7, 1), "timed_split": (56.0, 1)})
 
 
 def test_stress_clip_end_to_end_vs_committed_golden(stress_models):

@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--volume-gb", type=float, default=40.0)
     ap.add_argument("--skip-whole-pass", action="store_true")
+    ap.add_argument("--only-pipelined", action="store_true", help="stop after the pipelined single-graph leg")
     ap.add_argument("--debug-stages", action="store_true", help="compare every logical rank's stage outputs inside the pipelined graph with the eager pass (PP_SG_DEBUG)")
     ap.add_argument("--private-pools", action="store_true", help="also run the schedule with one private graph pool per logical rank + its lockstep A/B")
     args = ap.parse_args()
@@ -68,7 +69,8 @@ def main():
     L, H, W = args.frames, args.height, args.width
     models = seeded_models(dev, raft_precision=args.raft_dtype)
     cfg = InferenceConfig(raft_iter=args.raft_iter, subvideo_length=args.subvideo_length, neighbor_length=args.neighbor_length,
-                          ref_stride=args.ref_stride, fp16=True)
+                          ref_stride=args.ref_stride, fp16=True, window_streams=int(os.environ.get("PP_DIAG_LANES", "2")),
+                          batch_propagation=os.environ.get("PP_DIAG_NOBATCH") != "1")
     m = scipy.ndimage.binary_dilation(synthetic_mask(H, W), iterations=4).astype(np.uint8) * 255
     clip, masks = synthetic_clip(L, H, W, seed=2023), np.repeat(m[None], L, 0)
     rec = {"workload": f"{H}x{W}x{L} frames, subvideo_length {args.subvideo_length}, fp16 stages + RAFT {args.raft_dtype}, one MI355X",
@@ -105,7 +107,14 @@ def main():
             row["composited_bytes_differ"] = float((out_pipe[flo:fhi] != eager_out[flo:fhi]).float().mean())
             dbg.append(row)
         rec["pipelined_stage_deviation_vs_eager"] = dbg
+        again = sp1.replay().clone()
+        torch.cuda.synchronize(dev)
+        rec["pipelined_replay_to_replay"] = diff_stats(again, out_pipe)
+        rec["pipelined_vs_eager"] = diff_stats(out_pipe, eager_out)
         print(json.dumps(dbg), file=sys.stderr, flush=True)
+    if args.only_pipelined:
+        print(json.dumps(rec))
+        return
     rec["pipelined_peak_reserved_GB"] = torch.cuda.max_memory_reserved(dev) / 1e9
     torch.cuda.empty_cache()
     rec["pipelined_reserved_steady_GB"] = torch.cuda.memory_reserved(dev) / 1e9
