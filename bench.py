@@ -60,18 +60,25 @@ def pmc_traffic(kernel_class, raft_dtype):
     the figure is a committed profile's, never this run's: only a profile that records the commit it was measured at and the
     same RAFT precision is used, and both are reported.  Returns (bytes or None, source description or None)."""
     import glob
+    from propainter_amd import build as _build
     fam = TRAFFIC_FAMILY.get(kernel_class)
     best = None
+    digest = _build.source_digest()
     for f in glob.glob(os.path.join(ROOT, "profiles", "*hbm_traffic*.json")):
         try:
             d = json.load(open(f))
             rec = d["families"].get(fam)
         except Exception:
             continue
+        # only a profile of THESE kernel sources (SHA-256 over csrc/ + include/ + the build flags, recorded by the profiling run): a
+        # figure measured on other kernels is not this run's traffic (round 4 carried a profile that was several kernel changes old)
+        if d.get("csrc_digest") != digest:
+            continue
         if rec and d.get("commit") and d.get("raft_dtype") == raft_dtype and (best is None or d.get("commit_time", 0) > best[0]):
             best = (d.get("commit_time", 0), rec["hbm_bytes_per_launch"],
-                    f"{os.path.relpath(f, ROOT)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at commit {d['commit']}, RAFT {raft_dtype}; not collected in this run)")
-    return (best[1], best[2]) if best else (None, None)
+                    f"{os.path.relpath(f, ROOT)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at commit {d['commit']}, RAFT {raft_dtype}, the same "
+                    f"kernel sources as this run: csrc digest {digest[:12]}; not collected in this run)")
+    return (best[1], best[2]) if best else (None, f"no committed --pmc profile of these kernel sources (csrc digest {digest[:12]}): traffic not reported")
 
 
 def parse(argv=None):

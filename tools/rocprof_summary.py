@@ -16,6 +16,7 @@ import csv
 import glob
 import json
 import re
+import os
 import sys
 
 SPLIT_FAMILY = "conv_gemm_f16x3 (split-plane LDS-DMA implicit GEMM)"
@@ -159,6 +160,12 @@ def cmd_traffic(fetch_dir, write_dir, out):
     if len(sys.argv) > 5:         # commit the passes were measured at, its time, RAFT precision of the profiled command
         meta = {"commit": sys.argv[5], "commit_time": int(sys.argv[6]) if len(sys.argv) > 6 and sys.argv[6].isdigit() else 0,
                 "raft_dtype": sys.argv[7] if len(sys.argv) > 7 else "f16x3"}
+    try:          # the digest of the kernel sources the profiled library was built from (bench.py refuses a profile of other sources)
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from propainter_amd import build as _b
+        meta["csrc_digest"] = _b.source_digest()
+    except Exception as e:      # noqa: BLE001
+        meta["csrc_digest"] = None
     json.dump({"note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B); WRITE_SIZE as reported; "
                        "both in KiB; separate --pmc passes", **meta, "families": res}, open(out, "w"), indent=1)
     for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"]):
