@@ -699,8 +699,8 @@ def main(argv=None, runtime=None):
             if not os.path.exists(path):
                 return {"error": f"{fn} not found"}
             g = np.load(path)
-            from oracle.make_golden_synth import inputs as golden_inputs       # (the checker's input recipe; regenerates, never computes)
-            gclip, gmasks = golden_inputs(int(g["L"]), int(g["H"]), int(g["W"]), str(g["recipe"]))
+            from propainter_amd.synthetic import case_inputs
+            gclip, gmasks = case_inputs(int(g["L"]), int(g["H"]), int(g["W"]), str(g["recipe"]))
             dg = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
             if dg(gclip) != str(g["frames_sha256"]) or dg(gmasks) != str(g["masks_sha256"]):
                 return {"error": f"{fn}: regenerated inputs do not match the fixture's digests"}

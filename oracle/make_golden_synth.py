@@ -15,11 +15,10 @@ import time
 import warnings
 
 import numpy as np
-import scipy.ndimage
 import torch
 
 from . import propainter_oracle as O
-from propainter_amd.synthetic import seeded_models, stress_clip, stress_mask, synthetic_clip, synthetic_mask
+from propainter_amd.synthetic import seeded_models
 
 GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 CASES = {
@@ -32,13 +31,9 @@ CASES = {
 
 
 def inputs(L, H, W, recipe):
-    """(frames uint8 [L,H,W,3], dilated masks uint8 [L,H,W] {0,255}) of a case: what bench.py times (tame) / its stress leg."""
-    if recipe == "tame":
-        clip, m = synthetic_clip(L, H, W), synthetic_mask(H, W)
-    else:
-        clip, m = stress_clip(L, H, W), stress_mask(H, W)
-    m = scipy.ndimage.binary_dilation(m, iterations=4).astype(np.uint8) * 255        # (--mask_dilation 4, inference_propainter.py:96,105)
-    return clip, np.repeat(m[None], L, 0)
+    """(frames uint8 [L,H,W,3], dilated masks uint8 [L,H,W] {0,255}) of a case: propainter_amd.synthetic.case_inputs."""
+    from propainter_amd.synthetic import case_inputs
+    return case_inputs(L, H, W, recipe)
 
 
 def digest(a):

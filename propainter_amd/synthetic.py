@@ -165,6 +165,19 @@ def stress_mask(height, width):
     return m
 
 
+def case_inputs(length, height, width, recipe="tame"):
+    """(frames uint8 [L,H,W,3], dilated masks uint8 [L,H,W] {0,255}) of a synthetic case: the clip bench.py times ("tame") or its stress
+    leg ("stress"), masks dilated 4x like the driver (--mask_dilation 4, inference_propainter.py:96,105).  The committed goldens
+    (tests/golden/synth_*.npz) store SHA-256 digests of exactly these arrays."""
+    import scipy.ndimage
+    if recipe == "tame":
+        clip, m = synthetic_clip(length, height, width), synthetic_mask(height, width)
+    else:
+        clip, m = stress_clip(length, height, width), stress_mask(height, width)
+    m = scipy.ndimage.binary_dilation(m, iterations=4).astype(np.uint8) * 255
+    return clip, np.repeat(m[None], length, 0)
+
+
 def seeded_models(device="cpu", raft_dtype=None, raft_precision=None, recipe="tame"):
     """The three drop-in modules with the repo-wide seeded weights (recipe "tame": the values the goldens were generated with;
     "stress": RECIPES_STRESS); used by the parity tests, smoke() and bench.py (no pretrained checkpoints exist offline)."""

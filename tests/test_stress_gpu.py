@@ -235,7 +235,7 @@ def test_fallback_counters_count_and_do_not_change_results():
 
 
 def _golden_case(fn, recipe):
-    from oracle.make_golden_synth import inputs
+    from propainter_amd.synthetic import case_inputs as inputs
     g = load_golden(fn)
     L, H, W = int(g["L"]), int(g["H"]), int(g["W"])
     clip, masks = inputs(L, H, W, recipe)
