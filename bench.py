@@ -756,6 +756,11 @@ def main(argv=None, runtime=None):
                     assert_finite_flows(smodels[0])
                 except FloatingPointError as e:
                     finite = f"{type(e).__name__}: {e}"
+                # where the stress pass spends its time, next to the headline's `kernels` table (one instrumented eager pass, windows serialised)
+                with hip.KernelProfiler() as kps:
+                    run_clip(smodels, sf, smk, smk, dataclasses.replace(cfg, window_streams=1, raft_streams=1), dev)
+                    rt.sync()
+                skern = {k: round(v["ms"], 1) for k, v in sorted(kps.summary().items(), key=lambda kv: -kv[1]["ms"])[:8]}
                 rt.empty_cache()
                 gs = ClipGraph(smodels, L, H, W, cfg, dev, example=(sf, smk, smk))
                 gs.replay()
@@ -772,6 +777,7 @@ def main(argv=None, runtime=None):
                           "recipe": "RECIPES_STRESS (flow head x1.0, offset heads x1.0), stress_clip (two layers in opposite directions at 8-48 px/frame "
                                     "+ occluder), stress_mask (outpainting border + one hole per attention window: every window masked)",
                           "mask_area_frac": float((sm_ > 0).mean()), "flows_finite": finite, "fallback": sfall,
+                          "kernels_ms": skern, "headline_kernels_ms": ({k: round(v["ms"], 1) for k, v in kernels.items() if k in skern} if kernels else None),
                           "parity": golden_parity("synth_stress_720x1280x6.npz", smodels, cfg)}
                 smodels = None
                 rt.empty_cache()
