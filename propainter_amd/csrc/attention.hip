@@ -317,6 +317,7 @@ __device__ __forceinline__ void attn_block(const AttnParams& p, const int b, con
     if (more) load_tile(fi_n, r0_n);
     // ---- S^T tiles: sacc[qt][kt][r] = score(key = k0 + kt*16 + (lane>>4)*4 + r, query = lane&15 of tile qt)
     f32x4 sacc[QT][4];
+    PP_ATTN_PRIO_BEGIN();
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
 #pragma unroll
@@ -329,6 +330,7 @@ __device__ __forceinline__ void attn_block(const AttnParams& p, const int b, con
         for (int qt = 0; qt < QT; ++qt) sacc[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qt][s], sacc[qt][kt], 0, 0, 0);
       }
     }
+    PP_ATTN_PRIO_END();
     if constexpr (PROF) { ta = __builtin_readcyclecounter(); pf[3] += ta - tb; }
     // ---- online softmax per query tile, in the exp2 domain: p = 2^(s*c - m), c = scale*log2(e), m = running max of s*c.
     // (one fma + one v_exp per score; the key-validity mask only on the partial last tile of a frame; the accumulator
@@ -379,6 +381,7 @@ __device__ __forceinline__ void attn_block(const AttnParams& p, const int b, con
     // ---- O^T += V^T P^T : k-slot (lane>>4)*8 + i of step j <-> key 32j + (i>>2)*16 + (lane>>4)*4 + (i&3);
     // accumulator row i of tile dt is channel (i/4)*32 + dt*4 + i%4 (column order of the transposing reads)
     const T* vbase = &Vs[((lane >> 4) * 4 + ((lane & 15) >> 2)) * VS_LD + (lane & 3) * 32];
+    PP_ATTN_PRIO_BEGIN();
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -390,6 +393,7 @@ __device__ __forceinline__ void attn_block(const AttnParams& p, const int b, con
         for (int qt = 0; qt < QT; ++qt) oacc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pfr[qt][j], oacc[qt][dt], 0, 0, 0);
       }
     }
+    PP_ATTN_PRIO_END();
     if constexpr (PROF) { ta = __builtin_readcyclecounter(); pf[5] += ta - tb; }
     __syncthreads();
   }

@@ -8,6 +8,45 @@
 
 #include "../../include/propainter_hip.h"
 
+// s_setprio around an MFMA cluster (cdna_hip_programming.md T5: the CU's issue arbiter prefers the wave that is entering its matrix
+// instructions over a co-resident wave that is issuing loads / scalar work).  Build-time switches so that tools/build_variant.sh can A/B
+// them; the shipped values follow the measurement (profiles/r5_setprio_ab.txt, interleaved rounds on one box, bit-identical outputs):
+//   PP_SETPRIO_SPLIT (tri-product cluster of the split-plane halo kernel, 48 MFMAs):  convc2 -3.5 %, flow head -1.5 %, convm -1.3 %, GRU gate
+//                    convolutions -0.8 ... -1.0 %                                                                        -> ON
+//   PP_SETPRIO       (fp16 halo clusters of 32 MFMAs, tiled v2 kernel incl. its tri step): -0.5 ... +4 % (worse on the fp16 GRU / convc2
+//                    shapes, +1.5 % on the split 1x1)                                                                    -> off
+//   PP_SETPRIO_ATTN  (S and PV clusters of the attention kernel): 0.692 vs 0.691 ms                                      -> off
+#ifndef PP_SETPRIO
+#define PP_SETPRIO 0
+#endif
+#ifndef PP_SETPRIO_SPLIT
+#define PP_SETPRIO_SPLIT 1
+#endif
+#if PP_SETPRIO_SPLIT
+#define PP_SPLIT_PRIO_BEGIN() __builtin_amdgcn_s_setprio(1)
+#define PP_SPLIT_PRIO_END() __builtin_amdgcn_s_setprio(0)
+#else
+#define PP_SPLIT_PRIO_BEGIN() ((void)0)
+#define PP_SPLIT_PRIO_END() ((void)0)
+#endif
+#ifndef PP_SETPRIO_ATTN
+#define PP_SETPRIO_ATTN 0
+#endif
+#if PP_SETPRIO_ATTN
+#define PP_ATTN_PRIO_BEGIN() __builtin_amdgcn_s_setprio(1)
+#define PP_ATTN_PRIO_END() __builtin_amdgcn_s_setprio(0)
+#else
+#define PP_ATTN_PRIO_BEGIN() ((void)0)
+#define PP_ATTN_PRIO_END() ((void)0)
+#endif
+#if PP_SETPRIO
+#define PP_MFMA_PRIO_BEGIN() __builtin_amdgcn_s_setprio(1)
+#define PP_MFMA_PRIO_END() __builtin_amdgcn_s_setprio(0)
+#else
+#define PP_MFMA_PRIO_BEGIN() ((void)0)
+#define PP_MFMA_PRIO_END() ((void)0)
+#endif
+
 namespace pp {
 
 void set_error(const char* fmt, ...);

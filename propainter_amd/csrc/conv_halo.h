@@ -264,6 +264,7 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : HALO_MIN_WAVES
             bf[kk][f] = *reinterpret_cast<const f16x8*>(sb + b_off + f * 16 * 128 + (((kk * 4 + l4) ^ bswz) << 4));
           }
         }
+        PP_SPLIT_PRIO_BEGIN();
 #pragma unroll
         for (int a = 0; a < TN; ++a)
 #pragma unroll
@@ -276,6 +277,7 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : HALO_MIN_WAVES
         for (int a = 0; a < TN; ++a)
 #pragma unroll
           for (int b = 0; b < TM; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[0][a], af[0][b], acc[a][b], 0, 0, 0);   // W_hi x A_hi
+        PP_SPLIT_PRIO_END();
       } else if constexpr (STAGGER == 0 && BN == 128 && WMT == 64 && BM == 128) {
         // the fragments of BOTH K halves are requested before the first MFMA (32 more live fragment registers; 231 in all for 3x3): the
         // reads of the second half complete under the 16 MFMAs of the first instead of being waited for in four small groups
@@ -292,12 +294,14 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : HALO_MIN_WAVES
           }
         }
         __builtin_amdgcn_sched_barrier(0);
+        PP_MFMA_PRIO_BEGIN();
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
           for (int a = 0; a < TN; ++a)
 #pragma unroll
             for (int b = 0; b < TM; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[kk][a], af[kk][b], acc[a][b], 0, 0, 0);
+        PP_MFMA_PRIO_END();
         __builtin_amdgcn_sched_barrier(0);
       } else {
 #pragma unroll
@@ -310,10 +314,12 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : HALO_MIN_WAVES
         }
 #pragma unroll
         for (int f = 0; f < TN; ++f) bf[f] = *reinterpret_cast<const f16x8*>(sb + b_off + f * 16 * 128 + (((kk * 4 + l4) ^ bswz) << 4));
+        PP_MFMA_PRIO_BEGIN();
 #pragma unroll
         for (int a = 0; a < TN; ++a)
 #pragma unroll
           for (int b = 0; b < TM; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[a], af[b], acc[a][b], 0, 0, 0);
+        PP_MFMA_PRIO_END();
       }
       }
       if constexpr (PROF) { asm volatile("s_nop 0" ::: "memory"); pf_comp += __builtin_readcyclecounter() - pf_a; }

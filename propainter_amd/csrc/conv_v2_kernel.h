@@ -320,6 +320,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N <= 4 && 
 #pragma unroll
         for (int t = 0; t < TN; ++t) bf[kk][t] = *reinterpret_cast<const f16x8*>(sb + b_off + t * 16 * ROWB + so);
       }
+      PP_MFMA_PRIO_BEGIN();
 #pragma unroll
       for (int a = 0; a < TN; ++a)
 #pragma unroll
@@ -332,6 +333,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N <= 4 && 
       for (int a = 0; a < TN; ++a)
 #pragma unroll
         for (int b = 0; b < TM; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[0][a], af[0][b], acc[a][b], 0, 0, 0);   // W_hi x A_hi
+      PP_MFMA_PRIO_END();
     } else if constexpr (SCHED == 0) {
       if (more) {
         if constexpr (UNI) {
@@ -381,6 +383,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N <= 4 && 
         else issue(ks + S - 1, nbuf, E);
       }
       __builtin_amdgcn_sched_barrier(0);
+      PP_MFMA_PRIO_BEGIN();
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
@@ -388,6 +391,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N <= 4 && 
 #pragma unroll
           for (int b = 0; b < TM; ++b)
             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[kk][a], af[kk][b], acc[a][b], 0, 0, 0);
+      PP_MFMA_PRIO_END();
     }
     buf = buf + 1 == S ? 0 : buf + 1;
     nbuf = nbuf + 1 == S ? 0 : nbuf + 1;

@@ -8,6 +8,7 @@ Usage (GPU box):  python tools/bench_conv.py [--reps 20] > gpurun_out/conv_sweep
 import argparse
 import math
 import os
+import re
 import sys
 
 import torch
@@ -43,6 +44,12 @@ SHAPES = [
     ("gen_enc_128_s2", 18, 360, 640, [64], 128, (3, 3), 2, 1, 1),
     ("gen_dec_64_cout3", 11, 720, 1280, [64], 3, (3, 3), 1, 1, 1),
     ("fc_dec_32_3x3", 16, 360, 640, [32], 32, (3, 3), 1, 1, 1),
+    # the batched feature propagation of the generator windows (round 4: 14 windows per launch) and the decoder at 11 local frames
+    ("prop_off0_n14", 14, 180, 320, [128, 128, 5], 128, (3, 3), 1, 1, 1),
+    ("prop_off2_n14", 14, 180, 320, [128], 128, (3, 3), 1, 1, 1),
+    ("prop_off6_n14", 14, 180, 320, [128], 432, (3, 3), 1, 1, 1),
+    ("dec_128_64_n11", 11, 360, 640, [128], 64, (3, 3), 1, 1, 1),
+    ("dec_64_64_n11", 11, 720, 1280, [64], 64, (3, 3), 1, 1, 1),
 ]
 IMPLS = {"cout>64": [1, 112, 12, 10, 11, 13, 14, 17, 18, 19], "cout>32": [1, 122, 22, 20, 21], "cout>16": [1, 132, 32, 30, 31], "cout<=16": [1, 142, 42, 40, 41]}
 
@@ -96,7 +103,7 @@ def main():
     g = torch.Generator().manual_seed(5)
     print(f"{'shape':24s} {'impl':>4s} {'ms':>9s} {'TFLOP/s':>9s} {'max|d| vs impl1':>16s}")
     for name, N, H, W, cin, cout, k, stride, pad, groups in SHAPES:
-        if args.only and args.only not in name:
+        if args.only and not re.search(args.only, name):
             continue
         kh, kw = k
         wt = torch.randn(cout, sum(cin), kh, kw, generator=g) / math.sqrt(sum(cin) * kh * kw)
