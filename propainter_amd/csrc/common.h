@@ -15,22 +15,29 @@
 //                    convolutions -0.8 ... -1.0 %                                                                        -> ON
 //   PP_SETPRIO       (fp16 halo clusters of 32 MFMAs, tiled v2 kernel incl. its tri step): -0.5 ... +4 % (worse on the fp16 GRU / convc2
 //                    shapes, +1.5 % on the split 1x1)                                                                    -> off
-//   PP_SETPRIO_ATTN  (S and PV clusters of the attention kernel): 0.692 vs 0.691 ms                                      -> off
+//   PP_SETPRIO_ATTN  (S and PV clusters of the attention kernel): 0.692 vs 0.691 ms alone, but 71.1 -> 68.7 ms per clip inside the pass
+//                    (two window lanes overlap)                                                                           -> ON
 #ifndef PP_SETPRIO
 #define PP_SETPRIO 0
 #endif
 #ifndef PP_SETPRIO_SPLIT
 #define PP_SETPRIO_SPLIT 1
 #endif
-#if PP_SETPRIO_SPLIT
+#if PP_SETPRIO_SPLIT == 2      // (variant: raised from the fragment reads on)
+#define PP_SPLIT_PRIO_EARLY() __builtin_amdgcn_s_setprio(1)
+#define PP_SPLIT_PRIO_BEGIN() ((void)0)
+#define PP_SPLIT_PRIO_END() __builtin_amdgcn_s_setprio(0)
+#elif PP_SETPRIO_SPLIT
+#define PP_SPLIT_PRIO_EARLY() ((void)0)
 #define PP_SPLIT_PRIO_BEGIN() __builtin_amdgcn_s_setprio(1)
 #define PP_SPLIT_PRIO_END() __builtin_amdgcn_s_setprio(0)
 #else
+#define PP_SPLIT_PRIO_EARLY() ((void)0)
 #define PP_SPLIT_PRIO_BEGIN() ((void)0)
 #define PP_SPLIT_PRIO_END() ((void)0)
 #endif
 #ifndef PP_SETPRIO_ATTN
-#define PP_SETPRIO_ATTN 0
+#define PP_SETPRIO_ATTN 1      // pass level (profiles/r5_setprio_ab.txt): attention class 71.1 -> 68.7 ms per clip, bit-identical
 #endif
 #if PP_SETPRIO_ATTN
 #define PP_ATTN_PRIO_BEGIN() __builtin_amdgcn_s_setprio(1)

@@ -252,6 +252,7 @@ __global__ __launch_bounds__(TH * TW * 128 / WMT, WMT == 32 ? 4 : HALO_MIN_WAVES
         // tri-product step: fragments of both planes (kk 0 = hi / W_hi, kk 1 = lo / W_lo), then the three products with the
         // accumulators interleaved (an accumulator is revisited every 16 MFMAs; small terms first)
         f16x8 af[2][TM], bf[2][TN];
+        PP_SPLIT_PRIO_EARLY();
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
