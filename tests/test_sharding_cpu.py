@@ -262,3 +262,27 @@ def test_wavefront_order_of_the_streaming_schedule():
     assert all(pos[(q, s - 1)] < pos[(r, s)] for r, s in order if s for q in far(r, s - 1))
     with pytest.raises(RuntimeError):
         wavefront_order(2, 2, lambda r, s: [5])                                    # a source that never runs
+
+
+def test_generator_frame_walker_sees_through_the_no_grad_driver():
+    """sharding._generator_tensors (what the single-graph streaming capture keeps alive at every segment boundary): `sharded_clip_steps` is
+    decorated with @torch.no_grad(), which wraps the generator function in a DRIVER generator -- the tensors alive at a yield live in the
+    frames behind it (the body, and `_halo` through `yield from`).  Round 5's first capture walked only the driver's frame, kept nothing
+    alive, and the caching allocator recycled blocks another captured stream still read (wrong frames 16 of 16)."""
+    from propainter_amd.sharding import _generator_frames, _generator_tensors, sharded_clip_steps
+    clip, m = _inputs(50)
+    cfg = InferenceConfig(raft_iter=20, subvideo_length=20, neighbor_length=10, ref_stride=10)
+    g = sharded_clip_steps(MODELS, clip, m, m, cfg, torch.device("cpu"), 0, 2)
+    ex = next(g)
+    assert ex.tag == "gt_flows"
+    frames = _generator_frames(g)
+    assert len(frames) >= 3                                  # driver -> body -> _halo
+    names = set().union(*(set(f.f_locals) for f in frames))
+    assert {"frames", "flow_masks", "masks_dilated", "gt"} <= names
+    alive = _generator_tensors(g)
+    ids = {t.data_ptr() for t in alive}
+    body = next(f for f in frames if "flow_masks" in f.f_locals)
+    for key in ("frames", "flow_masks", "masks_dilated"):
+        assert body.f_locals[key].t.data_ptr() in ids, key   # Span objects are followed
+    assert all(t.data_ptr() in ids for t in ex.send.values())
+    g.close()
