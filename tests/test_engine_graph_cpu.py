@@ -283,3 +283,44 @@ def test_edge_clips_through_the_host_path(models, name, L, mk):
     d = np.abs(comp.astype(int) - ref.astype(int))
     assert comp.shape == ref.shape and (comp[masks == 0] == clip[masks == 0]).all()
     assert d.max() <= 1 and O.psnr(comp, ref) > 80.0, (O.psnr(comp, ref), d.max())
+
+
+def test_rolling_propagation_bookkeeping(models):
+    """_GenEngine.propagate_windows / ensure_propagated / release_window (round 5, ADVICE medium): windows of equal length are grouped
+    under the byte budget, a group is propagated when its first window asks for it, every window of the group then reads the same
+    tensor, and the tensor is dropped when the LAST window of the group has been released -- one group alive at a time instead of every
+    window's result until the end of the pass.  (The arithmetic itself is covered by test_batched_feature_propagation_graph.)"""
+    with emulated_device_ops():
+        eng = _engine(models[2])
+    calls = []
+    saved = eng.feature_propagation, eng.prop_batch_bytes
+    eng.feature_propagation = lambda x, *a, **k: (calls.append(tuple(x.shape)), torch.zeros_like(x))[1]
+    try:
+        clip = dict(enc=torch.zeros(40, 4, 4, 128), aux_b=torch.zeros(39, 4, 4, 8), aux_f=torch.zeros(39, 4, 4, 8), mk8=torch.zeros(40, 4, 4, 8),
+                    interpolation="bilinear")
+        eng.prop_batch_bytes = 3 * (5 * 4 * 4 * 128 * 4)                      # three 5-frame windows per group
+        windows = [(f, 5) for f in range(0, 35, 5)] + [(35, 4)]               # seven equal windows and a shorter last one
+        eng.propagate_windows(clip, windows)
+        assert [g[1] for g in clip["prop_groups"]] == [[0, 5, 10], [15, 20, 25]]      # the 7th window is a left-over single: per-window path
+        assert set(clip["prop_plan"]) == {(f, 5) for f in (0, 5, 10, 15, 20, 25)} and clip["prop"] == {} and not calls
+        eng.ensure_propagated(clip, 0, 5)
+        assert calls == [(5, 3, 4, 4, 128)] and set(clip["prop"]) == {(0, 5), (5, 5), (10, 5)}
+        assert clip["prop"][(0, 5)][0] is clip["prop"][(10, 5)][0] and [clip["prop"][(f, 5)][1] for f in (0, 5, 10)] == [0, 1, 2]
+        eng.ensure_propagated(clip, 5, 5)                                      # already there
+        eng.ensure_propagated(clip, 30, 5)                                     # not batched
+        eng.ensure_propagated(clip, 35, 4)
+        assert len(calls) == 1
+        eng.release_window(clip, 0, 5)
+        eng.release_window(clip, 5, 5)
+        assert set(clip["prop"]) == {(0, 5), (5, 5), (10, 5)}                # the group lives until its last window
+        eng.ensure_propagated(clip, 15, 5)                                     # the next group while the first is still alive (lane overlap)
+        assert len(calls) == 2 and len(clip["prop"]) == 6
+        eng.release_window(clip, 10, 5)
+        assert set(clip["prop"]) == {(15, 5), (20, 5), (25, 5)}
+        for f in (15, 20, 25):
+            eng.release_window(clip, f, 5)
+        assert clip["prop"] == {}
+        eng.ensure_propagated(clip, 0, 5)                                      # a finished group is not recomputed behind the pass's back
+        assert len(calls) == 2 and clip["prop"] == {}
+    finally:
+        eng.feature_propagation, eng.prop_batch_bytes = saved
