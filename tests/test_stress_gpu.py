@@ -134,30 +134,42 @@ def test_flow_completion_chunk_720p_stress(stress_models, stress_sds, dt):
             assert e_en.mean() <= 2e-2 * rng, (tag, e_en.mean())
 
 
+_gen_stress = {}
+
+
+def _gen_stress_case(stress_sds):
+    """inputs + oracle output of the stress generator window (computed once for both precisions)"""
+    if not _gen_stress:
+        H, W, tt, lt = 720, 1280, 6, 3
+        gq = torch.Generator().manual_seed(4200)
+        fr = torch.rand(1, tt, 3, H, W, generator=gq) * 2 - 1
+        mk = _stress_mask_t(tt, H, W)
+        mu = mk.clone()
+        mu[..., : H // 3, :] = 0                                           # image propagation filled the top third
+        base = torch.zeros(1, lt - 1, 2, H, W)
+        base[:, :, 0, : H // 2], base[:, :, 0, H // 2:] = 48.0, -48.0
+        gfl = (base + torch.randn(1, lt - 1, 2, H, W, generator=gq) * 4, -base + torch.randn(1, lt - 1, 2, H, W, generator=gq) * 4)
+        _threads()
+        with torch.no_grad():
+            ref = O.generator_forward(stress_sds["gen"], fr * (1 - mk), gfl, mk, mu, lt)
+        _gen_stress.update(fr=fr, mk=mk, mu=mu, gfl=gfl, lt=lt, ref=ref)
+    return _gen_stress
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.float16], ids=["f32", "f16"])
 def test_generator_window_720p_stress(stress_models, stress_sds, dt):
     """Stage D at 720x1280 on the stress recipe: EVERY attention window masked (all 144 windows take the full key set of every layer: own +
     rolled + pooled keys of the dilation phase), offset heads at full size on flows of +-12 px at 1/4 resolution (deformable corners far
     from the mean-shifted patch), same tolerances as the tame window."""
     from propainter_amd import hip
-    H, W, tt, lt = 720, 1280, 6, 3
-    gq = torch.Generator().manual_seed(4200)
-    fr = torch.rand(1, tt, 3, H, W, generator=gq) * 2 - 1
-    mk = _stress_mask_t(tt, H, W)
-    mu = mk.clone()
-    mu[..., : H // 3, :] = 0                                           # image propagation filled the top third
-    base = torch.zeros(1, lt - 1, 2, H, W)
-    base[:, :, 0, : H // 2], base[:, :, 0, H // 2:] = 48.0, -48.0
-    gfl = (base + torch.randn(1, lt - 1, 2, H, W, generator=gq) * 4, -base + torch.randn(1, lt - 1, 2, H, W, generator=gq) * 4)
-    _threads()
-    with torch.no_grad():
-        ref = O.generator_forward(stress_sds["gen"], fr * (1 - mk), gfl, mk, mu, lt)
+    c = _gen_stress_case(stress_sds)
+    fr, mk, mu, gfl, lt, ref = c["fr"], c["mk"], c["mu"], c["gfl"], c["lt"], c["ref"]
     with hip.FallbackStats(torch.device("cuda")) as fs:
         out = stress_models[2]((fr * (1 - mk)).cuda().to(dt), (gfl[0].cuda().to(dt), gfl[1].cuda().to(dt)), mk.cuda().to(dt), mu.cuda().to(dt), lt)
         st = fs.read()
     name = "f32" if dt == torch.float32 else "f16"
     print(f"STRESS gen720_{name}: deformable samples outside the staged patch {st['dcn_out_of_patch_frac']}")
-    assert out.shape == ref.shape == (1, lt, 3, H, W)
+    assert out.shape == ref.shape == (1, lt, 3, 720, 1280)
     rel_check(f"gen720_stress_{name}", out, ref, RTOL[dt]["gen"])
 
 
