@@ -2,6 +2,7 @@
 
     python -m oracle.make_golden_synth c2        # BASELINE config 2: 432x240, 80 frames, tame recipe        (~7 CPU-min on 8 cores)
     python -m oracle.make_golden_synth c3w       # 720x1280, 18 frames: windows WITH reference frames, tame  (~12 CPU-min)
+    python -m oracle.make_golden_synth c3        # BASELINE config 3: 720x1280, 80 frames, 16 windows, reference frames +-40: the TIMED clip (~1 CPU-hour)
     python -m oracle.make_golden_synth stress    # 720x1280, 6 frames, STRESS recipe: full-size flow / offset heads, two layers moving in
                                                  # opposite directions at 8-48 px/frame + occluder, border + lattice mask (all windows masked)
 
@@ -25,6 +26,7 @@ CASES = {
     # name: (file, L, H, W, recipe)
     "c2": ("synth_c2_432x240x80.npz", 80, 240, 432, "tame"),
     "c3w": ("synth_c3_720x1280x18.npz", 18, 720, 1280, "tame"),
+    "c3": ("synth_c3_720x1280x80.npz", 80, 720, 1280, "tame"),      # BASELINE config 3 itself: the clip bench.py times on rank 0
     "stress": ("synth_stress_720x1280x6.npz", 6, 720, 1280, "stress"),
     "stress_small": ("synth_stress_240x432x12.npz", 12, 240, 432, "stress"),
 }

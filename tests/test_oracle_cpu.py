@@ -1,5 +1,7 @@
 """Pins the oracle (CPU restatement) against known answers, the committed golden vectors produced by the REAL
 reference, and — where /root/reference exists — the real reference itself."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -92,3 +94,57 @@ def test_oracle_matches_real_reference(sds):
         y = gen(fr * (1 - mk), fl, mk, mk, lt)
         y2 = O.generator_forward(sds["gen"], fr * (1 - mk), fl, mk, mk, lt)
     assert (y - y2).abs().max() < 2e-4
+
+
+@pytest.mark.skipif(not reference_available(), reason="the reference tree is absent (GPU box)")
+def test_driver_restatement_equals_the_reference_script_run_as_main(sds, tmp_path):
+    """The reference's OWN driver, /root/reference/inference_propainter.py, executed unmodified as ``__main__`` on a frame folder + mask
+    folder with seeded checkpoint files (oracle/run_reference_driver.py: stub cv2 / imageio / torchvision modules only), against
+      (a) ``O.inpaint_video`` -- the restated DRIVER -- over the REFERENCE's modules: byte for byte, incl. completed flows / updated frames;
+      (b) ``O.inpaint_video`` over the restated stages: what fp32 reassociation leaves (the uint8 truncation of :440,448 flips bytes
+          whose value sits on an integer; measured 5 bytes of 737 280 off by one; the oracle at another thread count is as far from itself);
+      (c) the committed fixture tests/golden/e2e_128x192.npz (generated from the script by oracle/make_golden.py at another thread count);
+      (d) the product's host-side mask pre-processing and preview (video_io.read_masks / masked_preview vs read_mask :77-115, :247-258).
+    --subvideo_length 6 on 10 frames takes every chunked branch (:341-368, :373-398) and the ref_num branch of get_ref_index."""
+    from oracle.run_reference_driver import reference_main_on_clip, reference_modules
+    from propainter_amd import video_io
+    from propainter_amd.synthetic import synthetic_clip, synthetic_mask
+    g = load_golden("e2e_128x192.npz")
+    L, H, W = 10, 128, 192
+    clip = synthetic_clip(L, H, W, seed=7)
+    assert np.array_equal(clip, g["frames_u8"])
+    kw = dict(raft_iter=int(g["raft_iter"]), subvideo_length=int(g["subvideo_length"]), neighbor_length=int(g["neighbor_length"]),
+              ref_stride=int(g["ref_stride"]))
+    work = str(tmp_path / "refmain")
+    r = reference_main_on_clip(clip, synthetic_mask(H, W).astype(np.uint8), sds, [a for k, v in kw.items() for a in ("--" + k, v)],
+                               threads=4, keep=work)
+    assert tuple(r["size"]) == (W, H) and tuple(r["out_size"]) == (W, H) and int(r["fps"]) == 24
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(4)                      # the same reduction trees as the child process
+    try:
+        with torch.no_grad():
+            comp_a, st_a = O.inpaint_video(sds, clip, r["flow_masks"], r["masks_dilated"], return_stages=True, modules=reference_modules(sds), **kw)
+            comp_b, st_b = O.inpaint_video(sds, clip, r["flow_masks"], r["masks_dilated"], return_stages=True, **kw)
+    finally:
+        torch.set_num_threads(nthreads)
+    # (a) the driver restatement, exactly
+    assert np.array_equal(np.stack(comp_a), r["comp"])
+    assert np.array_equal(st_a["pred_flows"][0][0].numpy(), r["pred_f"]) and np.array_equal(st_a["pred_flows"][1][0].numpy(), r["pred_b"])
+    assert np.array_equal(st_a["updated_frames"][0].numpy(), r["upd_frames"]) and np.array_equal(st_a["updated_masks"][0].numpy(), r["upd_masks"])
+    # (b) the restated stages under the restated driver
+    d = np.abs(np.stack(comp_b).astype(np.int16) - r["comp"].astype(np.int16))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-4, (int(d.max()), float((d > 0).mean()))
+    assert np.abs(st_b["pred_flows"][0][0].numpy() - r["pred_f"]).max() < 1e-4
+    assert np.array_equal(st_b["updated_masks"][0].numpy(), r["upd_masks"])
+    # (c) the committed fixture
+    dg = np.abs(g["comp"].astype(np.int16) - r["comp"].astype(np.int16))
+    assert dg.max() <= 1 and (dg > 0).mean() < 1e-4
+    assert np.array_equal(g["masks_u8"], r["masks_dilated"]) and np.array_equal(g["upd_masks"][0], r["upd_masks"].astype(np.uint8))
+    # (d) host-side pre-processing of the product
+    fm, md = video_io.read_masks(os.path.join(work, "clip_mask"), L, (W, H), flow_mask_dilates=4, mask_dilates=4)
+    assert np.array_equal(np.stack(fm), r["flow_masks"]) and np.array_equal(np.stack(md), r["masks_dilated"])
+    frames, fps, size, name = video_io.read_frames(os.path.join(work, "clip"))
+    assert np.array_equal(np.stack([np.array(f) for f in frames]), clip) and fps is None and size == (W, H) and name == "clip"
+    assert np.array_equal(np.stack(video_io.masked_preview(list(clip), md)), r["masked_in"])
+    print(f"REFERENCE_MAIN: driver restatement over the reference's modules == the script byte for byte; restated stages: "
+          f"{int((d > 0).sum())} of {d.size} bytes off by one; committed fixture: {int((dg > 0).sum())} bytes off by one")
