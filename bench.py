@@ -534,15 +534,28 @@ def main(argv=None, runtime=None):
                 sys.stderr.write(f"[bench] rank {rank}: {have / 1e9:.1f} GB available for the shard graphs, ~{need / 1e9:.1f} GB needed\n")
             sys.stderr.write(f"[bench] rank {rank}: the ranks voted against the sharded hipGraph capture (memory); eager launches\n")
         else:
+            # the static inputs are allocated before the lock-step capture starts: a rank that cannot (out of memory) must not die alone
+            # and leave its peers in the first vote's all-reduce until the process-group timeout -- its failure is a 0 vote like any other
             try:
                 sgraph = ShardedClipGraph(models, L, H, W, cfg, dev, rank, world)
                 sgraph.load(clip_pin, masks_pin, masks_pin)
-                sgraph.capture(dist_exchanger(dev, None, None), vote=vote)
-            except CaptureAborted as e:
-                sys.stderr.write(f"[bench] sharded hipGraph capture abandoned on rank {rank} ({e}); eager launches\n")
+                built, why = True, None
+            except Exception as e:      # noqa: BLE001 -- whatever it is, the ranks must learn of it together
+                built, why, sgraph = False, f"{type(e).__name__}: {e}", None
+            if not vote(built):
+                sys.stderr.write(f"[bench] rank {rank}: the ranks voted against the sharded hipGraph capture "
+                                 f"({why or 'a peer could not build its static inputs'}); eager launches\n")
                 sgraph = None
                 rt.sync()
                 rt.empty_cache()
+            else:
+                try:
+                    sgraph.capture(dist_exchanger(dev, None, None), vote=vote)
+                except CaptureAborted as e:
+                    sys.stderr.write(f"[bench] sharded hipGraph capture abandoned on rank {rank} ({e}); eager launches\n")
+                    sgraph = None
+                    rt.sync()
+                    rt.empty_cache()
         capture_s = time.perf_counter() - t_c
     if not args.eager and not use_ranks and rt.graphs:      # one clip per rank: the whole pass as ONE hipGraph
         from propainter_amd.pipeline import ClipGraph

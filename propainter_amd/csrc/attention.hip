@@ -571,7 +571,7 @@ extern "C" int pp_window_tables(int Hp, int Wp, int wh, int ww, int32_t* own, in
 extern "C" int pp_window_mask(const void* mask, float* wmask, int B, int Lt, int Hp, int Wp, int wh, int ww, int dtype,
                               void* stream) {
   PP_REQUIRE(mask && wmask && B > 0 && Lt > 0 && wh > 0 && ww > 0 && Hp % wh == 0 && Wp % ww == 0, PP_ERR_ARG,
-             "pp_window_mask: bad arguments (window %d x %d: at most 64 positions)", wh, ww);
+             "pp_window_mask: bad arguments (window %d x %d: any window size)", wh, ww);
   PP_REQUIRE(dtype == PP_F32 || dtype == PP_F16, PP_ERR_DTYPE, "pp_window_mask: dtype %d", dtype);
   const int n = B * (Hp / wh) * (Wp / ww);
   if (dtype == PP_F16)

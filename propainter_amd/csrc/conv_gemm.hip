@@ -584,11 +584,11 @@ extern "C" int pp_conv2d(const pp_conv_args_t* a, void* stream) {
     // split == 2: TRI-PRODUCT K format (per tap 4 hi + 4 lo chunks of 32 channels, weights [W_hi | W_lo]): the halo-tile kernel only;
     // split == 1: every block walked three times by a plain K loop: the LDS-DMA (v2) kernel
     // ... or, outside the halo family (1x1, strided, batched GEMM, sources that are no multiples of 32 channels), the v2 kernel's tri step
-    const int v2cfg = (a->impl >= 10 && a->impl < 70) || (a->impl > 110 && (a->impl < 116 || a->impl > 118)) ? a->impl : 0;
+    const int v2cfg = (a->impl >= 10 && a->impl < 70) || (a->impl > 110 && (a->impl < 116 || a->impl > 118)) ? a->impl : 0;      // (82 / 83: halo8, below)
     int rc = -1000;
     if (a->split == 2 && (a->impl == 0 || a->impl == 110)) rc = conv_head_dispatch(p, st, a->impl == 110);   // 3x3 heads with <= 4 couts (opt-in)
     PP_REQUIRE(a->impl != 110 || rc != -1000, PP_ERR_ARG, "pp_conv2d: impl 110 (streaming head kernel) not available for this layer");
-    if (rc == -1000 && a->split == 2 && v2cfg == 0) rc = conv_v3s_dispatch(p, a->impl == 71 || a->impl == 72 ? a->impl : 0, st);
+    if (rc == -1000 && a->split == 2 && v2cfg == 0) rc = conv_v3s_dispatch(p, a->impl == 71 || a->impl == 72 || a->impl == 82 || a->impl == 83 ? a->impl : 0, st);
     if (rc == -1000) rc = conv_v2s_dispatch(p, v2cfg, st);
     PP_REQUIRE(rc != -1000, PP_ERR_ARG, "pp_conv2d: no split-plane kernel for this layer (split %d, kchunks %d, %dx%d taps, impl %d)", a->split,
                a->kchunks, a->tap_h, a->tap_w, a->impl);
@@ -609,7 +609,7 @@ extern "C" int pp_conv2d(const pp_conv_args_t* a, void* stream) {
     if (rc != -1000) return rc;
     PP_REQUIRE(a->impl == 0, PP_ERR_ARG, "pp_conv2d: impl 110 (streaming head kernel) not available for this layer");
   }
-  if (a->dtype == PP_F16 && !deform && (a->impl == 0 || (a->impl >= 70 && a->impl < 80) || a->impl == 109)) {
+  if (a->dtype == PP_F16 && !deform && (a->impl == 0 || (a->impl >= 70 && a->impl < 80) || a->impl == 82 || a->impl == 83 || a->impl == 109)) {
     // halo-tile kernel family (stride-1 "same" 3x3 / 1x5 / 5x1 windows over 64-channel-multiple sources)
     const int rc = conv_v3_dispatch(p, a->impl, st);
     if (rc != -1000) return rc;

@@ -20,7 +20,7 @@
 //        (row & 7) is conflict-free at every alignment (exhaustive check: tools/lds_swizzle_check.py).  The weight tile
 //        keeps ((row >> 1) & 7): its fragments start at multiples of 16 rows.
 //   4 waves (2 x 2), wave tile 64 px x BN/2 couts, v_mfma_f32_16x16x32_f16, fp32 accumulate.  Epilogue as in v2.
-#include "conv_halo.h"
+#include "conv_halo8.h"
 #include <stdlib.h>
 
 namespace pp {
@@ -48,6 +48,30 @@ template <int TH, int TW, int KH, int KW>
 static int launch_tiny(const ConvParams& p, hipStream_t stream) {     // 16-cout tiles (flow head, RGB decoder)
   return halo_shared_weights() ? launch_v3<TH, TW, KH, KW, 16>(p, stream) : launch_v3<TH, TW, KH, KW, 16, false, 0, 64, false, true>(p, stream);
 }
+
+// Ping-pong form (conv_halo8.h): 256-pixel tiles, eight waves in two groups in opposite phases, one block per CU.
+// PP_HALO8=0 switches it off (A/B); cfg 82 / 83 force it with 128- / 64-cout tiles, cfg 70..72 force the 128-pixel kernel.
+static bool halo8_enabled() {
+  static const bool v = !(getenv("PP_HALO8") != nullptr && getenv("PP_HALO8")[0] == '0');
+  return v;
+}
+template <int BN, bool SPLIT>
+static int launch_h8_taps(const ConvParams& p, int kh, int kw, hipStream_t stream) {
+  if (kh == 3 && kw == 3) return launch_h8<16, 16, 3, 3, BN, SPLIT>(p, stream);
+  if (kh == 1 && kw == 5) return launch_h8<16, 16, 1, 5, BN, SPLIT>(p, stream);
+  if (kh == 5 && kw == 1) return launch_h8<16, 16, 5, 1, BN, SPLIT>(p, stream);
+  return -1000;
+}
+// enough 256-pixel tiles to give every CU a block, and images that fill 16 x 16 tiles reasonably
+static bool halo8_fits(const ConvParams& p, int bn) {
+  const long long blk = (long long)p.N * ((p.H + 15) / 16) * ((p.W + 15) / 16) * ((p.cout_g + bn - 1) / bn);
+  return p.H >= 16 && p.W >= 16 && blk >= 256;
+}
+int conv_h8_dispatch(const ConvParams& p, int bn, bool split, hipStream_t stream) {
+  if (split) return bn == 128 ? launch_h8_taps<128, true>(p, p.tap_h, p.tap_w, stream) : launch_h8_taps<64, true>(p, p.tap_h, p.tap_w, stream);
+  return bn == 128 ? launch_h8_taps<128, false>(p, p.tap_h, p.tap_w, stream) : launch_h8_taps<64, false>(p, p.tap_h, p.tap_w, stream);
+}
+bool conv_h8_auto(const ConvParams& p, int bn) { return halo8_enabled() && bn == 128 && halo8_fits(p, bn); }
 
 // Returns -1000 when the shape is outside the halo-tile family (caller falls back to v2).
 // cfg: 0 = auto, 70 = force (BN by cout), 71 = BN 128, 72 = BN 64.
@@ -94,8 +118,10 @@ int conv_v3_dispatch(const ConvParams& p, int cfg, hipStream_t stream) {
     ConvParams q = p;
     q.preadd = p.residual; q.preadd_cstride = p.res_cstride; q.preadd_choff = p.res_choff;
     q.residual = nullptr; q.act = p.act2; q.act_param = 0.f; q.act2 = PP_ACT_NONE;
+    if (cfg == 82 || cfg == 83 || (cfg == 0 && conv_h8_auto(q, n64 ? 64 : 128))) return conv_h8_dispatch(q, cfg == 83 || (cfg == 0 && n64) ? 64 : 128, false, stream);
     return launch_plain(q, kh, kw, n64, stream);
   }
+  if (cfg == 82 || cfg == 83 || (cfg == 0 && conv_h8_auto(p, n64 ? 64 : 128))) return conv_h8_dispatch(p, cfg == 83 || (cfg == 0 && n64) ? 64 : 128, false, stream);
   return launch_plain(p, kh, kw, n64, stream);
 }
 

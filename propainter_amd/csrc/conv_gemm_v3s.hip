@@ -43,6 +43,7 @@ int conv_v3s_dispatch(const ConvParams& p, int cfg, hipStream_t stream) {
     q.preadd = p.residual; q.preadd_cstride = p.res_cstride; q.preadd_choff = p.res_choff; q.preadd_lo = p.res_lo;
     q.residual = nullptr; q.act = p.act2; q.act_param = 0.f; q.act2 = PP_ACT_NONE;
   }
+  if (bn != 16 && (cfg == 82 || cfg == 83 || (cfg == 0 && conv_h8_auto(q, bn)))) return conv_h8_dispatch(q, cfg == 83 ? 64 : (cfg == 82 ? 128 : bn), true, stream);
   static const bool shared_w = !(getenv("PP_HALO_PRIVATE_WEIGHTS") != nullptr && getenv("PP_HALO_PRIVATE_WEIGHTS")[0] == '1');
   if (kh == 3) return launch_v3s<3, 3>(q, bn, shared_w, stream);
   if (kh == 1) return launch_v3s<1, 5>(q, bn, shared_w, stream);

@@ -63,6 +63,9 @@ __device__ __forceinline__ float act_late(float v, int act, float slope) {
 int conv_v2_dispatch(const ConvParams& p, int cfg, hipStream_t stream);
 // conv_gemm_v3.hip (halo tiles); returns -1000 when the shape is outside that family (caller falls back to v2)
 int conv_v3_dispatch(const ConvParams& p, int cfg, hipStream_t stream);
+// conv_gemm_v3.hip, ping-pong form (conv_halo8.h: 256-pixel tiles, 8 waves): explicit launch / the automatic choice
+int conv_h8_dispatch(const ConvParams& p, int bn, bool split, hipStream_t stream);
+bool conv_h8_auto(const ConvParams& p, int bn);
 // conv_gemm_v3s.hip / conv_gemm_v2s.hip: the same kernels with split-plane epilogues (p.split); -1000 outside the family
 int conv_v3s_dispatch(const ConvParams& p, int cfg, hipStream_t stream);
 int conv_v2s_dispatch(const ConvParams& p, int cfg, hipStream_t stream);

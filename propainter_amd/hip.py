@@ -11,6 +11,7 @@ import numpy as np
 import torch
 
 from . import build as _build
+from . import hazard as _hazard
 
 PP_F32, PP_F16, PP_F16S = 0, 1, 2      # PP_F16S: split-plane fp16 pair (value = hi + lo, lo plane at cstride / 2 in the aux ops)
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID, ACT_TANH, ACT_GELU = 0, 1, 2, 3, 4, 5
@@ -83,6 +84,8 @@ def loaded_library_path():
 
 
 def _check(rc, what):
+    if _hazard.active() is not None:          # capture-time hazard checker (propainter_amd/hazard.py): this launch's pointers are complete
+        _hazard.active().flush(what)
     if rc != 0:
         msg = lib().pp_last_error_string().decode(errors="replace")
         raise RuntimeError(f"{what} failed (code {rc}): {msg}")
@@ -155,7 +158,12 @@ class FallbackStats:
         units, sub, single, samples, outside = v[0], v[1], v[2], v[4], v[5]
         return {"corr_tile_levels": units, "corr_subtile_fallbacks": sub, "corr_single_pixel_fallbacks": single,
                 "corr_subtile_fallback_frac": sub / units if units else None,
+                # a (tile, level) unit that falls back splits into 2 sub-tiles of 16 pixels in the split-plane kernel and into 4 in the
+                # fp16 kernel: both add to the same counters, so the fraction is given per fallback UNIT (exact for either kernel), and per
+                # sub-tile under the split-plane kernel's count (the timed default; half that under the fp16 kernel)
+                "corr_single_pixel_fallbacks_per_fallback_unit": single / sub if sub else (0.0 if units else None),
                 "corr_single_pixel_fallback_frac_of_subtiles": single / (2 * sub) if sub else (0.0 if units else None),
+                "corr_single_pixel_fallback_frac_of_subtiles_note": "2 sub-tiles per unit (corr_otf_split_kernel); corr_otf_kernel (f16) has 4: halve it there",
                 "dcn_samples": samples, "dcn_out_of_patch_samples": outside,
                 "dcn_out_of_patch_frac": outside / samples if samples else None}
 
@@ -279,12 +287,19 @@ def on_input_device(fn):
     return wrapper
 
 
-def _p(t):
+def _p(t, write=False):
     if t is None:
         return None
     if not t.is_cuda:
         raise RuntimeError("libpropainter_hip kernels need GPU tensors: there is no CPU fallback in the product path")
+    if _hazard.active() is not None:
+        _hazard.active().note(t, write)
     return C.c_void_p(t.data_ptr())
+
+
+def _pw(t):
+    """pointer of a tensor the launch WRITES (same as _p; the hazard checker tells reads from writes by it)"""
+    return _p(t, True)
 
 
 def _i(v):
@@ -337,12 +352,32 @@ def window_tables(Hp, Wp, wh=5, ww=9):
 
 # ----------------------------------------------------------------------------------------------
 # device ops
+def _note_conv(rec, a):
+    """hazard checker: the byte extents a pp_conv2d launch reads / writes, from the raw pointers and strides of its ConvArgs"""
+    esz = 2 if a.dtype == PP_F16 else 4
+    osz = 2 if a.out_dtype == PP_F16 else 4
+    npix_in, npix_out = a.N * a.H * a.W, a.N * a.OH * a.OW
+    for i in range(a.nsrc):
+        if a.src[i].ptr:
+            rec.note_range(a.src[i].ptr, npix_in * a.src[i].cstride * esz, False, True)
+    for ptr, cs in ((a.residual, a.res_cstride), (a.preadd, a.preadd_cstride), (a.fuse_a, a.fuse_a_cstride), (a.fuse_b, a.fuse_b_cstride),
+                    (a.dcn_offmask, a.dcn_cstride)):
+        if ptr:
+            rec.note_range(ptr, npix_out * cs * esz, False, True)
+    whole = a.out_choff == 0 and a.out_cstride in (a.cout_g * a.groups, a.cout_pad * a.groups, 2 * a.cout_pad * a.groups)
+    rec.note_range(a.out, npix_out * a.out_cstride * osz, True, not whole)
+    if a.out2:
+        rec.note_range(a.out2, npix_out * a.out2_cstride * osz, True, True)
+
+
 # ----------------------------------------------------------------------------------------------
 def conv2d_raw(args: ConvArgs, cin_read=None, on=None, split_k=0):
     """cin_read: channels read per input pixel (for the profiler's byte model; defaults to K per group x groups);
     on: a tensor of the launch (names the device / stream); split_k: the K table is a split-plane expansion (profiler accounting)."""
     if _stats is not None and args.dcn_offmask:
         args.dcn_stats = _stats.buf.data_ptr() + 8 * 4
+    if _hazard.active() is not None:
+        _note_conv(_hazard.active(), args)
     if _profiler is None:
         _check(lib().pp_conv2d(C.byref(args), _stream(on)), "pp_conv2d")
         return
@@ -386,7 +421,7 @@ def flow_warp(x, flow, out=None, mode="bilinear", x_choff=0, C_=None, fl_choff=0
     if out is None:
         out = torch.empty((N, H, W, C_), dtype=x.dtype, device=x.device)
     assert x.is_contiguous() and flow.is_contiguous() and out.is_contiguous() and flow.dtype == x.dtype
-    timed("flow_warp", 0, _nbytes(out) * 2 + _nbytes(flow), lambda: _check(lib().pp_flow_warp(_p(x), _i(Cx), _i(x_choff), _p(flow), _i(flow.shape[-1]), _i(fl_choff), _p(out),
+    timed("flow_warp", 0, _nbytes(out) * 2 + _nbytes(flow), lambda: _check(lib().pp_flow_warp(_p(x), _i(Cx), _i(x_choff), _p(flow), _i(flow.shape[-1]), _i(fl_choff), _pw(out),
                               _i(out.shape[-1]), _i(out_choff), _i(N), _i(H), _i(W), _i(C_),
                               _i(1 if mode == "nearest" else 0), _i(dtype_code(x.dtype)), _stream(x)),
            "pp_flow_warp"))
@@ -399,7 +434,7 @@ def fb_check(flow_fw, flow_bw, out=None, out_choff=0):
     if out is None:
         out = torch.empty((N, H, W, 1), dtype=flow_fw.dtype, device=flow_fw.device)
     assert flow_fw.is_contiguous() and flow_bw.is_contiguous() and out.is_contiguous()
-    timed("fb_check", 0, _nbytes(flow_fw) * 3, lambda: _check(lib().pp_fb_check(_p(flow_fw), _i(flow_fw.shape[-1]), _p(flow_bw), _i(flow_bw.shape[-1]), _p(out),
+    timed("fb_check", 0, _nbytes(flow_fw) * 3, lambda: _check(lib().pp_fb_check(_p(flow_fw), _i(flow_fw.shape[-1]), _p(flow_bw), _i(flow_bw.shape[-1]), _pw(out),
                              _i(out.shape[-1]), _i(out_choff), _i(N), _i(H), _i(W), _i(dtype_code(flow_fw.dtype)),
                              _stream(flow_fw)),
            "pp_fb_check"))
@@ -412,7 +447,7 @@ def img_prop_step(x_prop, m_prop, x_cur, m_cur, flow_prop, flow_check, x_out, m_
     for t in (x_prop, m_prop, x_cur, m_cur, flow_prop, flow_check, x_out, m_out):
         assert t.is_contiguous() and t.dtype == x_cur.dtype
     timed("img_prop_step", 0, _nbytes(x_prop) + _nbytes(m_prop) + _nbytes(x_cur) + _nbytes(m_cur) + _nbytes(flow_prop) + _nbytes(flow_check) + _nbytes(x_out) + _nbytes(m_out), lambda: _check(lib().pp_img_prop_step(_p(x_prop), _p(m_prop), _p(x_cur), _p(m_cur), _p(flow_prop), _p(flow_check),
-                                  _p(x_out), _p(m_out), _i(N), _i(Cc), _i(H), _i(W),
+                                  _pw(x_out), _pw(m_out), _i(N), _i(Cc), _i(H), _i(W),
                                   _i(1 if mode == "nearest" else 0), _i(dtype_code(x_cur.dtype)), _stream(x_cur)),
            "pp_img_prop_step"))
 
@@ -422,7 +457,7 @@ def binary_dilate(mask_u8, iterations):
     N, H, W = mask_u8.shape
     assert mask_u8.dtype == torch.uint8 and mask_u8.is_contiguous()
     out = torch.empty_like(mask_u8)
-    timed("binary_dilate", 0, 2 * mask_u8.numel(), lambda: _check(lib().pp_binary_dilate(_p(mask_u8), _p(out), _i(N), _i(H), _i(W),
+    timed("binary_dilate", 0, 2 * mask_u8.numel(), lambda: _check(lib().pp_binary_dilate(_p(mask_u8), _pw(out), _i(N), _i(H), _i(W),
                                                                                        _i(iterations), _stream(mask_u8)), "pp_binary_dilate"))
     return out
 
@@ -437,7 +472,7 @@ def resize_bilinear_u8(x_u8, size):
         return x_u8
     out = torch.empty((N, OH, OW, Cc), dtype=torch.uint8, device=x_u8.device)
     timed("resize_bilinear_u8", 0, x_u8.numel() + out.numel(),
-          lambda: _check(lib().pp_resize_bilinear_u8(_p(x_u8), _p(out), _i(N), _i(H), _i(W), _i(Cc), _i(OH), _i(OW), _stream(x_u8)),
+          lambda: _check(lib().pp_resize_bilinear_u8(_p(x_u8), _pw(out), _i(N), _i(H), _i(W), _i(Cc), _i(OH), _i(OW), _stream(x_u8)),
                          "pp_resize_bilinear_u8"))
     return out
 
@@ -451,14 +486,14 @@ def composite_window(pred, mask_u8, ori_u8, comp_u8, frame_ids, blend_flags):
     ids = (C.c_int32 * n)(*[int(i) for i in frame_ids])
     bits = sum(1 << i for i, b in enumerate(blend_flags) if b)
     timed("composite_window", 0, _nbytes(pred) + n * H * W * 10,
-          lambda: _check(lib().pp_composite_window(_p(pred), _i(dtype_code(pred.dtype)), _p(mask_u8), _i(1), _p(ori_u8), _p(comp_u8), ids, C.c_uint32(bits),
+          lambda: _check(lib().pp_composite_window(_p(pred), _i(dtype_code(pred.dtype)), _p(mask_u8), _i(1), _p(ori_u8), _pw(comp_u8), ids, C.c_uint32(bits),
                                                    _i(n), _i(H), _i(W), _stream(pred)), "pp_composite_window"))
     return comp_u8
 
 
 def corr_avgpool(x, M, H, W):
     out = torch.empty((M, H // 2, W // 2), dtype=torch.float32, device=x.device)
-    timed("corr_avgpool", 0, _nbytes(out) * 5, lambda: _check(lib().pp_corr_avgpool(_p(x), _p(out), C.c_int64(M), _i(H), _i(W), _stream(x)),
+    timed("corr_avgpool", 0, _nbytes(out) * 5, lambda: _check(lib().pp_corr_avgpool(_p(x), _pw(out), C.c_int64(M), _i(H), _i(W), _stream(x)),
            "pp_corr_avgpool"))
     return out
 
@@ -468,7 +503,7 @@ def corr_lookup(levels, coords, out, split=False):
     B, h, w, _ = coords.shape
     assert coords.dtype == torch.float32 and coords.is_contiguous() and out.is_contiguous()
     cs = out.shape[-1]
-    timed("corr_lookup", 0, B * h * w * 4 * 100 * 4 + _nbytes(out), lambda: _check(lib().pp_corr_lookup(_p(levels[0]), _p(levels[1]), _p(levels[2]), _p(levels[3]), _p(coords), _p(out),
+    timed("corr_lookup", 0, B * h * w * 4 * 100 * 4 + _nbytes(out), lambda: _check(lib().pp_corr_lookup(_p(levels[0]), _p(levels[1]), _p(levels[2]), _p(levels[3]), _p(coords), _pw(out),
                                 _i(cs), _i(cs // 2 if split else cs), _i(B), _i(h), _i(w), _i(PP_F16S if split else dtype_code(out.dtype)),
                                 _stream(coords)),
            "pp_corr_lookup"))
@@ -508,7 +543,7 @@ def corr_lookup_otf(f1, f2_levels, coords, out):
     npix = P * h * w
     timed("corr_lookup_otf", 2.0 * 256 * 400 * npix, _nbytes(f1) + sum(_nbytes(t) for t in f2_levels) + _nbytes(coords) + _nbytes(out),
           lambda: _check(lib().pp_corr_lookup_otf_stats(_p(f1), _p(f2_levels[0]), _p(f2_levels[1]), _p(f2_levels[2]), _p(f2_levels[3]),
-                                                        _p(coords), _p(out), _i(out.shape[-1]), _i(out.shape[-1]), _i(P), _i(h), _i(w),
+                                                        _p(coords), _pw(out), _i(out.shape[-1]), _i(out.shape[-1]), _i(P), _i(h), _i(w),
                                                         _stats_ptr(0), _stream(f1)), "pp_corr_lookup_otf"))
     return out
 
@@ -528,7 +563,7 @@ def corr_lookup_otf_split(f1, f2_levels, coords, out):
     # FLOPs: ~400 positions per pixel x 256 channels (the algorithmic dot products of the 4 x (10 x 10) neighbourhoods), three fp16 products each
     timed("corr_lookup_otf_split", 2.0 * 256 * 400 * npix, _nbytes(f1) + sum(_nbytes(t) for t in f2_levels) + _nbytes(coords) + _nbytes(out),
           lambda: _check(lib().pp_corr_lookup_otf_split_stats(_p(f1), _p(f2_levels[0]), _p(f2_levels[1]), _p(f2_levels[2]), _p(f2_levels[3]),
-                                                              _p(coords), _p(out), _i(out.shape[-1]), _i(P), _i(h), _i(w), _stats_ptr(0),
+                                                              _p(coords), _pw(out), _i(out.shape[-1]), _i(P), _i(h), _i(w), _stats_ptr(0),
                                                               _stream(f1)),
                          "pp_corr_lookup_otf_split"))
     return out
@@ -542,7 +577,7 @@ def raft_flow_taps(coords1, coords0, rows, flow_out=None, flow_choff=0, split=Fa
     assert rows.shape == (P, h, w, 32 if split else 16) and rows.is_contiguous() and (flow_out is None or (flow_out.is_contiguous() and flow_out.dtype == rows.dtype))
     assert not split or rows.dtype == torch.float16
     timed("raft_flow_taps", 0, 2 * _nbytes(coords1) + _nbytes(rows),
-          lambda: _check(lib().pp_raft_flow_taps(_p(coords1), _p(coords0), _p(rows), _p(flow_out), _i(flow_out.shape[-1] if flow_out is not None else 0),
+          lambda: _check(lib().pp_raft_flow_taps(_p(coords1), _p(coords0), _p(rows), _pw(flow_out), _i(flow_out.shape[-1] if flow_out is not None else 0),
                                                  _i(flow_choff), _i(P), _i(h), _i(w), _i(PP_F16S if split else dtype_code(rows.dtype)), _stream(coords1)),
                          "pp_raft_flow_taps"))
     return rows
@@ -553,7 +588,7 @@ def convex_upsample(flow, mask):
     B, h, w, _ = flow.shape
     out = torch.empty((B, 2, 8 * h, 8 * w), dtype=torch.float32, device=flow.device)
     assert flow.dtype == torch.float32 and flow.is_contiguous() and mask.is_contiguous()
-    timed("convex_upsample", 0, _nbytes(flow) + _nbytes(mask) + _nbytes(out), lambda: _check(lib().pp_convex_upsample(_p(flow), _p(mask), _i(mask.shape[-1]), _i(dtype_code(mask.dtype)), _p(out),
+    timed("convex_upsample", 0, _nbytes(flow) + _nbytes(mask) + _nbytes(out), lambda: _check(lib().pp_convex_upsample(_p(flow), _p(mask), _i(mask.shape[-1]), _i(dtype_code(mask.dtype)), _pw(out),
                                     _i(B), _i(h), _i(w), _stream(flow)),
            "pp_convex_upsample"))
     return out
@@ -564,7 +599,7 @@ def window_mask(mask, wh=5, ww=9):
     B, Lt, Hp, Wp = mask.shape
     out = torch.empty((B, (Hp // wh) * (Wp // ww)), dtype=torch.float32, device=mask.device)
     assert mask.is_contiguous()
-    timed("window_mask", 0, _nbytes(mask) + _nbytes(out), lambda: _check(lib().pp_window_mask(_p(mask), _p(out), _i(B), _i(Lt), _i(Hp), _i(Wp), _i(wh), _i(ww),
+    timed("window_mask", 0, _nbytes(mask) + _nbytes(out), lambda: _check(lib().pp_window_mask(_p(mask), _pw(out), _i(B), _i(Lt), _i(Hp), _i(Wp), _i(wh), _i(ww),
                                 _i(dtype_code(mask.dtype)), _stream(mask)),
            "pp_window_mask"))
     return out
@@ -597,6 +632,11 @@ def sparse_window_attention(q, k, v, pk, pv, own, rolled, tind, wmask, heads=4, 
     a.impl = impl
     work = torch.empty((1 + B * wmask.shape[-1],), dtype=torch.int32, device=q.device)   # compacted masked-window list
     a.work, a.work_ints = work.data_ptr(), work.numel()
+    if _hazard.active() is not None:
+        for t in (q, k, v, pk, pv, own, rolled, tind, wmask):
+            _hazard.active().note(t)
+        _hazard.active().note(out, True)
+        _hazard.active().note(work, True)
     for t in (q, k, v, own, rolled, tind, wmask):
         if not t.is_cuda:
             raise RuntimeError("sparse_window_attention needs GPU tensors")
@@ -621,7 +661,7 @@ def fold_tokens(tokens, BT, fh, fw, Cc, H, W, normalize=False, act=ACT_NONE):
     """tokens [BT, fh*fw, Cc*49] -> NHWC [BT,H,W,Cc]."""
     out = torch.empty((BT, H, W, Cc), dtype=tokens.dtype, device=tokens.device)
     assert tokens.is_contiguous()
-    timed("fold_tokens", 0, _nbytes(tokens) + _nbytes(out), lambda: _check(lib().pp_fold_tokens(_p(tokens), _p(out), _i(BT), _i(fh), _i(fw), _i(Cc), _i(H), _i(W),
+    timed("fold_tokens", 0, _nbytes(tokens) + _nbytes(out), lambda: _check(lib().pp_fold_tokens(_p(tokens), _pw(out), _i(BT), _i(fh), _i(fw), _i(Cc), _i(H), _i(W),
                                 _i(1 if normalize else 0), _i(act), _i(dtype_code(tokens.dtype)), _stream(tokens)),
            "pp_fold_tokens"))
     return out
@@ -632,7 +672,7 @@ def layernorm(x, gamma, beta, eps=1e-5):
     Cc = x.shape[-1]
     out = torch.empty_like(x)
     assert x.is_contiguous() and gamma.dtype == torch.float32 and beta.dtype == torch.float32
-    timed("layernorm", 0, _nbytes(x) + _nbytes(out), lambda: _check(lib().pp_layernorm(_p(x), _p(gamma), _p(beta), _p(out), C.c_int64(x.numel() // Cc), _i(Cc),
+    timed("layernorm", 0, _nbytes(x) + _nbytes(out), lambda: _check(lib().pp_layernorm(_p(x), _p(gamma), _p(beta), _pw(out), C.c_int64(x.numel() // Cc), _i(Cc),
                               C.c_float(eps), _i(dtype_code(x.dtype)), _stream(x)),
            "pp_layernorm"))
     return out
@@ -643,7 +683,7 @@ def layernorm_grid(x, gamma, beta, out, eps=1e-5):
     `out` are left as they are: zero-filled once by the caller)."""
     N, gh, gw, Cc = x.shape
     assert out.shape[0] == N and out.shape[3] == Cc and out.dtype == x.dtype and x.is_contiguous() and out.is_contiguous()
-    timed("layernorm", 0, 2 * _nbytes(x), lambda: _check(lib().pp_layernorm_grid(_p(x), _p(gamma), _p(beta), _p(out), _i(N), _i(gh), _i(gw), _i(out.shape[1]),
+    timed("layernorm", 0, 2 * _nbytes(x), lambda: _check(lib().pp_layernorm_grid(_p(x), _p(gamma), _p(beta), _pw(out), _i(N), _i(gh), _i(gw), _i(out.shape[1]),
                                                                                  _i(out.shape[2]), _i(Cc), C.c_float(eps), _i(dtype_code(x.dtype)), _stream(x)),
                                                  "pp_layernorm_grid"))
     return out
@@ -654,7 +694,7 @@ def depthwise_pool(x, weight, bias, k=4):
     N, H, W, Cc = x.shape
     out = torch.empty((N, H // k, W // k, Cc), dtype=x.dtype, device=x.device)
     assert x.is_contiguous() and weight.dtype == torch.float32
-    timed("depthwise_pool", 0, _nbytes(x) + _nbytes(out), lambda: _check(lib().pp_depthwise_pool(_p(x), _p(weight), _p(bias), _p(out), _i(N), _i(H), _i(W), _i(Cc), _i(k),
+    timed("depthwise_pool", 0, _nbytes(x) + _nbytes(out), lambda: _check(lib().pp_depthwise_pool(_p(x), _p(weight), _p(bias), _pw(out), _i(N), _i(H), _i(W), _i(Cc), _i(k),
                                    _i(dtype_code(x.dtype)), _stream(x)),
            "pp_depthwise_pool"))
     return out
@@ -667,7 +707,7 @@ def instance_norm(x, relu=False, eps=1e-5, out=None):
     L.pp_instance_norm_workspace_floats.restype = C.c_int64
     ws = torch.empty((int(L.pp_instance_norm_workspace_floats(N, H, W, Cc)),), dtype=torch.float32, device=x.device)
     assert x.is_contiguous()
-    timed("instance_norm", 0, _nbytes(x) * 2 + _nbytes(out), lambda: _check(lib().pp_instance_norm(_p(x), _p(out), _p(ws), _i(N), _i(H), _i(W), _i(Cc), C.c_float(eps),
+    timed("instance_norm", 0, _nbytes(x) * 2 + _nbytes(out), lambda: _check(lib().pp_instance_norm(_p(x), _pw(out), _pw(ws), _i(N), _i(H), _i(W), _i(Cc), C.c_float(eps),
                                   _i(1 if relu else 0), _i(dtype_code(x.dtype)), _stream(x)),
            "pp_instance_norm"))
     return out
@@ -685,7 +725,7 @@ def instance_norm_split(x, relu=False, eps=1e-5, residual=None, res_choff=0, rel
     if residual is not None:
         assert residual.dtype == torch.float16 and residual.is_contiguous() and residual.shape[:3] == (N, H, W)
     timed("instance_norm", 0, _nbytes(x) * 2 + _nbytes(out) * (2 if residual is not None else 1),
-          lambda: _check(lib().pp_instance_norm_split(_p(x), _p(out), _p(ws), _i(N), _i(H), _i(W), _i(Cc), C.c_float(eps), _i(1 if relu else 0),
+          lambda: _check(lib().pp_instance_norm_split(_p(x), _pw(out), _pw(ws), _i(N), _i(H), _i(W), _i(Cc), C.c_float(eps), _i(1 if relu else 0),
                                                       _p(residual), _i(residual.shape[-1] if residual is not None else 0), _i(res_choff),
                                                       _i(1 if relu2 else 0), _stream(x)), "pp_instance_norm_split"))
     return out
@@ -695,7 +735,7 @@ def upsample2x(x):
     N, H, W, Cc = x.shape
     out = torch.empty((N, 2 * H, 2 * W, Cc), dtype=x.dtype, device=x.device)
     assert x.is_contiguous()
-    timed("upsample2x", 0, _nbytes(x) + _nbytes(out), lambda: _check(lib().pp_upsample2x(_p(x), _p(out), _i(N), _i(H), _i(W), _i(Cc), _i(dtype_code(x.dtype)), _stream(x)),
+    timed("upsample2x", 0, _nbytes(x) + _nbytes(out), lambda: _check(lib().pp_upsample2x(_p(x), _pw(out), _i(N), _i(H), _i(W), _i(Cc), _i(dtype_code(x.dtype)), _stream(x)),
            "pp_upsample2x"))
     return out
 
@@ -715,7 +755,7 @@ def gru_gate(zr, h, h_choff, Cc, out, out_choff, q=None):
     """mode 0 (q is None): out = r*h with r = zr[..., C:2C]; mode 1: out = (1-z)*h + z*q, z = zr[..., :C]."""
     npix = zr.numel() // zr.shape[-1]
     timed("gru_gate", 0, npix * Cc * 4 * zr.element_size(), lambda: _check(lib().pp_gru_gate(_p(zr), _i(zr.shape[-1]), _p(h), _i(h.shape[-1]), _i(h_choff), _p(q),
-                             _i(q.shape[-1] if q is not None else 0), _p(out), _i(out.shape[-1]), _i(out_choff),
+                             _i(q.shape[-1] if q is not None else 0), _pw(out), _i(out.shape[-1]), _i(out_choff),
                              C.c_int64(npix), _i(Cc), _i(0 if q is None else 1), _i(dtype_code(zr.dtype)), _stream(zr)),
            "pp_gru_gate"))
     return out
@@ -730,7 +770,7 @@ def nchw_to_nhwc(x, out=None, out_choff=0, out_dtype=None, cpad=None, scale=1.0,
         dt = torch.float16 if split else (out_dtype or x.dtype)
         out = (torch.zeros if cpad != Cc else torch.empty)((N, H, W, 2 * cpad if split else cpad), dtype=dt, device=x.device)
     assert x.is_contiguous() and out.is_contiguous() and (not split or (x.dtype == torch.float32 and out.dtype == torch.float16))
-    timed("nchw_to_nhwc", 0, _nbytes(x) * 2, lambda: _check(lib().pp_nchw_to_nhwc(_p(x), _i(dtype_code(x.dtype)), _p(out), _i(PP_F16S if split else dtype_code(out.dtype)),
+    timed("nchw_to_nhwc", 0, _nbytes(x) * 2, lambda: _check(lib().pp_nchw_to_nhwc(_p(x), _i(dtype_code(x.dtype)), _pw(out), _i(PP_F16S if split else dtype_code(out.dtype)),
                                  _i(out.shape[-1]), _i(out_choff), _i(N), _i(Cc), _i(H), _i(W), C.c_float(scale),
                                  _stream(x)),
            "pp_nchw_to_nhwc"))
@@ -749,7 +789,7 @@ def pack_nhwc8(srcs, out=None):
         out = torch.empty((N, H, W, 8), dtype=x0.dtype, device=x0.device)
     assert out.is_contiguous() and out.dtype == x0.dtype and tuple(out.shape) == (N, H, W, 8)
     ptrs = [_p(t) for t in srcs] + [None] * (3 - len(srcs))
-    timed("nchw_to_nhwc", 0, _nbytes(out) * 2, lambda: _check(lib().pp_pack_nhwc8(ptrs[0], _i(cs[0]), ptrs[1], _i(cs[1]), ptrs[2], _i(cs[2]), _p(out), _i(N),
+    timed("nchw_to_nhwc", 0, _nbytes(out) * 2, lambda: _check(lib().pp_pack_nhwc8(ptrs[0], _i(cs[0]), ptrs[1], _i(cs[1]), ptrs[2], _i(cs[2]), _pw(out), _i(N),
                                                                             _i(H), _i(W), _i(dtype_code(x0.dtype)), _stream(x0)), "pp_pack_nhwc8"))
     return out
 
@@ -759,7 +799,7 @@ def nhwc_to_nchw(x, Cc=None, choff=0, out_dtype=None, act=ACT_NONE):
     Cc = Cs if Cc is None else Cc
     out = torch.empty((N, Cc, H, W), dtype=out_dtype or x.dtype, device=x.device)
     assert x.is_contiguous()
-    timed("nhwc_to_nchw", 0, _nbytes(out) * 2, lambda: _check(lib().pp_nhwc_to_nchw(_p(x), _i(dtype_code(x.dtype)), _i(Cs), _i(choff), _p(out),
+    timed("nhwc_to_nchw", 0, _nbytes(out) * 2, lambda: _check(lib().pp_nhwc_to_nchw(_p(x), _i(dtype_code(x.dtype)), _i(Cs), _i(choff), _pw(out),
                                  _i(dtype_code(out.dtype)), _i(N), _i(Cc), _i(H), _i(W), _i(act), _stream(x)),
            "pp_nhwc_to_nchw"))
     return out

@@ -330,8 +330,10 @@ def assert_finite_flows(raft):
     With seeded and released-style weights RAFT's activations stay below ~1e3 (features are instance-normalised, correlations are scaled by
     1/16, flows are pixels), so the guard is a backstop for foreign checkpoints or corrupt inputs; ``precision="f32"`` (exact fp32 matrix
     instructions) has fp32's range."""
-    flags = getattr(raft, "_flows_finite", None) or []
-    raft._flows_finite = [fc for fc in flags if fc[1]]
+    flags = (getattr(raft, "_flows_finite", None) or []) + [(f, False) for f, _ in (getattr(raft, "_flows_finite_eager", None) or [])]
+    if flags:
+        torch.cuda.synchronize(flags[0][0].device)     # the flags were written on whatever streams the forwards ran on
+    raft._flows_finite_eager = []
     if flags and not bool(torch.stack([f.reshape(()) for f, _ in flags]).all()):
         prec = getattr(raft, "_flows_precision", "?")
         hint = ("a value left fp16's range (|v| > 65504) in the split-plane engine: run RAFT_bi(precision='f32') (CLI: --raft_fp32)"
@@ -378,7 +380,8 @@ class RAFT_bi(nn.Module):
         # fp32 all-pairs correlation volumes + pyramids of the pair-direction chunks in flight (volume modes "f32" / "f16x3")
         self.volume_budget_bytes = float(os.environ.get("PP_RAFT_VOLUME_GB", "40")) * 1e9
         self._engines = {}
-        self._flows_finite = []                # device flags of the last forwards (assert_finite_flows)
+        self._flows_finite = []                # device flags of the forwards recorded under hipGraph capture (refreshed by every replay)
+        self._flows_finite_eager = []          # (flag, event) of the eager forwards since the last assert_finite_flows
         self.to(device)
         self.eval()
 
@@ -489,13 +492,27 @@ class RAFT_bi(nn.Module):
         #  by itself; eager flags are folded into one running AND, so no call's flag is ever dropped -- a long clip makes many calls)
         captured = up.is_cuda and torch.cuda.is_current_stream_capturing()
         flag = torch.isfinite(up32).all()
-        flags = getattr(self, "_flows_finite", None) or []
-        eager = [f for f, c in flags if not c]
-        if not captured and eager:
-            flag = flag & eager[0].reshape(())
-            flags = [fc for fc in flags if fc[1]]
-        flags.append((flag, captured))
-        self._flows_finite = flags[-256:]          # (captured flags of graphs long gone are bounded; the eager flag is ONE folded entry)
+        if captured:
+            flags = getattr(self, "_flows_finite", None) or []
+            flags.append((flag, True))
+            self._flows_finite = [fc for fc in flags if not fc[1]] + [fc for fc in flags if fc[1]][-256:]
+        else:
+            # eager flags: kept one by one WITH an event recorded behind them on the stream that wrote them (another logical rank / lane may
+            # call next on another stream: nothing else orders the two); assert_finite_flows stacks them after its synchronisation.  A caller
+            # that never asserts (a long-running server) is bounded by folding 256 of them into one, each awaited through its event
+            ev = torch.cuda.Event()
+            ev.record()
+            eager = getattr(self, "_flows_finite_eager", None) or []
+            eager.append((flag, ev))
+            if len(eager) > 256:
+                cur = torch.cuda.current_stream(up.device)
+                for _, e in eager:
+                    cur.wait_event(e)
+                folded = torch.stack([f.reshape(()) for f, _ in eager]).all()
+                ev = torch.cuda.Event()
+                ev.record()
+                eager = [(folded, ev)]
+            self._flows_finite_eager = eager
         self._flows_precision = prec
         half = P // 2
         return up[:half].view(b, l_t - 1, 2, h, w), up[half:].view(b, l_t - 1, 2, h, w)

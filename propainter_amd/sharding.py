@@ -1029,7 +1029,7 @@ class StreamingClipGraph:
             if lockstep:
                 raise ValueError("StreamingClipGraph(single_graph=True) holds one graph: there is no lockstep order to replay")
             self._single.replay()                         # on the current stream, behind the uploads of load()
-            return self._single_out
+            return self._single_out.clone()               # a fresh tensor like the chained form's: the next replay overwrites the static buffer
         if concurrent:
             import warnings
             warnings.warn("StreamingClipGraph.replay(concurrent=True): overlapping launches of several hipGraphs give WRONG frames in most "

@@ -54,15 +54,17 @@ def main():
     print(torch.cuda.get_device_name(0), flush=True)
     g = torch.Generator().manual_seed(5)
     P, h, w = args.pairs, args.h8, args.w8
-    halo_alt = [0, 116, 0, 116]      # 116: the software-pipelined halo kernel (conv_halo_pipe.h); each twice
+    # halo layers: the 128-pixel kernel (71: 128-cout tiles, 72: 64-cout tiles) against the ping-pong kernel (82 / 83, conv_halo8.h), each twice
+    halo_alt = [71, 82, 71, 82]
+    halo_alt64 = [72, 83, 72, 83]
     v2_alt = [0, 12, 13, 22]
     # name, N, H, W, cin list, cout, k, stride, pad, impls, extras
     L = [
         ("convc1_1x1_324", P, h, w, [324], 256, (1, 1), 1, 0, v2_alt, dict(act="relu")),
-        ("convc2_3x3_256_192", P, h, w, [256], 192, (3, 3), 1, 1, halo_alt, dict(act="relu")),
+        ("convc2_3x3_256_192", P, h, w, [256], 192, (3, 3), 1, 1, halo_alt64, dict(act="relu")),
         ("convf1_7x1_16_128", P, h, w, [16], 128, (7, 1), 1, (3, 0), v2_alt, dict(act="relu")),
-        ("convf2_3x3_128_64", P, h, w, [128], 64, (3, 3), 1, 1, halo_alt, dict(act="relu")),
-        ("convm_3x3_256_126", P, h, w, [192, 64], 126, (3, 3), 1, 1, halo_alt, dict(act="relu")),
+        ("convf2_3x3_128_64", P, h, w, [128], 64, (3, 3), 1, 1, halo_alt64, dict(act="relu")),
+        ("convm_3x3_256_126", P, h, w, [192, 64], 126, (3, 3), 1, 1, halo_alt64, dict(act="relu")),
         ("gru_zr_1x5", P, h, w, [128, 128], 256, (1, 5), 1, (0, 2), halo_alt, dict(act="sigmoid", gru="zr")),
         ("gru_q_1x5", P, h, w, [128, 128], 128, (1, 5), 1, (0, 2), halo_alt, dict(act="tanh", gru="h")),
         ("gru_zr_5x1", P, h, w, [128, 128], 256, (5, 1), 1, (2, 0), halo_alt, dict(act="sigmoid", gru="zr")),
@@ -70,9 +72,9 @@ def main():
         ("fh1_3x3_128_256", P, h, w, [128], 256, (3, 3), 1, 1, halo_alt, dict(act="relu")),
         ("fh2_3x3_256_2", P, h, w, [256], 2, (3, 3), 1, 1, [0, 110], dict(out_f32=True)),
         ("enc_7x7s2_3_64", 4, 720, 1280, [3], 64, (7, 7), 2, 3, [0, 22, 12], dict(out_f32=True)),
-        ("enc_3x3_64_64", 4, 360, 640, [64], 64, (3, 3), 1, 1, halo_alt, dict(out_f32=True)),
+        ("enc_3x3_64_64", 4, 360, 640, [64], 64, (3, 3), 1, 1, halo_alt64, dict(out_f32=True)),
         ("enc_3x3s2_64_96", 4, 360, 640, [64], 96, (3, 3), 2, 1, v2_alt, dict(out_f32=True)),
-        ("enc_3x3_96_96", 8, 180, 320, [96], 96, (3, 3), 1, 1, halo_alt, dict(out_f32=True)),
+        ("enc_3x3_96_96", 8, 180, 320, [96], 96, (3, 3), 1, 1, halo_alt64, dict(out_f32=True)),
         ("enc_3x3s2_96_128", 8, 180, 320, [96], 128, (3, 3), 2, 1, v2_alt, dict(out_f32=True)),
         ("enc_3x3_128_128", 16, 90, 160, [128], 128, (3, 3), 1, 1, halo_alt, dict(out_f32=True)),
         ("enc_1x1_128_256", 16, 90, 160, [128], 256, (1, 1), 1, 0, v2_alt, dict()),

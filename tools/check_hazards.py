@@ -1,0 +1,71 @@
+"""Capture-time memory-hazard check (propainter_amd/hazard.py) of the multi-stream submission forms, on the GPU:
+
+    python tools/check_hazards.py clip   [frames=80]  [subvideo=80] [height=720] [width=1280]     whole-pass ClipGraph (lanes inside)
+    python tools/check_hazards.py stream [frames=320] [subvideo=80] [height] [width] [stages=0,2]  StreamingClipGraph, ONE stage-pipelined graph
+    python tools/check_hazards.py multi  [frames=320] [subvideo=80] [height] [width]               per-(rank, segment) graphs, CONCURRENT launches
+    python tools/check_hazards.py eager  [frames]     [subvideo]                                   the eager pass alone (window / RAFT lanes)
+
+Prints one JSON line `HAZARDS {...}`: launches seen, allocator generations, and every pair of accesses to overlapping memory (one a
+write) that no stream / event edge orders -- "alias" (a recycled block touched without an edge from its previous life), "race"
+(inside one allocation), "race?" (two strided channel windows of one NHWC buffer: overlap as byte ranges only).  With PP_HAZARD_STACKS=1
+the findings carry the Python call sites.  The pass's bytes are compared with an eager pass WITHOUT the recorder as well."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import scipy.ndimage
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from propainter_amd import hazard                                                        # noqa: E402
+from propainter_amd.pipeline import ClipGraph, InferenceConfig, run_clip                 # noqa: E402
+from propainter_amd.synthetic import seeded_models, synthetic_clip, synthetic_mask     # noqa: E402
+
+mode = sys.argv[1] if len(sys.argv) > 1 else "clip"
+defaults = {"clip": ["80", "80"], "eager": ["80", "80"], "stream": ["320", "80"], "multi": ["320", "80"]}[mode] + ["720", "1280"]
+argv = sys.argv[2:6]
+L, S, H, W = (int(v) for v in (argv + defaults[len(argv):]))
+stages = sys.argv[6] if len(sys.argv) > 6 else "0,2"
+dev = torch.device("cuda")
+models = seeded_models(dev, raft_precision="f16x3")
+cfg = InferenceConfig(subvideo_length=S, fp16=True)
+clip = torch.from_numpy(synthetic_clip(L, H, W)).to(dev)
+m = scipy.ndimage.binary_dilation(synthetic_mask(H, W), iterations=4).astype(np.uint8) * 255
+masks = torch.from_numpy(np.repeat(m[None], L, 0)).to(dev)
+
+ref = run_clip(models, clip, masks, masks, cfg, dev).clone()          # engines, tables; the bytes every form must reproduce
+torch.cuda.synchronize()
+t0 = time.time()
+same = []
+with hazard.Recorder(dev, stacks=os.environ.get("PP_HAZARD_STACKS") == "1") as rec:
+    if mode == "eager":
+        for _ in range(2):
+            same.append(bool(torch.equal(run_clip(models, clip, masks, masks, cfg, dev), ref)))
+    elif mode == "clip":
+        g = ClipGraph(models, L, H, W, cfg, dev, example=(clip, masks, masks))
+        for _ in range(2):
+            same.append(bool(torch.equal(g.replay(), ref)))
+    else:
+        from propainter_amd.sharding import StreamingClipGraph
+        if mode == "stream":
+            os.environ["PP_SG_STAGES"] = stages
+            s = StreamingClipGraph(models, L, H, W, cfg, dev, single_graph=True, validate=0)
+        else:
+            s = StreamingClipGraph(models, L, H, W, cfg, dev, single_graph=False, share_pool=False)
+        s.load(clip, masks, masks)
+        s.capture()
+        for _ in range(3):
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                out = s.replay(concurrent=True) if mode == "multi" else s.replay()
+            same.append(bool(torch.equal(out, ref)))
+    torch.cuda.synchronize()
+rep = rec.report()
+rep.update(mode=mode, frames=L, subvideo=S, height=H, width=W, stages=stages if mode == "stream" else None,
+           replays_equal_eager=same, seconds=round(time.time() - t0, 1), stream_names=len(rec.names))
+for k in ("alias", "race", "race?"):
+    rep[k + "_count"] = len(rep[k])
+print("HAZARDS " + json.dumps(rep), flush=True)
