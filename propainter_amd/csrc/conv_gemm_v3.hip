@@ -49,10 +49,14 @@ static int launch_tiny(const ConvParams& p, hipStream_t stream) {     // 16-cout
   return halo_shared_weights() ? launch_v3<TH, TW, KH, KW, 16>(p, stream) : launch_v3<TH, TW, KH, KW, 16, false, 0, 64, false, true>(p, stream);
 }
 
-// Ping-pong form (conv_halo8.h): 256-pixel tiles, eight waves in two groups in opposite phases, one block per CU.
-// PP_HALO8=0 switches it off (A/B); cfg 82 / 83 force it with 128- / 64-cout tiles, cfg 70..72 force the 128-pixel kernel.
+// Ping-pong form (conv_halo8.h): 256-pixel tiles, eight waves in two groups in opposite phases, one block per CU.  MEASURED
+// (profiles/r6_halo8_pingpong.txt: kbench + tools/bench_split.py, interleaved with the 128-pixel kernel on one box, bit-identical):
+// 3-9 % SLOWER on the fp16 128-cout layers, 17 % slower with 64-cout tiles, 2.5-4 % slower on the split-plane GRU / flow-head
+// layers -- with the DMA pieces issued between the MFMA clusters; 9-24 % / 4 % slower with the DMA at the head of the READ phase;
+// s_setprio on the MFMA phase, on the READ phase or nowhere: no difference.  Not dispatched automatically: impl 82 / 83 select it
+// (128- / 64-cout tiles), PP_HALO8=1 lets the automatic choice take it for 128-cout tiles of launches with >= 256 blocks.
 static bool halo8_enabled() {
-  static const bool v = !(getenv("PP_HALO8") != nullptr && getenv("PP_HALO8")[0] == '0');
+  static const bool v = getenv("PP_HALO8") != nullptr && getenv("PP_HALO8")[0] == '1';
   return v;
 }
 template <int BN, bool SPLIT>

@@ -26,6 +26,22 @@
 #pragma once
 #include "conv_halo.h"
 
+// Variant switches (A/B builds, tools/build_h8_variant.sh):
+//   PP_H8_DMA_IN_MFMA 1 (default): the LDS-DMA pieces of a step are issued BETWEEN the MFMA clusters of the wave's MFMA phase (a piece
+//                      costs ~60 cycles among bare MFMAs and 100-185 inside a phase that carries fragment reads: MI355X_MICROARCH.md),
+//                      the READ phase is the 16 fragment reads and two waits only; 0: issued at the head of the READ phase (first form).
+//   PP_H8_PRIO         0 none, 1 (default) s_setprio 1 over the MFMA phase, 2 s_setprio 1 over the READ phase (the partner's MFMAs
+//                      need one issue slot in four; the READ phase is the serial chain).
+#ifndef PP_H8_DMA_IN_MFMA
+#define PP_H8_DMA_IN_MFMA 1
+#endif
+#ifndef PP_H8_PRIO
+#define PP_H8_PRIO 1
+#endif
+#ifndef PP_H8_HOIST_TAPS
+#define PP_H8_HOIST_TAPS 5      // tap windows of at most this many taps keep their swizzled fragment addresses in registers
+#endif
+
 namespace pp {
 
 template <int TH, int TW, int KH, int KW, int BN, bool SPLIT>
@@ -162,31 +178,88 @@ __global__ __launch_bounds__(512, 1) void conv_halo8_kernel(const ConvParams p) 
     for (int f = 0; f < TN; ++f) bf[kk][f] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
   }
 
-#define H8_MFMA()                                                                                               \
+  // DMA of one step: the weight stage of step ks + 2 and, on taps 0 .. NTAPS-2, this wave's share of the next channel block's patch
+  // (the last two steps / the last block issue nothing: no request is in flight when the loop ends and LDS becomes the epilogue's)
+#define H8_ISSUE_WEIGHTS() do { if (ks + 2 < nk) H8_ISSUE_B(ks + 2, st2); } while (0)
+#define H8_ISSUE_PATCH(t)                                                                                       \
+  do {                                                                                                          \
+    if (have_next) {                                                                                            \
+      if ((t) == 0) {                       /* source of the next channel block: selected once per block, not per piece */ \
+        v3_entry_ready(en);                                                                                     \
+        if constexpr (SPLIT) { v3_entry_ready(enl); lobn = (enl[3] - en[3]) * 2; }                              \
+        const int s_ = en[2] & 0xff;                                                                            \
+        rsn = s_ == 1 ? rs1 : s_ == 2 ? rs2 : s_ == 3 ? rs3 : rs0;                                              \
+        rbn = s_ == 1 ? rb1 : s_ == 2 ? rb2 : s_ == 3 ? rb3 : rb0;                                              \
+        cbn = en[3] * 2 + (SPLIT ? (lca & 3) * 16 + ((lca & 4) ? lobn : 0) : lca * 16);                         \
+      }                                                                                                         \
+      if ((t) < TSPREAD) {                                                                                      \
+        _Pragma("unroll") for (int jj = (t); jj < PPW; jj += TSPREAD) {                                         \
+          const int voff_ = ppix[jj] >= 0 ? ppix[jj] * rbn + cbn : (int)0x80000000;                             \
+          v3_dma16(rsn, patch0 + pnext * PATCH_BYTES + (jj * NW + wave) * 1024, voff_, 0);                      \
+        }                                                                                                       \
+      }                                                                                                         \
+    }                                                                                                           \
+  } while (0)
+
+#define H8_MFMA16(WB, AB)                                                                                       \
+  _Pragma("unroll") for (int a = 0; a < TN; ++a)                                                                \
+    _Pragma("unroll") for (int b = 0; b < TM; ++b)                                                              \
+      acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[WB][a], af[AB][b], acc[a][b], 0, 0, 0)
+
+  // MFMA(ks): the products of one step from the fragment registers (same order per accumulator as conv_halo.h); with
+  // PP_H8_DMA_IN_MFMA the step's DMA pieces go between the clusters
+#define H8_MFMA(t)                                                                                              \
   do {                                                                                                          \
     __builtin_amdgcn_sched_barrier(0);                                                                          \
-    __builtin_amdgcn_s_setprio(1);                                                                              \
+    if (PP_H8_PRIO == 1) __builtin_amdgcn_s_setprio(1);                                                         \
     if constexpr (SPLIT) {                                                                                      \
-      _Pragma("unroll") for (int a = 0; a < TN; ++a)                                                            \
-        _Pragma("unroll") for (int b = 0; b < TM; ++b)                                                          \
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[0][a], af[1][b], acc[a][b], 0, 0, 0);           \
-      _Pragma("unroll") for (int a = 0; a < TN; ++a)                                                            \
-        _Pragma("unroll") for (int b = 0; b < TM; ++b)                                                          \
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[1][a], af[0][b], acc[a][b], 0, 0, 0);           \
-      _Pragma("unroll") for (int a = 0; a < TN; ++a)                                                            \
-        _Pragma("unroll") for (int b = 0; b < TM; ++b)                                                          \
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[0][a], af[0][b], acc[a][b], 0, 0, 0);           \
+      H8_MFMA16(0, 1);                                                     /* W_hi x A_lo */                    \
+      if (PP_H8_DMA_IN_MFMA) { __builtin_amdgcn_sched_barrier(0); H8_ISSUE_WEIGHTS(); __builtin_amdgcn_sched_barrier(0); } \
+      H8_MFMA16(1, 0);                                                     /* W_lo x A_hi */                    \
+      if (PP_H8_DMA_IN_MFMA) { __builtin_amdgcn_sched_barrier(0); H8_ISSUE_PATCH(t); __builtin_amdgcn_sched_barrier(0); }  \
+      H8_MFMA16(0, 0);                                                     /* W_hi x A_hi */                    \
     } else {                                                                                                    \
-      _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                          \
-        _Pragma("unroll") for (int a = 0; a < TN; ++a)                                                          \
-          _Pragma("unroll") for (int b = 0; b < TM; ++b)                                                        \
-            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[kk][a], af[kk][b], acc[a][b], 0, 0, 0);       \
+      H8_MFMA16(0, 0);                                                                                          \
+      if (PP_H8_DMA_IN_MFMA) { __builtin_amdgcn_sched_barrier(0); H8_ISSUE_WEIGHTS(); H8_ISSUE_PATCH(t); __builtin_amdgcn_sched_barrier(0); } \
+      H8_MFMA16(1, 1);                                                                                          \
     }                                                                                                           \
-    __builtin_amdgcn_s_setprio(0);                                                                              \
+    if (PP_H8_PRIO == 1) __builtin_amdgcn_s_setprio(0);                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                                          \
   } while (0)
 
-  // counted wait at the end of a READ slot: everything older than the `cnt` pieces issued in this slot has landed
+  // READ(ks) at tap t: the 16 fragment reads of the step, retired before the slot barrier; then the DMA pieces this wave issued one
+  // slot ago (PP_H8_DMA_IN_MFMA: in its MFMA phase, nothing since) must have landed: a plain vmcnt(0), never a drain of younger requests
+#define H8_READ(t)                                                                                              \
+  do {                                                                                                          \
+    const int sh_ = ((t) / KW) * PW + ((t) % KW);                 /* compile-time after unrolling */             \
+    if (PP_H8_PRIO == 2) __builtin_amdgcn_s_setprio(1);                                                         \
+    if (!PP_H8_DMA_IN_MFMA) { H8_ISSUE_WEIGHTS(); H8_ISSUE_PATCH(t); }                                          \
+    const char* sb_ = bst0 + st0 * BSTAGE;                                                                      \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                          \
+      _Pragma("unroll") for (int f = 0; f < TN; ++f)                                                            \
+        bf[kk][f] = *reinterpret_cast<const f16x8*>(sb_ + b_off + f * 16 * 128 + (((kk * 4 + l4) ^ bswz) << 4)); \
+      _Pragma("unroll") for (int f = 0; f < TM; ++f) {                                                          \
+        int r0_ = pp0[f];                                                                                       \
+        if (NTAPS > PP_H8_HOIST_TAPS) asm volatile("" : "+v"(r0_));   /* opaque per use: 9 taps x 8 hoisted addresses spill */ \
+        const int row = r0_ + sh_;                                                                              \
+        af[kk][f] = *reinterpret_cast<const f16x8*>(pcur + row * 128 + (((kk * 4 + l4) ^ (row & 7)) << 4));     \
+      }                                                                                                         \
+    }                                                                                                           \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                          \
+    if (PP_H8_DMA_IN_MFMA) {                                                                                    \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                          \
+    } else {                                                                                                    \
+      const int npp_ = (t) < TSPREAD ? (PPW > (t) ? (PPW - (t) + TSPREAD - 1) / TSPREAD : 0) : 0;               \
+      const bool more_b_ = ks + 2 < nk;                                                                         \
+      if (more_b_ && have_next) H8_WAIT_VM(B_PER_WAVE + npp_);                                                  \
+      else if (more_b_) H8_WAIT_VM(B_PER_WAVE);                                                                 \
+      else if (have_next) H8_WAIT_VM(npp_);                                                                     \
+      else H8_WAIT_VM(0);                                                                                       \
+    }                                                                                                           \
+    if (PP_H8_PRIO == 2) __builtin_amdgcn_s_setprio(0);                                                         \
+  } while (0)
+
+  // counted wait (first form): everything older than the `cnt` pieces issued in this slot has landed
 #define H8_WAIT_VM(cnt)                                                                                         \
   do {                                                                                                          \
     if ((cnt) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
@@ -195,40 +268,6 @@ __global__ __launch_bounds__(512, 1) void conv_halo8_kernel(const ConvParams p) 
     else if ((cnt) == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                                       \
     else if ((cnt) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                       \
     else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");                                                       \
-  } while (0)
-
-  // READ(ks) at tap t of the current block: DMA for later steps first (so that it travels under the fragment reads), then the reads
-#define H8_READ(t)                                                                                              \
-  do {                                                                                                          \
-    const int sh_ = ((t) / KW) * PW + ((t) % KW);                 /* compile-time after unrolling */             \
-    const int npp_ = (t) < TSPREAD ? (PPW > (t) ? (PPW - (t) + TSPREAD - 1) / TSPREAD : 0) : 0;                 \
-    const bool more_b_ = ks + 2 < nk;                                                                           \
-    if (more_b_) H8_ISSUE_B(ks + 2, st2);                                                                       \
-    if (have_next) {                                                                                            \
-      if ((t) == 0) {                                                                                           \
-        v3_entry_ready(en);                                                                                     \
-        if constexpr (SPLIT) { v3_entry_ready(enl); lobn = (enl[3] - en[3]) * 2; }                              \
-      }                                                                                                         \
-      if ((t) < TSPREAD) {                                                                                      \
-        _Pragma("unroll") for (int jj = (t); jj < PPW; jj += TSPREAD) H8_ISSUE_PIECE(jj, pnext, en, lobn);      \
-      }                                                                                                         \
-    }                                                                                                           \
-    const char* sb_ = bst0 + st0 * BSTAGE;                                                                      \
-    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                          \
-      _Pragma("unroll") for (int f = 0; f < TN; ++f)                                                            \
-        bf[kk][f] = *reinterpret_cast<const f16x8*>(sb_ + b_off + f * 16 * 128 + (((kk * 4 + l4) ^ bswz) << 4)); \
-      _Pragma("unroll") for (int f = 0; f < TM; ++f) {                                                          \
-        int r0_ = pp0[f];            /* opaque per use: 9 taps x 8 swizzled addresses hoisted out of the block loop spill */ \
-        asm volatile("" : "+v"(r0_));                                                                           \
-        const int row = r0_ + sh_;                                                                              \
-        af[kk][f] = *reinterpret_cast<const f16x8*>(pcur + row * 128 + (((kk * 4 + l4) ^ (row & 7)) << 4));     \
-      }                                                                                                         \
-    }                                                                                                           \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                          \
-    if (more_b_ && have_next) H8_WAIT_VM(B_PER_WAVE + npp_);                                                    \
-    else if (more_b_) H8_WAIT_VM(B_PER_WAVE);                                                                   \
-    else if (have_next) H8_WAIT_VM(npp_);                                                                       \
-    else H8_WAIT_VM(0);                                                                                         \
   } while (0)
 
   // ONE instruction stream for both groups; group 1 passes one extra barrier first and so runs one slot behind group 0 for the
@@ -243,14 +282,15 @@ __global__ __launch_bounds__(512, 1) void conv_halo8_kernel(const ConvParams p) 
       v3_fetch_entry(p.ktable + (blk + 1) * (NTAPS * 8), en);
       if constexpr (SPLIT) v3_fetch_entry(p.ktable + (blk + 1) * (NTAPS * 8) + 4, enl);
     }
-    int lobn = 0;
+    int lobn = 0, rbn = 0, cbn = 0;
+    __amdgpu_buffer_rsrc_t rsn = rs0;
     const char* pcur = patch0 + (blk & 1) * PATCH_BYTES;
     const int pnext = (blk + 1) & 1;
 #pragma unroll
     for (int t = 0; t < NTAPS; ++t) {
       H8_READ(t);
       __builtin_amdgcn_s_barrier();
-      H8_MFMA();
+      H8_MFMA(t);
       __builtin_amdgcn_s_barrier();
       ++ks;
       st0 = st0 == NSTAGE - 1 ? 0 : st0 + 1;
@@ -316,6 +356,9 @@ __global__ __launch_bounds__(512, 1) void conv_halo8_kernel(const ConvParams p) 
 #undef H8_ISSUE_PIECE
 #undef H8_ISSUE_B
 #undef H8_MFMA
+#undef H8_MFMA16
+#undef H8_ISSUE_WEIGHTS
+#undef H8_ISSUE_PATCH
 #undef H8_WAIT_VM
 #undef H8_READ
 #endif

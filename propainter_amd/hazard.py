@@ -46,7 +46,7 @@ def active():
 
 class _Gen:
     """One life of an address range in the caching allocator."""
-    __slots__ = ("lo", "hi", "gid", "born", "stream", "pred", "last", "acc", "recorded", "label", "has_write")
+    __slots__ = ("lo", "hi", "gid", "born", "stream", "pred", "last", "acc", "recorded", "label", "has_write", "opaque")
 
     def __init__(self, lo, hi, gid, born, stream, label):
         self.lo, self.hi, self.gid, self.born, self.stream, self.label = lo, hi, gid, born, stream, label
@@ -55,6 +55,7 @@ class _Gen:
         self.acc = []             # (stream, n, lo, hi, is_write, strided, name, where)
         self.recorded = set()     # streams the allocator itself protects (record_stream)
         self.has_write = False
+        self.opaque = label == "pre-existing"       # contents written by something the recorder did not see (no uninitialised-read check)
 
 
 def _merge(iv):
@@ -98,7 +99,9 @@ class Recorder(TorchDispatchMode):
         self.ngen = 0
         self.launches = 0
         self.pending = []                 # pointers of the engine launch being assembled
-        self.findings = {"alias": [], "race": [], "race?": []}
+        self.findings = {"alias": [], "race": [], "race?": [], "uninit": []}
+        self.cap_id = 0                   # > 0 while a graph is being captured: such accesses describe the GRAPH, not the host timeline
+        self.ncap = 0
         self.seen = set()
         self.names = {}                   # stream handle -> short name
         self.capturing = None             # summary under construction: {"r": [], "w": []}
@@ -147,6 +150,20 @@ class Recorder(TorchDispatchMode):
         for c in ([self._clk(sid)] if sid is not None else list(self.clock.values())):
             self._join(self.host, c)
 
+    def end_capture(self):
+        """The accesses recorded under a capture were checked against each other as they came; they did not EXECUTE on the host's
+        timeline (a replay does, on the replaying stream: graph_access).  Forget them, and treat what they touched as written."""
+        cid, self.cap_id = self.cap_id, 0
+        if not cid:
+            return
+        for g in self.gens:
+            if any(a[8] == cid for a in g.acc):
+                g.acc = [a for a in g.acc if a[8] != cid]
+                g.opaque = True
+                g.has_write = any(a[4] for a in g.acc)
+            g.last = {k: v for k, v in g.last.items() if v[2] != cid}
+            g.pred = {k: v for k, v in g.pred.items() if v[2] != cid}
+
     def on_alloc(self, lo, hi, sid, label="alloc"):
         return self._new_gen(lo, hi, sid, True, label)
 
@@ -174,9 +191,9 @@ class Recorder(TorchDispatchMode):
         while i1 < len(self.gens) and self.gens[i1].lo < hi:
             g = self.gens[i1]
             if fresh:
-                for s_, (n, d) in list(g.pred.items()) + [(s_, v) for s_, v in g.last.items() if s_ not in g.recorded]:
-                    if pred.get(s_, (0, None))[0] < n:
-                        pred[s_] = (n, d)
+                for s_, (n, d, c_) in list(g.pred.items()) + [(s_, v) for s_, v in g.last.items() if s_ not in g.recorded]:
+                    if pred.get(s_, (0, None, 0))[0] < n:
+                        pred[s_] = (n, d, c_)
             i1 += 1
         if not fresh and i1 > i0:          # a pointer into memory already tracked: no new generation
             return self.gens[i0]
@@ -228,25 +245,30 @@ class Recorder(TorchDispatchMode):
                 if g is None:
                     g = self._new_gen(lo, hi, sid, False, "pre-existing")
                 # class "alias": every access of the closed generations of this range must be visible to this launch
-                for s_, (pn, pdesc) in g.pred.items():
+                for s_, (pn, pdesc, _pc) in g.pred.items():
                     if s_ != sid and c.get(s_, 0) < pn:
                         self._report("alias", (name, pdesc.split(" on ")[0], self.names[s_], self.names[sid]),
                                      f"{desc} touches [{lo:#x},{hi:#x}) of a block recycled by the allocator (generation {g.gid}, {g.label}) "
                                      f"without an edge from its previous life's access {pdesc} (sees {self.names[s_]}#{c.get(s_, 0)} < #{pn})")
                 # class "race": inside the generation
                 if is_write or g.has_write:
-                    for (s_, an, alo, ahi, aw, astr, aname, awhere) in g.acc:
+                    for (s_, an, alo, ahi, aw, astr, aname, awhere, _cap) in g.acc:
                         if s_ != sid and (aw or is_write) and alo < hi and lo < ahi and c.get(s_, 0) < an:
                             kind = "race?" if (strided and astr) else "race"
                             self._report(kind, (kind, name, aname, self.names[s_], self.names[sid], is_write, aw),
                                          f"{desc} {'writes' if is_write else 'reads'} [{lo:#x},{hi:#x}) while {aname} [{awhere}] on "
                                          f"{self.names[s_]}#{an} {'writes' if aw else 'reads'} [{alo:#x},{ahi:#x}) unordered "
                                          f"(generation {g.gid}, {g.label})")
+                # class "uninit": a read of memory nothing has written in this life of the block (the allocator hands out stale bytes:
+                # whatever the previous tenant left -- the result then depends on the allocation pattern, not on the inputs)
+                if not is_write and not g.opaque and not any(a[4] and a[2] < hi and lo < a[3] for a in g.acc):
+                    self._report("uninit", ("uninit", name, g.label.split(" [")[0]),
+                                 f"{desc} reads [{lo:#x},{hi:#x}) of generation {g.gid} ({g.label}) that no launch has written")
                 g.has_write = g.has_write or is_write
                 # keep the list short: an access on the same stream covering an older one of the same kind supersedes it
                 g.acc = [a for a in g.acc if not (a[0] == sid and a[4] == is_write and lo <= a[2] and a[3] <= hi)]
-                g.acc.append((sid, n, lo, hi, is_write, strided, name, where))
-                g.last[sid] = (n, desc)
+                g.acc.append((sid, n, lo, hi, is_write, strided, name, where, self.cap_id))
+                g.last[sid] = (n, desc, self.cap_id)
 
     # engine launches (propainter_amd.hip): pointers are collected by _p / _pw, the launch is closed by _check
     def note(self, t, write=False):
@@ -402,12 +424,15 @@ class Recorder(TorchDispatchMode):
             def capture_begin(g, *a, **k):
                 orig(g, *a, **k)
                 rec.capturing = {"r": [], "w": [], "n": 0}
+                rec.ncap += 1
+                rec.cap_id = rec.ncap
             return capture_begin
 
         def g_end(orig):
             def capture_end(g):
                 orig(g)
                 cap, rec.capturing = rec.capturing, None
+                rec.end_capture()
                 if cap is not None:
                     rec.graph_summaries[id(g)] = {"r": _merge(cap["r"]), "w": _merge(cap["w"]), "n": cap["n"], "graph": g}
             return capture_end

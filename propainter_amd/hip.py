@@ -517,7 +517,7 @@ def corr_feature_pyramid(f2):
     assert f2.dtype == torch.float16 and c == 256 and f2.is_contiguous()
     lv = [torch.empty((P, h >> l, w >> l, 256), dtype=f2.dtype, device=f2.device) for l in (1, 2, 3)]
     timed("corr_feature_pyramid", 0, _nbytes(f2) * 3 + sum(_nbytes(t) for t in lv),
-          lambda: _check(lib().pp_corr_feature_pyramid(_p(f2), _p(lv[0]), _p(lv[1]), _p(lv[2]), _i(P), _i(h), _i(w), _stream(f2)),
+          lambda: _check(lib().pp_corr_feature_pyramid(_p(f2), _pw(lv[0]), _pw(lv[1]), _pw(lv[2]), _i(P), _i(h), _i(w), _stream(f2)),
                          "pp_corr_feature_pyramid"))
     return [f2] + lv
 
@@ -529,7 +529,7 @@ def corr_feature_pyramid_split(f2):
     assert f2.dtype == torch.float16 and c == 512 and f2.is_contiguous()
     lv = [torch.empty((P, h >> l, w >> l, 512), dtype=f2.dtype, device=f2.device) for l in (1, 2, 3)]
     timed("corr_feature_pyramid", 0, _nbytes(f2) * 3 + sum(_nbytes(t) for t in lv),
-          lambda: _check(lib().pp_corr_feature_pyramid_split(_p(f2), _p(lv[0]), _p(lv[1]), _p(lv[2]), _i(P), _i(h), _i(w), _stream(f2)),
+          lambda: _check(lib().pp_corr_feature_pyramid_split(_p(f2), _pw(lv[0]), _pw(lv[1]), _pw(lv[2]), _i(P), _i(h), _i(w), _stream(f2)),
                          "pp_corr_feature_pyramid_split"))
     return lv
 
@@ -577,7 +577,7 @@ def raft_flow_taps(coords1, coords0, rows, flow_out=None, flow_choff=0, split=Fa
     assert rows.shape == (P, h, w, 32 if split else 16) and rows.is_contiguous() and (flow_out is None or (flow_out.is_contiguous() and flow_out.dtype == rows.dtype))
     assert not split or rows.dtype == torch.float16
     timed("raft_flow_taps", 0, 2 * _nbytes(coords1) + _nbytes(rows),
-          lambda: _check(lib().pp_raft_flow_taps(_p(coords1), _p(coords0), _p(rows), _pw(flow_out), _i(flow_out.shape[-1] if flow_out is not None else 0),
+          lambda: _check(lib().pp_raft_flow_taps(_p(coords1), _p(coords0), _pw(rows), _pw(flow_out), _i(flow_out.shape[-1] if flow_out is not None else 0),
                                                  _i(flow_choff), _i(P), _i(h), _i(w), _i(PP_F16S if split else dtype_code(rows.dtype)), _stream(coords1)),
                          "pp_raft_flow_taps"))
     return rows
@@ -744,7 +744,7 @@ def dcn_offset_mask_act(offmask, mag, flow=None, fl_choff=0):
     """in place on NHWC [N,H,W,432(+pad)]."""
     npix = offmask.numel() // offmask.shape[-1]
     assert offmask.is_contiguous() and (flow is None or (flow.is_contiguous() and flow.dtype == offmask.dtype))
-    timed("dcn_offset_mask_act", 0, _nbytes(offmask) * 2, lambda: _check(lib().pp_dcn_offset_mask_act(_p(offmask), _i(offmask.shape[-1]), _p(flow),
+    timed("dcn_offset_mask_act", 0, _nbytes(offmask) * 2, lambda: _check(lib().pp_dcn_offset_mask_act(_pw(offmask), _i(offmask.shape[-1]), _p(flow),
                                         _i(flow.shape[-1] if flow is not None else 0), _i(fl_choff), C.c_float(mag),
                                         C.c_int64(npix), _i(dtype_code(offmask.dtype)), _stream(offmask)),
            "pp_dcn_offset_mask_act"))

@@ -787,8 +787,16 @@ class StreamingClipGraph:
 
     NSEG = 5          # compute segments of sharded_clip_steps: RAFT | completion | image propagation | windows | boundary blends
 
-    def __init__(self, models, L, H, W, cfg, device, world=None, volume_gb=40.0, share_pool=True, single_graph=True, validate=3):
-        """single_graph=True (round 5, the default): the whole wavefront as ONE hipGraph, pipelined by stage -- RAFT and image
+    def __init__(self, models, L, H, W, cfg, device, world=None, volume_gb=40.0, share_pool=True, single_graph=False, validate=3):
+        """DEFAULT (round 6): one graph per (rank, segment) in ONE memory pool, replayed chained in the wavefront order -- the form that
+        has never produced a wrong byte.  The overlapped form is opt-in because its failure mode is silent and unexplained: the
+        capture-time hazard checker (propainter_amd/hazard.py, tools/check_hazards.py) finds NO unordered access in the stage-pipelined
+        capture -- neither with the shipped stage map nor with flow completion on a third branch -- yet the third-branch map gives
+        frames that differ from the eager pass at 720x1280x320 (3 of 3 replays, profiles/r6_hazards.txt).  Whatever reorders those
+        bytes sits below the submitted program (runtime / cache coherence between concurrently running branches), so a validation on
+        the capture clip can only sample it.
+
+        single_graph=True (round 5): the whole wavefront as ONE hipGraph, pipelined by stage -- RAFT and image
         propagation of the sub-videos on two branches forked from the capture stream, flow completion, the generator windows and the
         boundary blends on the capture stream, the exchanges as direct tensor hand-overs ordered by captured events
         (``_capture_single_graph``); ``validate`` replays of the captured graph are compared bit for bit with the eager pass at capture

@@ -108,9 +108,10 @@ def test_ping_pong_kernel_fused_gru_epilogues(dev, split, k, pad):
             assert torch.equal(a, b_), f"run {i}: {name} differs in {int((a != b_).sum())} values"
 
 
-def test_auto_dispatch_picks_the_ping_pong_kernel_only_when_it_fills_the_chip(dev, monkeypatch):
-    """impl 0: 256 blocks of 256 pixels or more -> conv_halo8; fewer -> the 128-pixel kernel; PP_HALO8=0 is read once per process, so the
-    switch is exercised through the explicit impls here -- the automatic choice must simply agree with both bit for bit."""
+def test_automatic_dispatch_agrees_with_both_kernels(dev):
+    """impl 0 takes the 128-pixel kernel (the ping-pong form measured 3-9 % slower: profiles/r6_halo8_pingpong.txt; PP_HALO8=1, read once
+    per process, would let launches of >= 256 blocks take it) -- whichever it takes, it must agree with both explicit forms bit for bit,
+    on a launch that cannot fill the chip with 256-pixel tiles and on one that can."""
     from propainter_amd.conv import ConvLayer
     g = torch.Generator().manual_seed(5)
     w = torch.randn(128, 128, 3, 3, generator=g) / math.sqrt(128 * 9)

@@ -92,3 +92,24 @@ def test_graph_launches_in_flight_together():
     r._cur = 2; r.graph_access(g2)
     assert not r.report()["race"]
     assert _overlap(_merge([(0, 4), (4, 8), (20, 30)]), _merge([(8, 20)])) is None and _merge([(0, 4), (4, 8)]) == [[0, 8]]
+
+
+def test_uninitialised_read_and_capture_scoped_accesses():
+    r = _rec()
+    r.on_alloc(A, A + 256, 1, "torch.empty")
+    r.access("reader", [(A, A + 128, False)], [], sid=1)               # nothing has written this life of the block
+    r.access("writer", [], [(A, A + 256, False)], sid=1)
+    r.access("reader2", [(A + 64, A + 128, False)], [], sid=1)
+    rep = r.report()
+    assert len(rep["uninit"]) == 1 and rep["uninit"][0].startswith("reader "), rep
+    # accesses recorded under a graph capture describe the graph: after the capture they neither race with nor order eager work
+    r = _rec()
+    r.on_alloc(B, B + 64, 1, "static out")
+    r.cap_id = r.ncap = 1
+    r.capturing = {"r": [], "w": [], "n": 0}
+    r.access("captured_writer", [], [(B, B + 64, False)], sid=7)        # the capture stream
+    r.capturing = None
+    r.end_capture()
+    r.access("eager_reader", [(B, B + 64, False)], [], sid=1)           # e.g. torch.equal(graph.replay(), ref) on the default stream
+    rep = r.report()
+    assert not rep["race"] and not rep["alias"] and not rep["uninit"], rep

@@ -470,10 +470,10 @@ def test_streaming_schedule_matches_the_unsharded_pass(models):
         ref_a, ref_b = run_clip(models, clip_a, masks, masks, cfg, dev), run_clip(models, clip_b, masks, masks, cfg, dev)
         outs = {}
         for share in ("pipelined", True, False):
-            # "pipelined" (default, round 5): the wavefront as ONE hipGraph pipelined by stage -- the overlapped form;
+            # "pipelined" (round 5; opt-in since round 6): the wavefront as ONE hipGraph pipelined by stage -- the overlapped form;
             # share_pool=True: one graph per (rank, segment) in ONE memory pool, captured and replayed (chained) in the wavefront order;
             # share_pool=False: a private pool per logical rank, which the lockstep A/B order needs
-            sc = (StreamingClipGraph(models, L, H, W, cfg, dev) if share == "pipelined"
+            sc = (StreamingClipGraph(models, L, H, W, cfg, dev, single_graph=True) if share == "pipelined"
                   else StreamingClipGraph(models, L, H, W, cfg, dev, share_pool=share, single_graph=False))
             sc.load(clip_a, masks, masks)
             sc.capture()

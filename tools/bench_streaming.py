@@ -81,7 +81,7 @@ def main():
         os.environ["PP_SG_DEBUG"] = "1"
     torch.cuda.reset_peak_memory_stats(dev)
     t0 = time.perf_counter()
-    sp1 = StreamingClipGraph(models, L, H, W, cfg, dev, volume_gb=args.volume_gb)
+    sp1 = StreamingClipGraph(models, L, H, W, cfg, dev, volume_gb=args.volume_gb, single_graph=True)
     sp1.load(clip, masks, masks)
     sp1.capture()
     rec["pipelined_capture_s"] = time.perf_counter() - t0

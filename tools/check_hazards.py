@@ -7,7 +7,8 @@
 
 Prints one JSON line `HAZARDS {...}`: launches seen, allocator generations, and every pair of accesses to overlapping memory (one a
 write) that no stream / event edge orders -- "alias" (a recycled block touched without an edge from its previous life), "race"
-(inside one allocation), "race?" (two strided channel windows of one NHWC buffer: overlap as byte ranges only).  With PP_HAZARD_STACKS=1
+(inside one allocation), "race?" (two strided channel windows of one NHWC buffer: overlap as byte ranges only), "uninit" (a read of memory that nothing has written
+since the allocator handed the block out: the result then depends on what the previous tenant left).  With PP_HAZARD_STACKS=1
 the findings carry the Python call sites.  The pass's bytes are compared with an eager pass WITHOUT the recorder as well."""
 import json
 import os
@@ -56,16 +57,24 @@ with hazard.Recorder(dev, stacks=os.environ.get("PP_HAZARD_STACKS") == "1") as r
             s = StreamingClipGraph(models, L, H, W, cfg, dev, single_graph=False, share_pool=False)
         s.load(clip, masks, masks)
         s.capture()
+        outs = []
         for _ in range(3):
             import warnings
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
                 out = s.replay(concurrent=True) if mode == "multi" else s.replay()
             same.append(bool(torch.equal(out, ref)))
+            outs.append(out.clone())
+        # a deviation that is the SAME in every replay is a different (deterministic) computation; one that changes is a race
+        detail = {"replay_i_equals_replay_0": [bool(torch.equal(o, outs[0])) for o in outs],
+                  "frames_differing_from_eager": [[int(j) for j in range(L) if bool((o[j] != ref[j]).any())][:12] for o in outs],
+                  "bytes_differing_from_eager": [int((o != ref).sum()) for o in outs],
+                  "max_abs_vs_eager": [int((o.to(torch.int16) - ref.to(torch.int16)).abs().max()) for o in outs]}
     torch.cuda.synchronize()
 rep = rec.report()
+rep["replay_detail"] = detail if mode in ("stream", "multi") else None
 rep.update(mode=mode, frames=L, subvideo=S, height=H, width=W, stages=stages if mode == "stream" else None,
            replays_equal_eager=same, seconds=round(time.time() - t0, 1), stream_names=len(rec.names))
-for k in ("alias", "race", "race?"):
+for k in ("alias", "race", "race?", "uninit"):
     rep[k + "_count"] = len(rep[k])
 print("HAZARDS " + json.dumps(rep), flush=True)
