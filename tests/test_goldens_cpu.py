@@ -12,7 +12,7 @@ import pytest
 from propainter_amd.synthetic import case_inputs, seeded_models
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-FIXTURES = ["synth_c2_432x240x80.npz", "synth_c3_720x1280x18.npz", "synth_stress_240x432x12.npz", "synth_stress_720x1280x6.npz"]
+FIXTURES = ["synth_c2_432x240x80.npz", "synth_c3_720x1280x18.npz", "synth_c3_720x1280x80.npz", "synth_stress_240x432x12.npz", "synth_stress_720x1280x6.npz"]
 _weights = {}
 
 
