@@ -331,7 +331,7 @@ def assert_finite_flows(raft):
     1/16, flows are pixels), so the guard is a backstop for foreign checkpoints or corrupt inputs; ``precision="f32"`` (exact fp32 matrix
     instructions) has fp32's range."""
     flags = (getattr(raft, "_flows_finite", None) or []) + [(f, False) for f, _ in (getattr(raft, "_flows_finite_eager", None) or [])]
-    if flags:
+    if flags and flags[0][0].is_cuda:
         torch.cuda.synchronize(flags[0][0].device)     # the flags were written on whatever streams the forwards ran on
     raft._flows_finite_eager = []
     if flags and not bool(torch.stack([f.reshape(()) for f, _ in flags]).all()):
@@ -500,17 +500,22 @@ class RAFT_bi(nn.Module):
             # eager flags: kept one by one WITH an event recorded behind them on the stream that wrote them (another logical rank / lane may
             # call next on another stream: nothing else orders the two); assert_finite_flows stacks them after its synchronisation.  A caller
             # that never asserts (a long-running server) is bounded by folding 256 of them into one, each awaited through its event
-            ev = torch.cuda.Event()
-            ev.record()
+            ev = None
+            if up.is_cuda:                 # (the CPU emulation of the host-logic tests has no streams)
+                ev = torch.cuda.Event()
+                ev.record()
             eager = getattr(self, "_flows_finite_eager", None) or []
             eager.append((flag, ev))
             if len(eager) > 256:
-                cur = torch.cuda.current_stream(up.device)
-                for _, e in eager:
-                    cur.wait_event(e)
+                if up.is_cuda:
+                    cur = torch.cuda.current_stream(up.device)
+                    for _, e in eager:
+                        if e is not None:
+                            cur.wait_event(e)
                 folded = torch.stack([f.reshape(()) for f, _ in eager]).all()
-                ev = torch.cuda.Event()
-                ev.record()
+                if up.is_cuda:
+                    ev = torch.cuda.Event()
+                    ev.record()
                 eager = [(folded, ev)]
             self._flows_finite_eager = eager
         self._flows_precision = prec
