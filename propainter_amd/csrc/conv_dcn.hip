@@ -18,7 +18,8 @@
 //     block and tap through the texture path, the largest item of the ablations in profiles/r2_dcn_patch_kernel.txt; the stage fits
 //     since the modulation masks are staged per channel block -- 80-byte rows instead of 144-byte rows holding two blocks.)
 //   * a sample whose corners fall outside the staged patch (|offset - tile mean| >= 5) reads those corners from global
-//     memory: slower, never wrong.  Outside the image every corner contributes zero (torchvision's bilinear_interpolate).
+//     memory -- all corner reads of the tap in flight together, chosen per wave (round 6, see the sampling section of the kernel):
+//     slower, never wrong.  Outside the image every corner contributes zero (torchvision's bilinear_interpolate).
 // 4 waves, wave tile 32 pixels x 128 couts, v_mfma_f32_16x16x32_f16, fp32 accumulation; 2 blocks per CU.
 #include "conv_params.h"
 
@@ -248,62 +249,108 @@ __global__ __launch_bounds__(256, 2) void conv_dcn_patch_kernel(const ConvParams
       const bool more = step + 1 < nblocks * 9;
       f16x8 af[MT];
       const int trow = t / 3, tcol = t - trow * 3;
+      // Sampling.  Per M tile: corner weights and patch position of the lane's sample.  Then one of two forms, chosen PER WAVE:
+      //   * no lane of the wave leaves the staged patch (the common case on smooth flows): four LDS reads and the packed fp16 blend per
+      //     M tile, as in rounds 2-5;
+      //   * some lane does: EVERY corner read of the tap is put in flight before the first one is waited for -- the far lanes' corners
+      //     as raw buffer loads straight from the image (an offset beyond the image's bytes returns zeros: corners outside the image
+      //     and lanes that stay inside the patch cost no traffic), the patch reads of the other lanes, then one blend in torchvision's
+      //     corner order over whichever copy the lane uses.  The first form of this path read the corners of an out-of-patch sample one
+      //     by one, each inside its own validity branch: four serialised L2 round trips per sample (61 ms per clip on the stress clip's
+      //     flows against 30 on smooth ones; profiles/r6_dcn_far_samples.txt).  The arithmetic of both forms is the same.
+      typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+      _Float16 hw[MT][4];
+      int ry0[MT], rx0[MT];
+      bool use[MT], inpatch[MT];
+      bool far_lane = false;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-        h2 r2[4] = {h2{0, 0}, h2{0, 0}, h2{0, 0}, h2{0, 0}};
-        if (pin[mt] && !(dbg & 4)) {
-          const int q = (wave * MT + mt) * 16 + l15;
-          const h2 dd = *reinterpret_cast<const h2*>(offs + q * DCN_OSTR + (cb % OG) * NOFF + 2 * (gi * 9 + t));
-          const float mk = (float)msks[q * DCN_MSTR + (cb % MG) * NMSK + gi * 9 + t];
-          const float py = (float)(oy[mt] - 1 + trow) + (float)dd[0];
-          const float px = (float)(ox[mt] - 1 + tcol) + (float)dd[1];
-          const float fy = floorf(py), fx = floorf(px);
-          const float ly = py - fy, lx = px - fx;
-          // corner weights (x modulation mask) in fp16 pairs; the patch is zero outside the image, so corners outside the
-          // image contribute zero by themselves (= torchvision's per-corner test and its whole-sample test)
-          const float w11 = ly * lx * mk, w10 = (ly - ly * lx) * mk, w01 = (lx - ly * lx) * mk;
-          const float w00 = mk - w11 - w10 - w01;
-          const _Float16 hw[4] = {(_Float16)w00, (_Float16)w01, (_Float16)w10, (_Float16)w11};
-          // clamp far-out samples before the int conversion (they are handled by the slow path below anyway)
-          const int ry0 = (int)fminf(fmaxf(fy, -1.0e6f), 1.0e6f) - py0, rx0 = (int)fminf(fmaxf(fx, -1.0e6f), 1.0e6f) - px0;
-          if constexpr (STATS) {            // one sample per (pixel, offset group, tap): lanes with the same (pixel, group) count once
-            if (CG == 8 || (l4 & 1) == 0) {
-              ++n_samples;
-              n_outside += ((unsigned)ry0 < (unsigned)(DCN_PH - 1) && (unsigned)rx0 < (unsigned)(DCN_PW - 1)) ? 0u : 1u;
-            }
+        use[mt] = pin[mt] && !(dbg & 4);
+        const int q = (wave * MT + mt) * 16 + l15;
+        const h2 dd = *reinterpret_cast<const h2*>(offs + q * DCN_OSTR + (cb % OG) * NOFF + 2 * (gi * 9 + t));
+        const float mk = (float)msks[q * DCN_MSTR + (cb % MG) * NMSK + gi * 9 + t];
+        const float py = (float)(oy[mt] - 1 + trow) + (float)dd[0];
+        const float px = (float)(ox[mt] - 1 + tcol) + (float)dd[1];
+        const float fy = floorf(py), fx = floorf(px);
+        const float ly = py - fy, lx = px - fx;
+        // corner weights (x modulation mask) in fp16 pairs; the patch is zero outside the image, so corners outside the
+        // image contribute zero by themselves (= torchvision's per-corner test and its whole-sample test)
+        const float w11 = ly * lx * mk, w10 = (ly - ly * lx) * mk, w01 = (lx - ly * lx) * mk;
+        const float w00 = mk - w11 - w10 - w01;
+        hw[mt][0] = (_Float16)w00; hw[mt][1] = (_Float16)w01; hw[mt][2] = (_Float16)w10; hw[mt][3] = (_Float16)w11;
+        // clamp far-out samples before the int conversion (they are outside the patch and outside the image anyway)
+        ry0[mt] = (int)fminf(fmaxf(fy, -1.0e6f), 1.0e6f) - py0;
+        rx0[mt] = (int)fminf(fmaxf(fx, -1.0e6f), 1.0e6f) - px0;
+        inpatch[mt] = (unsigned)ry0[mt] < (unsigned)(DCN_PH - 1) && (unsigned)rx0[mt] < (unsigned)(DCN_PW - 1);
+        if constexpr (STATS) {            // one sample per (pixel, offset group, tap): lanes with the same (pixel, group) count once
+          if (use[mt] && (CG == 8 || (l4 & 1) == 0)) {
+            ++n_samples;
+            n_outside += inpatch[mt] ? 0u : 1u;
           }
-          if ((unsigned)ry0 < (unsigned)(DCN_PH - 1) && (unsigned)rx0 < (unsigned)(DCN_PW - 1)) {
-            // ---- all four corners inside the staged patch (the common case): 4 LDS reads, packed fp16 blend
-            const int pi0 = ry0 * DCN_PW + rx0;
+        }
+        far_lane = far_lane || (use[mt] && !inpatch[mt]);
+      }
+      if (__builtin_amdgcn_ballot_w64(far_lane) == 0ull) {
+        // ---- every sample of the wave inside the staged patch: 4 LDS reads, packed fp16 blend
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          h2 r2[4] = {h2{0, 0}, h2{0, 0}, h2{0, 0}, h2{0, 0}};
+          if (use[mt]) {
+            const int pi0 = ry0[mt] * DCN_PW + rx0[mt];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
               const int pi = pi0 + (c >> 1) * DCN_PW + (c & 1);
               const u32x4 raw = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(
                   (const __attribute__((address_space(3))) char*)patch + pi * 64 + (((l4 + 2 * (pi >> 2)) & 3) << 4));
               const h2* hv = reinterpret_cast<const h2*>(&raw);
-              const h2 wv = h2{hw[c], hw[c]};
+              const h2 wv = h2{hw[mt][c], hw[mt][c]};
 #pragma unroll
               for (int j = 0; j < 4; ++j) r2[j] = __builtin_elementwise_fma(wv, hv[j], r2[j]);
             }
-          } else {
-            // ---- some corner outside the patch (offset far from the tile mean): per-corner reads from global memory
-            const int y0 = ry0 + py0, x0 = rx0 + px0;
+          }
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              const int yy = y0 + (c >> 1), xx = x0 + (c & 1);
-              if ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) {
-                const u32x4 raw = *reinterpret_cast<const u32x4*>(sptr + ((img0 + (long long)yy * p.W + xx) * scs + sco + l4 * 8) * 2);
-                const h2* hv = reinterpret_cast<const h2*>(&raw);
-                const h2 wv = h2{hw[c], hw[c]};
+          for (int j = 0; j < 4; ++j) { af[mt][2 * j] = r2[j][0]; af[mt][2 * j + 1] = r2[j][1]; }
+        }
+      } else {
+        // ---- some sample of the wave leaves the patch: all reads of the tap first, one wait, one blend
+        const __amdgpu_buffer_rsrc_t rimg = uniform_buffer_rsrc(sptr + (img0 * scs + sco) * 2, p.H * p.W * scs * 2 - sco * 2);
+        u32x4 graw[MT][4], lraw[MT][4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) r2[j] = __builtin_elementwise_fma(wv, hv[j], r2[j]);
-              }
-            }
+        for (int mt = 0; mt < MT; ++mt) {
+          const bool far = use[mt] && !inpatch[mt];
+          const int y0 = ry0[mt] + py0, x0 = rx0[mt] + px0;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int yy = y0 + (c >> 1), xx = x0 + (c & 1);
+            const bool ok = far && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+            graw[mt][c] = __builtin_amdgcn_raw_buffer_load_b128(rimg, ok ? ((yy * p.W + xx) * scs + l4 * 8) * 2 : (int)0x80000000, 0, 0);
           }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { af[mt][2 * j] = r2[j][0]; af[mt][2 * j + 1] = r2[j][1]; }
+        for (int mt = 0; mt < MT; ++mt) {
+          const int pi0 = inpatch[mt] ? ry0[mt] * DCN_PW + rx0[mt] : 0;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int pi = pi0 + (c >> 1) * DCN_PW + (c & 1);
+            lraw[mt][c] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(
+                (const __attribute__((address_space(3))) char*)patch + pi * 64 + (((l4 + 2 * (pi >> 2)) & 3) << 4));
+          }
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          h2 r2[4] = {h2{0, 0}, h2{0, 0}, h2{0, 0}, h2{0, 0}};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            u32x4 raw = inpatch[mt] ? lraw[mt][c] : graw[mt][c];
+            if (!use[mt]) raw = u32x4{0, 0, 0, 0};
+            const h2* hv = reinterpret_cast<const h2*>(&raw);
+            const h2 wv = h2{hw[mt][c], hw[mt][c]};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r2[j] = __builtin_elementwise_fma(wv, hv[j], r2[j]);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { af[mt][2 * j] = r2[j][0]; af[mt][2 * j + 1] = r2[j][1]; }
+        }
       }
       // ---- this step's weights: every wave's two pieces have landed (own DMA: vmcnt, the others': barrier), the fragments go to
       //      registers, and once every wave holds its fragments the stage is refilled with the next step's weights
