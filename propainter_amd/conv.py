@@ -6,12 +6,14 @@ of the kernel); padded channels must hold finite values (zero-initialised buffer
 weights are zero.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
 
 from . import hip
 
+_CHECK_INPLACE = os.environ.get("PP_CHECK_INPLACE") == "1"     # diagnostic: see check_inplace
 ACTS = {None: hip.ACT_NONE, "none": hip.ACT_NONE, "relu": hip.ACT_RELU, "lrelu": hip.ACT_LRELU,
         "sigmoid": hip.ACT_SIGMOID, "tanh": hip.ACT_TANH, "gelu": hip.ACT_GELU}
 
@@ -137,6 +139,68 @@ def pconv_act_none(act):
     return act is None or ACTS[act] == hip.ACT_NONE
 
 
+inplace_findings = []     # filled by check_inplace when PP_CHECK_INPLACE=1 or a hazard recorder is active (diagnostic; see tools/check_hazards.py)
+
+
+def _windows_overlap(a, b):
+    """a, b: (first byte, row stride in bytes, window bytes, rows) of two channel windows of NHWC buffers.  True when some byte belongs to both."""
+    a0, sa, wa, ra = a
+    b0, sb, wb, rb = b
+    if a0 + (ra - 1) * sa + wa <= b0 or b0 + (rb - 1) * sb + wb <= a0:
+        return False
+    if sa != sb:
+        return True                       # differently strided views of overlapping extents: not analysed, reported
+    d = (b0 - a0) % sa
+    return d < wa or d + wb > sa
+
+
+def check_inplace(layer, srcs, out, out_choff, fuse=None, dcn_offmask=None):
+    """INTRA-launch hazard of one convolution launch: does the output window share bytes with a window the SAME launch reads at OTHER
+    pixels (its sources -- every tap reads neighbours, other cout tiles re-read the pixel -- or the deformable offsets)?  Blocks of one
+    launch are unordered, so such a launch is a race no stream / event edge can repair; the hazard recorder (inter-launch) cannot see it.
+    Epilogue operands (residual, pre-activation addend, h / z of the fused gating) are read at the very element that is written: in place
+    is well defined for them and they are not checked."""
+    esz = out.element_size()
+    rows_o = out.shape[0] * out.shape[1] * out.shape[2]
+    so = out.shape[-1] * esz
+    split_out = layer.split and out.dtype == torch.float16
+    zr = fuse is not None and fuse.get("out2") is not None          # fused z | r gating: `out` gets the first `split` couts, out2 the rest
+    plane = out.shape[-1] // 2 if split_out else out.shape[-1]
+    wo = min(int(fuse["split"]) if zr else layer.cout_pad * layer.groups, plane - out_choff)
+    outs = [(out.data_ptr() + out_choff * esz, so, wo * esz, rows_o)]
+    if split_out:
+        outs.append((out.data_ptr() + (plane + out_choff) * esz, so, wo * esz, rows_o))
+    if zr:
+        ot, oc = fuse["out2"] if not torch.is_tensor(fuse["out2"]) else (fuse["out2"], 0)
+        plane2 = ot.shape[-1] // 2 if split_out else ot.shape[-1]
+        w2 = min(layer.cout_pad - int(fuse["split"]), plane2 - oc)
+        outs.append((ot.data_ptr() + oc * esz, ot.shape[-1] * esz, w2 * esz, rows_o))
+        if split_out:
+            outs.append((ot.data_ptr() + (plane2 + oc) * esz, ot.shape[-1] * esz, w2 * esz, rows_o))
+    reads = []
+    for i, s in enumerate(srcs):
+        t, co = (s, 0) if torch.is_tensor(s) else s
+        rows = t.shape[0] * t.shape[1] * t.shape[2]
+        st = t.shape[-1] * t.element_size()
+        reads.append((f"source {i}", (t.data_ptr() + co * t.element_size(), st, layer.src_cpad[i] * t.element_size(), rows)))
+        if layer.split:
+            reads.append((f"source {i} (lo plane)", (t.data_ptr() + (layer.src_lo[i] + co) * t.element_size(), st, layer.src_cpad[i] * t.element_size(), rows)))
+    if dcn_offmask is not None:
+        reads.append(("deformable offsets / masks", (dcn_offmask.data_ptr(), dcn_offmask.shape[-1] * dcn_offmask.element_size(),
+                                                     dcn_offmask.shape[-1] * dcn_offmask.element_size(), rows_o)))
+    for name, r in reads:
+        for o in outs:
+            if _windows_overlap(r, o):
+                import traceback
+                where = next((f"{f.filename.split('/')[-1]}:{f.lineno}" for f in reversed(traceback.extract_stack()[:-1])
+                              if "conv.py" not in f.filename and "cpu_emulation" not in f.filename), "?")
+                inplace_findings.append(f"conv {layer.kh}x{layer.kw} cout {layer.cout} [{where}]: the output window overlaps {name}")
+    for i in range(len(outs)):
+        for j in range(i + 1, len(outs)):
+            if _windows_overlap(outs[i], outs[j]):
+                inplace_findings.append(f"conv {layer.kh}x{layer.kw} cout {layer.cout}: two output windows of one launch overlap")
+
+
 class ConvLayer:
     """One convolution / linear layer prepared for pp_conv2d (weights packed once, on the device)."""
 
@@ -225,6 +289,8 @@ class ConvLayer:
             out = (torch.zeros if cp != self.cout else torch.empty)((N, OH, OW, 2 * cp if (self.split and odt == torch.float16) else cp),
                                                                     dtype=odt, device=x0.device)
         split_out = self.split and out.dtype == torch.float16
+        if _CHECK_INPLACE or hip._hazard.active() is not None:
+            check_inplace(self, srcs, out, out_choff, fuse, dcn_offmask)
         a = hip.ConvArgs()
         a.dtype = hip.dtype_code(self.dtype)
         a.N, a.H, a.W, a.OH, a.OW = N, H, W, OH, OW

@@ -103,6 +103,8 @@ __global__ __launch_bounds__(256) void attn_ref_kernel(const AttnParams p) {
 }
 
 constexpr int KT = 64;          // keys per tile
+constexpr int ATTN_MAX_KEY_FRAMES = 256;     // key frames of a masked window per launch (the LDS table one block of 256 threads fills in one step;
+                                             // round 5 had 64 -- a 432x240 clip of more than ~1 200 frames at ref_stride 10 needs more)
 constexpr int KS_LD = HD;       // K tile row stride (elements): 256-byte rows, 16-byte slots XOR-swizzled by the key row
 constexpr int VS_LD = HD + 4;   // V tile row stride (elements): 264-byte rows (8-byte skew per key row for the transposing reads)
 
@@ -433,7 +435,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnParams p) {
   __shared__ __attribute__((aligned(16))) _Float16 Ks[KT * KS_LD];
   __shared__ __attribute__((aligned(16))) _Float16 Vs[KT * VS_LD];
   __shared__ int idx_lds[256];
-  __shared__ int tind_lds[64];
+  __shared__ int tind_lds[ATTN_MAX_KEY_FRAMES];
   __shared__ int koff_lds[256];
   const int head = blockIdx.x % p.heads;
   const int w = (blockIdx.x / p.heads) % p.nW;
@@ -456,7 +458,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_persistent_kernel(const Attn
   __shared__ __attribute__((aligned(16))) _Float16 Ks[KT * KS_LD];
   __shared__ __attribute__((aligned(16))) _Float16 Vs[KT * VS_LD];
   __shared__ int idx_lds[256];
-  __shared__ int tind_lds[64];
+  __shared__ int tind_lds[ATTN_MAX_KEY_FRAMES];
   __shared__ int koff_lds[256];
   const int total = p.work[0] * p.heads * gy;
   const int nxb = gridDim.x >> 3, xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;     // (gridDim.x is a multiple of 8)
@@ -592,7 +594,8 @@ extern "C" int pp_sparse_window_attention(const pp_attn_args_t* a, void* stream)
   PP_REQUIRE(a->wh * a->ww + a->n_rolled <= 256 && a->wh * a->ww <= 64, PP_ERR_ARG, "pp_sparse_window_attention: window too large");
   PP_REQUIRE(a->q && a->k && a->v && a->own && a->rolled && a->tind && a->wmask && a->out && (a->P == 0 || (a->pk && a->pv)),
              PP_ERR_ARG, "pp_sparse_window_attention: null pointer");
-  PP_REQUIRE(a->n_tind > 0 && a->n_tind <= a->T && a->n_tind <= 64, PP_ERR_ARG, "pp_sparse_window_attention: n_tind %d (1..min(T, 64))", a->n_tind);
+  PP_REQUIRE(a->n_tind > 0 && a->n_tind <= a->T && a->n_tind <= ATTN_MAX_KEY_FRAMES, PP_ERR_ARG, "pp_sparse_window_attention: n_tind %d (1..min(T, %d))", a->n_tind,
+             ATTN_MAX_KEY_FRAMES);
   const int esz = a->dtype == PP_F16 ? 2 : 4;
   PP_REQUIRE((a->qkv_cstride * esz) % 16 == 0 && (a->pkv_cstride * esz) % 16 == 0 && (uintptr_t)a->q % 16 == 0 &&
                  (uintptr_t)a->k % 16 == 0 && (uintptr_t)a->v % 16 == 0 && (uintptr_t)a->out % 16 == 0,

@@ -10,7 +10,11 @@ int conv_v2s_dispatch(const ConvParams& p, int cfg, hipStream_t stream) {
   for (int i = 0; i < p.nsrc; ++i) uni = uni && (long long)p.N * p.H * p.W * p.src[i].cstride * 2 < (1ll << 31);
   if (cfg >= 100) { uni = false; cfg -= 100; }
   if (cfg == 0) {   // the fp16 dispatch's choices (conv_v2_dispatch)
-    if (p.cout_g >= 512) cfg = 13;
+    // tri-product 1x1 layers with >= 256 couts and K >= 256 (RAFT's convc1: 324 correlation taps -> 256): one 256 x 256 tile fetches a
+    // pixel row once for all its couts -- 428 vs 480 us per 35-pair launch, bit-identical (profiles/r6_convc1_tile.txt); short-K layers
+    // (the encoders' 128 -> 256 projection) stay on the 128 x 128 tile
+    if (p.split == 2 && p.cout_g >= 256 && p.cout_g < 512 && p.kchunks >= 64) cfg = 18;
+    else if (p.cout_g >= 512) cfg = 13;
     else if (p.cout_g > 64) cfg = 12;
     else if (p.cout_g > 32) cfg = 22;
     else if (p.cout_g > 16) cfg = 32;
@@ -21,6 +25,7 @@ int conv_v2s_dispatch(const ConvParams& p, int cfg, hipStream_t stream) {
       case 12: return launch_v2<128, 128, 64, 2, 2, 2, 0, true, true>(p, uni, stream);
       case 13: return launch_v2<256, 128, 64, 4, 2, 3, 0, true, true>(p, uni, stream);
       case 22: return launch_v2<256, 64, 64, 4, 1, 2, 0, true, true>(p, uni, stream);
+      case 18: return launch_v2<256, 256, 64, 4, 2, 2, 0, true, true>(p, uni, stream);   // 8 waves of 64 x 128: every pixel row fetched once for 256 couts
       default: return -1000;
     }
   }

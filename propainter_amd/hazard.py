@@ -99,7 +99,7 @@ class Recorder(TorchDispatchMode):
         self.ngen = 0
         self.launches = 0
         self.pending = []                 # pointers of the engine launch being assembled
-        self.findings = {"alias": [], "race": [], "race?": [], "uninit": []}
+        self.findings = {"alias": [], "race": [], "race?": [], "uninit": [], "intra": []}
         self.cap_id = 0                   # > 0 while a graph is being captured: such accesses describe the GRAPH, not the host timeline
         self.ncap = 0
         self.seen = set()
@@ -239,6 +239,13 @@ class Recorder(TorchDispatchMode):
             self.capturing["r"].extend((lo, hi) for lo, hi, _ in reads)
             self.capturing["w"].extend((lo, hi) for lo, hi, _ in writes)
             self.capturing["n"] += 1
+        # class "intra": ONE launch reads and writes overlapping bytes.  Well defined for element-wise kernels (each thread reads the element
+        # it writes); a race for anything that reads neighbours (warps, resamplers, stencils) -- blocks of a launch are unordered.  Listed by
+        # kernel name for review; strided channel windows (convolutions) are checked exactly by conv.check_inplace instead.
+        for wlo, whi, wstr in writes:
+            for rlo, rhi, rstr in reads:
+                if rlo < whi and wlo < rhi and not (wstr and rstr):
+                    self._report("intra", ("intra", name), f"{desc} reads [{rlo:#x},{rhi:#x}) and writes [{wlo:#x},{whi:#x}) in the same launch")
         for is_write, ranges in ((False, reads), (True, writes)):
             for lo, hi, strided in ranges:
                 g = self._find(lo)

@@ -65,6 +65,8 @@ def _conv_call(self, srcs, out=None, out_choff=0, act=None, act_param=0.0, out_s
     N, H, W = x0.shape[:3]
     OH, OW = out_hw if out_hw is not None else self.out_hw(H, W)
     sp = bool(getattr(self, "split", False))
+    if out is not None:
+        pconv.check_inplace(self, srcs, out, out_choff, fuse, dcn_offmask)      # the intra-launch hazard check sees every emulated launch
     if out is None:
         cp = pconv.pad8(self.cout)
         odt = out_dtype or self.dtype

@@ -106,6 +106,31 @@ def test_clip_pipeline_graph(models):
     assert (comp != g["comp"]).mean() < 0.01
 
 
+def test_no_convolution_launch_of_the_pass_writes_what_it_reads_at_other_pixels(models):
+    """Intra-launch hazards (conv.check_inplace): the blocks of ONE launch are unordered, so a convolution whose output window shares
+    bytes with one of its own sources (or with its deformable offsets) is a race no stream / event edge can repair -- and one the
+    capture-time recorder, which orders LAUNCHES, cannot see.  Every convolution of the whole clip pass (split-plane RAFT, both
+    flow-completion chunks' forms, batched propagation, transformer, decoder) goes through the check; a planted in-place launch is found."""
+    import propainter_amd.conv as pconv
+    from propainter_amd.pipeline import InferenceConfig, run_clip
+    g = load_golden("e2e_128x192.npz")
+    cfg = InferenceConfig(raft_iter=2, subvideo_length=int(g["subvideo_length"]), neighbor_length=int(g["neighbor_length"]),
+                          ref_stride=int(g["ref_stride"]), fp16=False)
+    del pconv.inplace_findings[:]
+    with emulated_device_ops():
+        run_clip(models, g["frames_u8"], g["masks_u8"], g["masks_u8"], cfg, torch.device("cpu"))
+    assert pconv.inplace_findings == [], pconv.inplace_findings[:5]
+    # the planted case: a 3x3 convolution writing into the channel window it reads
+    w = torch.zeros(8, 8, 3, 3)
+    layer = pconv.ConvLayer(w, None, padding=1, src_channels=[8], dtype=torch.float32, device=torch.device("cpu"))
+    buf = torch.zeros(1, 4, 4, 16)
+    pconv.check_inplace(layer, [(buf, 0)], buf, 0)
+    assert len(pconv.inplace_findings) == 1 and "overlaps source 0" in pconv.inplace_findings[0]
+    del pconv.inplace_findings[:]
+    pconv.check_inplace(layer, [(buf, 0)], buf, 8)          # the neighbouring channel window of the same rows: disjoint bytes
+    assert pconv.inplace_findings == []
+
+
 def test_batched_feature_propagation_graph(models):
     """pipeline.run_clip with the windows' feature propagation batched (InpaintGenerator.propagate_windows) against the per-window
     chain, under the CPU emulation of the device ops: the host logic (step-major gathers, per-window read-back, the windows that stay on

@@ -763,6 +763,31 @@ def test_sparse_window_attention_against_rolled_tensors(dev, grid):
         check(f"attention_vs_rolled_tensors_{Hp}x{Wp}_{dt}", out, ref, lim)
 
 
+def test_sparse_window_attention_with_more_than_64_key_frames(dev):
+    """A long clip's window: 140 frames, temporal dilation 2 -> 70 key frames in a masked window's key set (the reference has no limit:
+    sparse_transformer.py:337-342 builds T_ind for any t; rounds 1-5 stopped at 64, the kernel's key-frame table is 256 entries now).
+    Against the tensor-rolling reference, both kernels."""
+    from propainter_amd import hip
+    Hp, Wp = 10, 18
+    g = torch.Generator().manual_seed(164)
+    B, T, C = 1, 140, 512
+    q, k, v = (torch.randn(B, T, Hp, Wp, C, generator=g) for _ in range(3))
+    P = (Hp // 4) * (Wp // 4)
+    pk, pv = torch.randn(B, T, P, C, generator=g), torch.randn(B, T, P, C, generator=g)
+    wmask = torch.tensor([[1.0, 0.0, 0.0, 3.0]])
+    tind = torch.arange(1, T, 2)
+    assert tind.numel() == 70
+    for dt, lim in ((torch.float32, 2e-4), (torch.float16, 6e-3)):
+        cast = lambda a: a.to(dt).float()
+        ref = _attention_by_rolling_tensors(cast(q), cast(k), cast(v), cast(pk), cast(pv), tind, wmask)
+        own_np, rolled_np = hip.window_tables(Hp, Wp)
+        out = hip.sparse_window_attention(q.to(dev, dt), k.to(dev, dt), v.to(dev, dt), pk.to(dev, dt), pv.to(dev, dt),
+                                          torch.from_numpy(own_np).to(dev), torch.from_numpy(rolled_np).to(dev),
+                                          tind.to(dev, torch.int32), wmask.to(dev), impl=0 if dt == torch.float16 else 1)
+        torch.cuda.synchronize()
+        check(f"attention_70_key_frames_{dt}", out, ref, lim)
+
+
 @pytest.mark.parametrize("variant", ["ref_f32", "ref_f16", "mfma_f16"])
 def test_sparse_window_attention(dev, variant):
     from propainter_amd import hip

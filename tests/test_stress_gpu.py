@@ -307,8 +307,9 @@ def test_documented_limits_raise_loudly():
     """Where the engine is NARROWER than the reference it must say so instead of returning something else (missing #4):
       * RAFT below 128 px: the reference's level-3 correlation map is 1 px wide and its bilinear_sampler divides by W - 1 = 0
         (RAFT/utils/utils.py:61-62: NaN flows); the engine raises ValueError;
-      * more than 64 key frames in one dilation phase of a window (t > 64 * t_dilation): the attention kernel's key-frame table has
-        64 entries; the reference has no such limit (sparse_transformer.py:337-342) -- RuntimeError naming n_tind;
+      * more than 256 key frames in one dilation phase of a window (t > 256 * t_dilation): the attention kernel's key-frame table has
+        256 entries (64 until round 5; 70 key frames are a parity test now: tests/test_ops_gpu.py); the reference has no such limit
+        (sparse_transformer.py:337-342) -- RuntimeError naming n_tind;
       * a window of ONE frame: layer 1's T_ind = arange(1, 1, 2) is empty (the reference attends to zero keys there); RuntimeError."""
     from propainter_amd import hip
     models = seeded_models("cuda")
@@ -317,7 +318,7 @@ def test_documented_limits_raise_loudly():
     Hp, Wp, C = 5, 9, 512
     own_np, rolled_np = hip.window_tables(Hp, Wp)
     own, rolled = torch.from_numpy(own_np).cuda(), torch.from_numpy(rolled_np).cuda()
-    for T, tind in ((66, torch.arange(0, 66, dtype=torch.int32)), (1, torch.zeros(0, dtype=torch.int32))):
+    for T, tind in ((258, torch.arange(0, 258, dtype=torch.int32)), (1, torch.zeros(0, dtype=torch.int32))):
         q = torch.zeros(1, T, Hp, Wp, C, dtype=torch.float16, device="cuda")
         pk = torch.zeros(1, T, 2, C, dtype=torch.float16, device="cuda")
         with pytest.raises(RuntimeError, match="n_tind|pointer"):

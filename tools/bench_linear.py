@@ -39,5 +39,12 @@ for name, K, N in (("qkv", 512, 1536), ("proj", 512, 512), ("fc1", 512, 1960), (
     t_lib = timeit(lambda: F.linear(x, wd, bd))
     t_mm = timeit(lambda: torch.mm(x, wd.t()))
     fl = 2.0 * M * K * N
+    if N % 64:                                             # output rows padded to a multiple of 128 bytes (same couts, aligned stores)
+        Np = (N + 63) // 64 * 64
+        outp = torch.zeros(1, 1, M, Np, dtype=torch.float16, device=dev)
+        layer(xs, out=outp)
+        assert torch.equal(outp[..., :N], out[..., :N])
+        t_al = timeit(lambda: layer(xs, out=outp))
+        print(f"LINEAR {name:8s} engine with the output row stride {Np}: {t_al * 1e3:7.1f} us = {fl / t_al / 1e9:6.0f} TFLOP/s")
     print(f"LINEAR {name:8s} M {M} K {K} N {N}: engine {t_mine * 1e3:7.1f} us = {fl / t_mine / 1e9:6.0f} TFLOP/s | F.linear {t_lib * 1e3:7.1f} us = {fl / t_lib / 1e9:6.0f} | "
           f"mm (no bias) {t_mm * 1e3:7.1f} us = {fl / t_mm / 1e9:6.0f} | max |engine - lib| {err:.3g}")

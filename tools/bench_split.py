@@ -57,7 +57,7 @@ def main():
     # halo layers: the 128-pixel kernel (71: 128-cout tiles, 72: 64-cout tiles) against the ping-pong kernel (82 / 83, conv_halo8.h), each twice
     halo_alt = [71, 82, 71, 82]
     halo_alt64 = [72, 83, 72, 83]
-    v2_alt = [0, 12, 13, 22]
+    v2_alt = [0, 12, 13, 18, 22, 0, 18]
     # name, N, H, W, cin list, cout, k, stride, pad, impls, extras
     L = [
         ("convc1_1x1_324", P, h, w, [324], 256, (1, 1), 1, 0, v2_alt, dict(act="relu")),

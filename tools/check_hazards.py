@@ -75,6 +75,8 @@ rep = rec.report()
 rep["replay_detail"] = detail if mode in ("stream", "multi") else None
 rep.update(mode=mode, frames=L, subvideo=S, height=H, width=W, stages=stages if mode == "stream" else None,
            replays_equal_eager=same, seconds=round(time.time() - t0, 1), stream_names=len(rec.names))
-for k in ("alias", "race", "race?", "uninit"):
+for k in ("alias", "race", "race?", "uninit", "intra"):
     rep[k + "_count"] = len(rep[k])
+from propainter_amd import conv as _pconv                                                # noqa: E402
+rep["conv_inplace"] = list(_pconv.inplace_findings)      # conv.check_inplace: exact channel-window test of every convolution launch
 print("HAZARDS " + json.dumps(rep), flush=True)
