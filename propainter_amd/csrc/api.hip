@@ -62,3 +62,28 @@ extern "C" int pp_conv_pack_weight(const float* weight, int cout, int kh, int kw
     }
   return cout_pad;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// [diagnosis, round 6] Explicit cache maintenance as a kernel of its own: every XCD of the chip has its own L2, which is not
+// coherent with the others' for ordinary device memory -- visibility between kernels is the command processor's job (release =
+// write-back at the end of the producer, acquire = invalidate before the consumer).  This kernel does both by hand, one wave
+// per block, enough blocks that every XCD runs some (blocks are dealt to the XCDs round-robin):
+//   mode & 1: buffer_wbl2 sc0 sc1 -- write the XCD's dirty L2 lines back (what a producer's release does);
+//   mode & 2: buffer_inv  sc0 sc1 -- drop the XCD's non-coherent lines (what a consumer's acquire does).
+// sharding.StreamingClipGraph places it on the cross-branch edges of the stage-pipelined single graph under PP_SG_FENCE=1 to test
+// whether the run-to-run deviation of that form is a visibility defect of cross-queue edges (profiles/r6_graph_queues.txt).
+// Not part of include/propainter_hip.h: no product path calls it.
+// ------------------------------------------------------------------------------------------------------------------
+namespace pp {
+__global__ __launch_bounds__(64) void cache_fence_kernel(int mode) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (mode & 1) asm volatile("buffer_wbl2 sc0 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+  if (mode & 2) asm volatile("buffer_inv sc0 sc1" ::: "memory");
+#endif
+}
+}  // namespace pp
+
+extern "C" int pp_debug_cache_fence(int mode, void* stream) {
+  hipLaunchKernelGGL(pp::cache_fence_kernel, dim3(64), dim3(64), 0, (hipStream_t)stream, mode);
+  return pp::launch_status("pp_debug_cache_fence");
+}

@@ -213,6 +213,12 @@ def _stream(t):
     return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
+def debug_cache_fence(device, mode=3):
+    """[diagnosis] one small kernel on the CURRENT stream of `device` that writes back (mode & 1) and / or invalidates (mode & 2) the L2 of
+    every XCD (csrc/api.hip: pp_debug_cache_fence).  Used by sharding.StreamingClipGraph under PP_SG_FENCE=1 only."""
+    _check(lib().pp_debug_cache_fence(C.c_int(int(mode)), C.c_void_p(torch.cuda.current_stream(device).cuda_stream)), "pp_debug_cache_fence")
+
+
 _side_streams = {}
 
 

@@ -21,6 +21,7 @@ import os
 import numpy as np
 import torch
 
+from . import hip
 from .pipeline import (InferenceConfig, _dev_index, _window_streams, compute_flows, subvideo_chunks, window_schedule)
 
 
@@ -963,6 +964,10 @@ class StreamingClipGraph:
                 # load, lanes on / off made no difference); with this map every stage of every rank equals the eager pass and the pass is
                 # 2 % faster (flow completion is latency-bound and overlaps the windows' tail either way).  PP_SG_STAGES overrides (diagnosis).
                 on_side = {int(v) for v in os.environ.get("PP_SG_STAGES", "0,2").split(",") if v != ""}
+                # PP_SG_FENCE (diagnosis, round 6; bit 0: L2 write-back kernel in front of every segment's event, bit 1: L2 invalidate kernel
+                # behind every cross-branch wait): tests whether the deviation of the three-branch map is a cache-visibility defect of
+                # cross-queue graph edges (profiles/r6_graph_queues.txt)
+                fence = int(os.environ.get("PP_SG_FENCE", "0"))
                 stage = [side[i] if i in on_side else cur for i in range(3)] + [cur, cur]
                 side = [st for st in side if st in stage]
                 for st in side:
@@ -976,17 +981,21 @@ class StreamingClipGraph:
                     pending.pop(i)
                     st = stage[s]
                     with torch.cuda.stream(st):
-                        got = None
+                        got, crossed = None, False
                         if s > 0:
                             got = {}
                             if stage[s - 1] is not st:
                                 st.wait_event(done[(r, s - 1)])
+                                crossed = True
                             for q, (shape, dtype) in sorted(reqs[(r, s - 1)].recv.items()):
                                 t = reqs[(q, s - 1)].send[r]
                                 assert tuple(t.shape) == tuple(shape) and t.dtype == dtype, (reqs[(r, s - 1)].tag, r, q, t.shape, shape)
                                 if stage[s - 1] is not st:
                                     st.wait_event(done[(q, s - 1)])
+                                    crossed = True
                                 got[q] = t
+                            if crossed and fence & 2:      # [diagnosis] acquire by hand behind the cross-branch waits
+                                hip.debug_cache_fence(dev, 2)
                         try:
                             ex = next(gens[r]) if s == 0 else gens[r].send(got)
                         except StopIteration as stop:
@@ -998,6 +1007,8 @@ class StreamingClipGraph:
                             self._single_debug = getattr(self, "_single_debug", {})
                             self._single_debug[(r, s)] = {k: (v.t if isinstance(v, Span) else v) for fr_ in _generator_frames(gens[r])
                                                           for k, v in fr_.f_locals.items() if torch.is_tensor(v) or isinstance(v, Span)}
+                        if fence & 1:                      # [diagnosis] release by hand in front of the event other branches wait for
+                            hip.debug_cache_fence(dev, 1)
                         ev = torch.cuda.Event()
                         ev.record(st)
                         done[(r, s)] = ev
