@@ -1,4 +1,5 @@
 #!/bin/bash
+# (profiles/r6_stream_counts.txt)
 # round 6: window / RAFT stream counts re-measured on the final kernels (same box, back to back)
 F="--no-cpu-baseline --no-profile --no-precisions --no-configs --no-stress --steps 5 --warmup 2"
 for cfg in "2 2" "3 2" "4 2" "2 3" "2 4" "3 3" "2 2"; do
