@@ -239,16 +239,20 @@ class _GenEngine:
         for l_t, firsts in by_len.items():
             firsts = sorted(set(firsts))
             step = firsts[1] - firsts[0] if len(firsts) > 1 else 1
-            if len(firsts) < 2 or l_t < 2 or any(b - a != step for a, b in zip(firsts, firsts[1:])):
+            if l_t < 2:
                 continue
             # batches of at most `bmax` windows: the step-major gather of a batch stays below ~2.5 GB (five such tensors are alive during
             # the chain; launches over >= 8 frames already run at the large-M rate, profiles/r4_batched_propagation.txt)
             per_window = l_t * h * w * 128 * enc.element_size()
             bmax = max(2, min(len(firsts), int(self.prop_batch_bytes // per_window)))
+            if any(b - a != step for a, b in zip(firsts, firsts[1:])):
+                bmax = 1                      # no arithmetic progression of first frames: every window a group of its own
             for b0 in range(0, len(firsts), bmax):
                 group = firsts[b0:b0 + bmax]
-                if len(group) < 2:
-                    continue                  # a single left-over window: per-window path
+                # (round 6: a single window -- the clip's first / last windows, whose lengths differ from the rest -- is a group of ONE and
+                #  goes through the same path: its recurrent chain of ~100 small launches then runs on the pass's main stream in
+                #  ensure_propagated, never inside a window LANE.  Captured into a hipGraph, lanes carrying those chains gave ~5 % of the replays
+                #  a few hundred wrong bytes in one frame of exactly these windows -- profiles/r6_replay_bytes.txt; same arithmetic either way.)
                 gid = len(clip["prop_groups"])
                 clip["prop_groups"].append((l_t, group, step))
                 clip["prop_left"][gid] = len(group)

@@ -326,15 +326,20 @@ def test_rolling_propagation_bookkeeping(models):
         eng.prop_batch_bytes = 3 * (5 * 4 * 4 * 128 * 4)                      # three 5-frame windows per group
         windows = [(f, 5) for f in range(0, 35, 5)] + [(35, 4)]               # seven equal windows and a shorter last one
         eng.propagate_windows(clip, windows)
-        assert [g[1] for g in clip["prop_groups"]] == [[0, 5, 10], [15, 20, 25]]      # the 7th window is a left-over single: per-window path
-        assert set(clip["prop_plan"]) == {(f, 5) for f in (0, 5, 10, 15, 20, 25)} and clip["prop"] == {} and not calls
+        # (round 6: a left-over single window and the shorter last window are groups of ONE -- their chains run on the pass's main stream too,
+        #  never inside a window lane: profiles/r6_replay_bytes.txt)
+        assert [g[1] for g in clip["prop_groups"]] == [[0, 5, 10], [15, 20, 25], [30], [35]]
+        assert set(clip["prop_plan"]) == {(f, 5) for f in (0, 5, 10, 15, 20, 25, 30)} | {(35, 4)} and clip["prop"] == {} and not calls
         eng.ensure_propagated(clip, 0, 5)
         assert calls == [(5, 3, 4, 4, 128)] and set(clip["prop"]) == {(0, 5), (5, 5), (10, 5)}
         assert clip["prop"][(0, 5)][0] is clip["prop"][(10, 5)][0] and [clip["prop"][(f, 5)][1] for f in (0, 5, 10)] == [0, 1, 2]
         eng.ensure_propagated(clip, 5, 5)                                      # already there
-        eng.ensure_propagated(clip, 30, 5)                                     # not batched
-        eng.ensure_propagated(clip, 35, 4)
         assert len(calls) == 1
+        eng.ensure_propagated(clip, 35, 4)                                     # a group of one: the same batched form with B = 1
+        assert calls[-1] == (4, 1, 4, 4, 128) and clip["prop"][(35, 4)][1] == 0
+        eng.release_window(clip, 35, 4)
+        assert (35, 4) not in clip["prop"]
+        calls.pop()
         eng.release_window(clip, 0, 5)
         eng.release_window(clip, 5, 5)
         assert set(clip["prop"]) == {(0, 5), (5, 5), (10, 5)}                # the group lives until its last window
