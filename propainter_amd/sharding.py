@@ -963,7 +963,10 @@ class StreamingClipGraph:
                 # +-1 byte in 0.2 % of that sub-video's bytes; smaller clips never showed it, the kernels are bit-stable next to unrelated
                 # load, lanes on / off made no difference); with this map every stage of every rank equals the eager pass and the pass is
                 # 2 % faster (flow completion is latency-bound and overlaps the windows' tail either way).  PP_SG_STAGES overrides (diagnosis).
-                on_side = {int(v) for v in os.environ.get("PP_SG_STAGES", "0,2").split(",") if v != ""}
+                # Round 6 (profiles/r6_replay_bytes.txt): what goes wrong on a forked branch is a long chain of small dependent launches -- flow
+                # completion here, a window's feature propagation in the whole-pass graph (~5 % of its replays until round 6).  Image
+                # propagation (158 steps of 20 us) is such a chain too, so the default map keeps only RAFT's large launches on a branch.
+                on_side = {int(v) for v in os.environ.get("PP_SG_STAGES", "0").split(",") if v != ""}
                 # PP_SG_FENCE (diagnosis, round 6; bit 0: L2 write-back kernel in front of every segment's event, bit 1: L2 invalidate kernel
                 # behind every cross-branch wait): tests whether the deviation of the three-branch map is a cache-visibility defect of
                 # cross-queue graph edges (profiles/r6_graph_queues.txt)
