@@ -58,7 +58,7 @@ with hazard.Recorder(dev, stacks=os.environ.get("PP_HAZARD_STACKS") == "1") as r
         s.load(clip, masks, masks)
         s.capture()
         outs, replay_ms = [], []
-        for _ in range(3):
+        for _ in range(int(os.environ.get("PP_HZ_REPLAYS", "3"))):
             import warnings
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
@@ -66,10 +66,10 @@ with hazard.Recorder(dev, stacks=os.environ.get("PP_HAZARD_STACKS") == "1") as r
                 out = s.replay(concurrent=True) if mode == "multi" else s.replay()
                 torch.cuda.synchronize(); replay_ms.append(round((time.time() - tr0) * 1e3, 1))
             same.append(bool(torch.equal(out, ref)))
-            outs.append(out.clone())
+            outs.append(out.clone() if len(outs) < 6 else out)
         # a deviation that is the SAME in every replay is a different (deterministic) computation; one that changes is a race
         detail = {"replay_ms_under_the_recorder": replay_ms, "replay_i_equals_replay_0": [bool(torch.equal(o, outs[0])) for o in outs],
-                  "frames_differing_from_eager": [[int(j) for j in range(L) if bool((o[j] != ref[j]).any())][:12] for o in outs],
+                  "frames_differing_from_eager": [[int(j) for j in range(L) if bool((o[j] != ref[j]).any())][:12] for o in outs[:6]],
                   "bytes_differing_from_eager": [int((o != ref).sum()) for o in outs],
                   "max_abs_vs_eager": [int((o.to(torch.int16) - ref.to(torch.int16)).abs().max()) for o in outs]}
     torch.cuda.synchronize()
