@@ -788,7 +788,7 @@ class StreamingClipGraph:
 
     NSEG = 5          # compute segments of sharded_clip_steps: RAFT | completion | image propagation | windows | boundary blends
 
-    def __init__(self, models, L, H, W, cfg, device, world=None, volume_gb=40.0, share_pool=True, single_graph=False, validate=3):
+    def __init__(self, models, L, H, W, cfg, device, world=None, volume_gb=40.0, share_pool=True, single_graph=False, validate=8):
         """DEFAULT (round 6): one graph per (rank, segment) in ONE memory pool, replayed chained in the wavefront order -- the form that
         has never produced a wrong byte.  The overlapped form is opt-in because its failure mode is silent and unexplained: the
         capture-time hazard checker (propainter_amd/hazard.py, tools/check_hazards.py) finds NO unordered access in the stage-pipelined
@@ -797,9 +797,9 @@ class StreamingClipGraph:
         bytes sits below the submitted program (runtime / cache coherence between concurrently running branches), so a validation on
         the capture clip can only sample it.
 
-        single_graph=True (round 5): the whole wavefront as ONE hipGraph, pipelined by stage -- RAFT and image
-        propagation of the sub-videos on two branches forked from the capture stream, flow completion, the generator windows and the
-        boundary blends on the capture stream, the exchanges as direct tensor hand-overs ordered by captured events
+        single_graph=True (round 5): the whole wavefront as ONE hipGraph, pipelined by stage -- RAFT of the sub-videos on a
+        branch forked from the capture stream (round 5 had image propagation on a second one: PP_SG_STAGES), flow completion, image
+        propagation, the generator windows and the boundary blends on the capture stream, the exchanges as direct tensor hand-overs ordered by captured events
         (``_capture_single_graph``); ``validate`` replays of the captured graph are compared bit for bit with the eager pass at capture
         time, and a graph that does not reproduce it is replaced by the chained per-segment graphs (with a warning).  The overlap of the
         schedule lives INSIDE one graph (parallel branches: the form the whole-pass ClipGraph and the generator lanes use), not in
