@@ -83,9 +83,14 @@ def loaded_library_path():
     return _build.LIB_PATH if _lib is not None else None
 
 
+_FENCE_EVERY_LAUNCH = int(os.environ.get("PP_FENCE_EVERY_LAUNCH", "0"))      # diagnosis (profiles/r6_replay_bytes.txt): L2 write-back / invalidate kernel behind every engine launch
+
+
 def _check(rc, what):
     if _hazard.active() is not None:          # capture-time hazard checker (propainter_amd/hazard.py): this launch's pointers are complete
         _hazard.active().flush(what)
+    if _FENCE_EVERY_LAUNCH and rc == 0 and what != "pp_debug_cache_fence" and torch.cuda.is_available():
+        lib().pp_debug_cache_fence(C.c_int(_FENCE_EVERY_LAUNCH), C.c_void_p(torch.cuda.current_stream().cuda_stream))
     if rc != 0:
         msg = lib().pp_last_error_string().decode(errors="replace")
         raise RuntimeError(f"{what} failed (code {rc}): {msg}")

@@ -15,6 +15,7 @@ Engine notes (all algebraically identical to the reference, see oracle/propainte
     convolution; forward-backward consistency checks of all propagation steps run as one batched launch.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -253,6 +254,8 @@ class _GenEngine:
                 #  goes through the same path: its recurrent chain of ~100 small launches then runs on the pass's main stream in
                 #  ensure_propagated, never inside a window LANE.  Captured into a hipGraph, lanes carrying those chains gave ~5 % of the replays
                 #  a few hundred wrong bytes in one frame of exactly these windows -- profiles/r6_replay_bytes.txt; same arithmetic either way.)
+                if len(group) < 2 and os.environ.get("PP_CHAIN_IN_LANES") == "1":
+                    continue                  # [diagnosis] rounds 2-5: a single window propagates inside its lane (the defect of profiles/r6_replay_bytes.txt)
                 gid = len(clip["prop_groups"])
                 clip["prop_groups"].append((l_t, group, step))
                 clip["prop_left"][gid] = len(group)
