@@ -15,15 +15,21 @@ from propainter_amd.pipeline import ClipGraph, InferenceConfig, run_clip        
 from propainter_amd.synthetic import seeded_models, synthetic_clip, synthetic_mask    # noqa: E402
 
 EAGER = "eager" in sys.argv
+STRESS = "stress" in sys.argv           # the stress recipe: full-size heads, opposite-moving layers, every attention window masked
 IMPLS = dict(a.split("=") for a in sys.argv[1:] if "=" in a)      # e.g. dcn=1 off=1 bb=1: kernel family of the propagation layers (diagnosis)
-argv = [a for a in sys.argv[1:] if a != "eager" and "=" not in a]
+argv = [a for a in sys.argv[1:] if a not in ("eager", "stress") and "=" not in a]
 N, WS, RS, L, H, W = (int(v) for v in (argv[:6] + ["40", "2", "2", "80", "720", "1280"][len(argv):]))
 dev = torch.device("cuda")
-models = seeded_models(dev, raft_precision="f16x3")
+models = seeded_models(dev, raft_precision="f16x3", recipe="stress" if STRESS else "tame")
 cfg = InferenceConfig(fp16=True, window_streams=WS, raft_streams=RS)
-clip = torch.from_numpy(synthetic_clip(L, H, W)).to(dev)
-m = scipy.ndimage.binary_dilation(synthetic_mask(H, W), iterations=4).astype(np.uint8) * 255
-masks = torch.from_numpy(np.repeat(m[None], L, 0)).to(dev)
+if STRESS:
+    from propainter_amd.synthetic import case_inputs
+    c_, m_ = case_inputs(L, H, W, "stress")
+    clip, masks = torch.from_numpy(c_).to(dev), torch.from_numpy(m_).to(dev)
+else:
+    clip = torch.from_numpy(synthetic_clip(L, H, W)).to(dev)
+    m = scipy.ndimage.binary_dilation(synthetic_mask(H, W), iterations=4).astype(np.uint8) * 255
+    masks = torch.from_numpy(np.repeat(m[None], L, 0)).to(dev)
 if IMPLS:
     run_clip(models, clip, masks, masks, cfg, dev)          # builds the engines
     eng = models[2]._engine[1]
@@ -49,7 +55,7 @@ for i in range(N):
                "bytes_off_by_more_than_1": int((d > 1).sum())}
         bad.append(rec)
         print("REPLAY_DIFF " + json.dumps(rec), flush=True)
-print("REPLAY_BYTES " + json.dumps({"replays": N, "mode": "eager passes" if EAGER else "graph replays", "ms_per_pass_incl_compare": round((time.time() - t0) / N * 1e3, 1), "deviating": len(bad), "window_streams": WS, "raft_streams": RS, "clip": f"{H}x{W}x{L}",
+print("REPLAY_BYTES " + json.dumps({"replays": N, "mode": "eager passes" if EAGER else "graph replays", "ms_per_pass_incl_compare": round((time.time() - t0) / N * 1e3, 1), "deviating": len(bad), "window_streams": WS, "raft_streams": RS, "clip": f"{H}x{W}x{L}" + (" stress recipe" if STRESS else ""),
                                     "second_eager_pass_identical": eager_same, "lib": os.environ.get("PP_LIB_PATH", "in-tree"),
                                     "queues": os.environ.get("DEBUG_HIP_FORCE_GRAPH_QUEUES"), "prop_layer_impls": IMPLS or None,
                                     "env": {k: v for k, v in os.environ.items() if k in ("PP_CHAIN_IN_LANES", "PP_FENCE_EVERY_LAUNCH")}}), flush=True)
