@@ -625,17 +625,10 @@ def main(argv=None, runtime=None):
     # profiles/r6_replay_bytes.txt; one comparison per run cannot see that.)  Outside the timed region, on the device.
     replay_consistency = None
     if rank == 0 and world == 1 and graph is not None and rt.extras and args.replay_checks > 0 and dev.type == "cuda":
-        first = graph.replay().clone()
-        differing, worst = 0, 0
-        for _ in range(args.replay_checks):
-            o_ = graph.replay()
-            if not torch.equal(o_, first):
-                differing += 1
-                worst = max(worst, int((o_.to(torch.int16) - first.to(torch.int16)).abs().max()))
+        differing, worst = graph.self_check(args.replay_checks)          # pipeline.ClipGraph.self_check
         rt.sync()
         replay_consistency = {"replays_compared_with_the_first": args.replay_checks, "differing": differing, "max_abs": worst,
-                              "first_equals_last_timed_step": bool(timed_out is not None and np.array_equal(first.cpu().numpy(), timed_out))}
-        del first
+                              "last_equals_last_timed_step": bool(timed_out is not None and np.array_equal(graph.out.cpu().numpy(), timed_out))}
     host_submit = [host_submit[0]] + [host_submit[i] - host_submit[i - 1] for i in range(1, len(host_submit))]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
