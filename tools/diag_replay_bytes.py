@@ -38,6 +38,30 @@ if IMPLS:
             key = "dcn" if lname == "dcn" else ("off" if lname.startswith("off") else "bb")
             if key in IMPLS:
                 layer.impl = int(IMPLS[key])
+    if "gen3x3" in IMPLS:        # every other multi-tap stride-1 convolution of the generator (encoder tail, fusion, decoder, SoftComp bias conv): the halo family's layers
+        from propainter_amd.conv import ConvLayer
+        seen, n_set = set(), 0
+
+        def walk(o, depth=0):
+            global n_set
+            if id(o) in seen or depth > 6:
+                return
+            seen.add(id(o))
+            if isinstance(o, ConvLayer):
+                if o.kh * o.kw > 1 and tuple(o.stride) == (1, 1) and not getattr(o, "dcn", False) and o.impl == 0:
+                    o.impl = int(IMPLS["gen3x3"])
+                    n_set += 1
+            elif isinstance(o, dict):
+                for v in o.values():
+                    walk(v, depth + 1)
+            elif isinstance(o, (list, tuple)):
+                for v in o:
+                    walk(v, depth + 1)
+            elif hasattr(o, "__dict__") and type(o).__module__.startswith("propainter_amd"):
+                for v in vars(o).values():
+                    walk(v, depth + 1)
+        walk(eng)
+        print(f"REPLAY_NOTE {n_set} generator convolutions set to impl {IMPLS['gen3x3']}", flush=True)
 ref = run_clip(models, clip, masks, masks, cfg, dev).clone()
 eager_same = bool(torch.equal(run_clip(models, clip, masks, masks, cfg, dev), ref))
 torch.cuda.synchronize()
