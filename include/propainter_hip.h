@@ -395,7 +395,10 @@ int pp_nchw_to_nhwc(const void* in, int in_dtype, void* out, int out_dtype, int 
 
 /* Encoder input packer: up to three planar sources [N,c_i,H,W] of one dtype (c0 + c1 + c2 <= 8; in1 / in2 may be NULL with c = 0) ->
  * NHWC [N,H,W,8], missing channels zero, one launch writing whole 16-byte rows.  Replaces the reference's
- * torch.cat([frames, masks_in, masks_updated], dim=2) in front of the Encoder (model/propainter.py:334-336). */
+ * torch.cat([frames, masks_in, masks_updated], dim=2) in front of the Encoder (model/propainter.py:334-336) and the
+ * cat(masked_flows, masks) in front of the flow-completion encoder (model/recurrent_flow_completion.py:279).
+ * dtype PP_F16S: fp32 sources -> split-plane fp16 rows [N,H,W,8 hi | 8 lo] (pp_nchw_to_nhwc's split arithmetic, whole 32-byte rows):
+ * the frames entering RAFT's encoders (RAFT/raft.py:96-99). */
 int pp_pack_nhwc8(const void* in0, int c0, const void* in1, int c1, const void* in2, int c2, void* out, int N, int H, int W,
                   int dtype, void* stream);
 int pp_nhwc_to_nchw(const void* in, int in_dtype, int in_cstride, int in_choff, void* out, int out_dtype, int N,

@@ -425,6 +425,25 @@ __global__ __launch_bounds__(256) void pack_nhwc8_kernel(const T* __restrict__ a
   }
 }
 
+// The same packer for the split-plane engine (PP_F16S): fp32 planar sources -> [8 ch hi | 8 ch lo] fp16 per pixel, hi = fp16(v), lo = fp16(v - hi)
+// (pp_nchw_to_nhwc's split arithmetic), one 32-byte row store per pixel instead of two 2-byte stores per (pixel, channel).
+__global__ __launch_bounds__(256) void pack_nhwc8_split_kernel(const float* __restrict__ a, int ca, const float* __restrict__ b, int cb,
+                                                               const float* __restrict__ c, int cc, _Float16* __restrict__ out, long long N, int HW) {
+  const long long total = N * HW;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long n = i / HW;
+    const int p = (int)(i - n * HW);
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j < ca) v[j] = a[(n * ca + j) * HW + p];
+      else if (j < ca + cb) v[j] = b[(n * cb + (j - ca)) * HW + p];
+      else if (j < ca + cb + cc) v[j] = c[(n * cc + (j - ca - cb)) * HW + p];
+    }
+    store8_split(out + i * 16, out + i * 16 + 8, v);
+  }
+}
+
 template <typename TI, typename TO>
 __global__ void nhwc_to_nchw_kernel(const TI* __restrict__ in, int ics, int ico, TO* __restrict__ out, int N, int C, int HW,
                                     int act) {
@@ -616,9 +635,14 @@ extern "C" int pp_pack_nhwc8(const void* in0, int c0, const void* in1, int c1, c
   PP_REQUIRE(in0 && out && N > 0 && H > 0 && W > 0 && c0 > 0 && c1 >= 0 && c2 >= 0 && c0 + c1 + c2 <= 8, PP_ERR_ARG,
              "pp_pack_nhwc8: bad arguments (%d + %d + %d channels must be 1..8)", c0, c1, c2);
   PP_REQUIRE((c1 == 0 || in1) && (c2 == 0 || in2), PP_ERR_ARG, "pp_pack_nhwc8: a source with channels needs a pointer");
-  PP_REQUIRE(dtype == PP_F32 || dtype == PP_F16, PP_ERR_DTYPE, "pp_pack_nhwc8: dtype %d", dtype);
+  PP_REQUIRE(dtype == PP_F32 || dtype == PP_F16 || dtype == PP_F16S, PP_ERR_DTYPE, "pp_pack_nhwc8: dtype %d", dtype);
   PP_REQUIRE((uintptr_t)out % 16 == 0, PP_ERR_ALIGN, "pp_pack_nhwc8: out must be 16-byte aligned");
   const int g = grid_for((long long)N * H * W);
+  if (dtype == PP_F16S) {      // fp32 sources -> split-plane rows [N,H,W,8 hi | 8 lo]
+    hipLaunchKernelGGL(pack_nhwc8_split_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)in0, c0, (const float*)in1, c1,
+                       (const float*)in2, c2, (_Float16*)out, (long long)N, H * W);
+    return launch_status("pp_pack_nhwc8");
+  }
   PP_DISPATCH_T(dtype, hipLaunchKernelGGL((pack_nhwc8_kernel<T>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const T*)in0, c0, (const T*)in1, c1,
                                           (const T*)in2, c2, (T*)out, (long long)N, H * W);)
   return launch_status("pp_pack_nhwc8");

@@ -788,20 +788,23 @@ def nchw_to_nhwc(x, out=None, out_choff=0, out_dtype=None, cpad=None, scale=1.0,
     return out
 
 
-def pack_nhwc8(srcs, out=None):
+def pack_nhwc8(srcs, out=None, split=False):
     """srcs: one to three planar [N,c_i,H,W] tensors of one dtype with sum(c_i) <= 8 -> NHWC [N,H,W,8], missing channels zero; one launch
-    that writes whole 16-byte rows (the encoder input cat(frame, mask, updated mask), model/propainter.py:334-336)."""
+    that writes whole 16-byte rows (the encoder input cat(frame, mask, updated mask), model/propainter.py:334-336).  split: fp32 sources ->
+    split-plane fp16 [N,H,W,8 hi | 8 lo] (the RAFT encoders' input of the f16x3 engine), whole 32-byte rows."""
     x0 = srcs[0]
     N, _, H, W = x0.shape
     assert 1 <= len(srcs) <= 3 and all(t.is_contiguous() and t.dtype == x0.dtype and t.shape[0] == N and t.shape[2:] == x0.shape[2:] for t in srcs)
     cs = [t.shape[1] for t in srcs] + [0] * (3 - len(srcs))
-    assert sum(cs) <= 8
+    assert sum(cs) <= 8 and (not split or x0.dtype == torch.float32)
+    oshape, odt = ((N, H, W, 16), torch.float16) if split else ((N, H, W, 8), x0.dtype)
     if out is None:
-        out = torch.empty((N, H, W, 8), dtype=x0.dtype, device=x0.device)
-    assert out.is_contiguous() and out.dtype == x0.dtype and tuple(out.shape) == (N, H, W, 8)
+        out = torch.empty(oshape, dtype=odt, device=x0.device)
+    assert out.is_contiguous() and out.dtype == odt and tuple(out.shape) == oshape
     ptrs = [_p(t) for t in srcs] + [None] * (3 - len(srcs))
-    timed("nchw_to_nhwc", 0, _nbytes(out) * 2, lambda: _check(lib().pp_pack_nhwc8(ptrs[0], _i(cs[0]), ptrs[1], _i(cs[1]), ptrs[2], _i(cs[2]), _pw(out), _i(N),
-                                                                            _i(H), _i(W), _i(dtype_code(x0.dtype)), _stream(x0)), "pp_pack_nhwc8"))
+    timed("nchw_to_nhwc", 0, sum(_nbytes(t) for t in srcs) + _nbytes(out),
+          lambda: _check(lib().pp_pack_nhwc8(ptrs[0], _i(cs[0]), ptrs[1], _i(cs[1]), ptrs[2], _i(cs[2]), _pw(out), _i(N), _i(H), _i(W),
+                                             _i(PP_F16S if split else dtype_code(x0.dtype)), _stream(x0)), "pp_pack_nhwc8"))
     return out
 
 

@@ -418,7 +418,7 @@ class RAFT_bi(nn.Module):
         fm, cx_ = [], []
         for s in range(0, b * l_t, fchunk):
             if eng.split:     # split-plane engine: [n, H, W, 8 hi | 8 lo] fp16 planes of the fp32 frames
-                x = hip.nchw_to_nhwc(fr[s:s + fchunk].contiguous().float(), cpad=8, split=True)
+                x = hip.pack_nhwc8([fr[s:s + fchunk].contiguous().float()], split=True)
             else:
                 x = hip.nchw_to_nhwc(fr[s:s + fchunk].contiguous(), out_dtype=dt, cpad=8)
             f_, c_ = hip.fork_join(dev, [lambda: eng.encode(eng.fnet, x, True), lambda: eng.encode(eng.cnet, x, False)], streams)

@@ -121,9 +121,12 @@ class _FCEngine:
     def _encode(self, masked_flows, masks):
         """downsample + P3D encoders + dilated mid convs of ONE sequence [t,2,H,W] / [t,1,H,W] (:272-286)."""
         t, _, H, W = masked_flows.shape
-        x = torch.zeros((t, H, W, 8), dtype=self.dtype, device=masked_flows.device)
-        hip.nchw_to_nhwc(masked_flows.contiguous(), out=x, out_choff=0)
-        hip.nchw_to_nhwc(masks.contiguous(), out=x, out_choff=2)
+        if masked_flows.dtype == self.dtype and masks.dtype == self.dtype:     # one launch, whole 16-byte rows
+            x = hip.pack_nhwc8([masked_flows.contiguous(), masks.contiguous()])
+        else:
+            x = torch.zeros((t, H, W, 8), dtype=self.dtype, device=masked_flows.device)
+            hip.nchw_to_nhwc(masked_flows.contiguous(), out=x, out_choff=0)
+            hip.nchw_to_nhwc(masks.contiguous(), out=x, out_choff=2)
         x = self.down([x], act="lrelu", act_param=0.2)
         feats = []
         for si, (spatial, temporal) in enumerate(self.p3d):

@@ -352,13 +352,13 @@ def _gru_gate(zr, h, h_choff, Cc, out, out_choff, q=None):
     return out
 
 
-def _pack_nhwc8(srcs, out=None):
+def _pack_nhwc8(srcs, out=None, split=False):
     x = torch.cat(list(srcs), 1)
     N, c, H, W = x.shape
     if out is None:
-        out = torch.empty((N, H, W, 8), dtype=x.dtype, device=x.device)
+        out = torch.empty((N, H, W, 16 if split else 8), dtype=torch.float16 if split else x.dtype, device=x.device)
     out.zero_()
-    out[..., :c] = x.permute(0, 2, 3, 1)
+    _put(out, 0, x.float().permute(0, 2, 3, 1), split) if split else out[..., :c].copy_(x.permute(0, 2, 3, 1))
     return out
 
 

@@ -392,6 +392,26 @@ def test_pack_nhwc8_equals_three_window_writes(dev, dt):
         hip.pack_nhwc8([torch.zeros(N, 5, H, W, dtype=dt, device=dev), torch.zeros(N, 4, H, W, dtype=dt, device=dev)])
 
 
+def test_pack_nhwc8_split_plane_equals_the_split_window_write(dev):
+    """pp_pack_nhwc8 with dtype PP_F16S (fp32 frames -> [8 hi | 8 lo] fp16 rows, the RAFT encoders' input of the f16x3 engine) against
+    pp_nchw_to_nhwc's split-plane window write into a zeroed buffer: identical bytes, odd sizes; hi + lo restores 22 bits of the input."""
+    from propainter_amd import hip
+    g = torch.Generator().manual_seed(10)
+    N, H, W = 2, 41, 67
+    a = (torch.randn(N, 3, H, W, generator=g) * 3).to(dev)
+    b = torch.rand(N, 1, H, W, generator=g).to(dev)
+    ref = hip.nchw_to_nhwc(a, cpad=8, split=True)
+    hip.nchw_to_nhwc(b, out=ref, out_choff=3, split=True)
+    out = torch.full((N, H, W, 16), 7.0, dtype=torch.float16, device=dev)
+    assert hip.pack_nhwc8([a, b], out=out, split=True) is out
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    back = (out[..., :4].float() + out[..., 8:12].float()).permute(0, 3, 1, 2)
+    assert (back - torch.cat([a, b], 1)).abs().max().item() <= 3 * 4 * 2.0 ** -22
+    with pytest.raises(AssertionError):
+        hip.pack_nhwc8([a.half()], split=True)
+
+
 def test_conv2d_output_window_and_large_m(dev):
     """writes into a channel window of a wider buffer; M not a multiple of the tile; asymmetric data (transposes)."""
     from propainter_amd.conv import ConvLayer
