@@ -49,6 +49,7 @@ FAMILIES = [   # (substring of the demangled OR mangled kernel name, family)
     ("img_prop", "img_prop_step"),
     ("convex_upsample", "convex_upsample"),
     ("nchw_to_nhwc", "nchw_to_nhwc"),
+    ("pack_nhwc8", "nchw_to_nhwc"),
     ("nhwc_to_nchw", "nhwc_to_nchw"),
     ("window_mask", "window_mask"),
     ("raft_flow_taps", "raft_flow_taps"),
