@@ -117,6 +117,10 @@ def parse(argv=None):
                     help="RAFT encoders / pair-direction groups on this many HIP streams (InferenceConfig.raft_streams; identical flows)")
     ap.add_argument("--window-streams", type=int, default=2,
                     help="generator windows in flight on separate HIP streams (pipeline.InferenceConfig.window_streams)")
+    ap.add_argument("--graph-lanes", action="store_true",
+                    help="keep the window / RAFT lanes INSIDE the captured hipGraph (pipeline.ClipGraph(forked_branches=True)); default: the "
+                         "captured pass is one chain of launches -- with forked branches config 5 left wrong bytes in 3 of 64 replays "
+                         "(profiles/r6_c5_replays.txt); the lanes still serve eager submission")
     ap.add_argument("--single-pass", action="store_true",
                     help="profiling aid: run exactly ONE eager pass of the clip and exit (what the rocprofv3 passes of "
                          "tools/gpu_profile.sh wrap, so that per-kernel counts are per pass)")
@@ -569,7 +573,7 @@ def main(argv=None, runtime=None):
             # the graph gets a private pool as large as the eager pass's: when the eager pools already hold more than a third of the
             # device (long clips / 1080p), hand them back to the driver first
             big = rt.reserved(dev) > rt.total_memory(dev) // 3
-            graph = ClipGraph(models, L, H, W, cfg, dev, example=(frames_dev, masks_dev, masks_dev), release_eager_pool=big)
+            graph = ClipGraph(models, L, H, W, cfg, dev, example=(frames_dev, masks_dev, masks_dev), release_eager_pool=big, forked_branches=args.graph_lanes)
             rt.sync()
         except Exception as e:       # capture refused (driver / runtime state): measure the eager submission instead of dying
             sys.stderr.write(f"[bench] hipGraph capture failed on rank {rank} ({type(e).__name__}: {e}); falling back to eager launches\n")
@@ -712,7 +716,10 @@ def main(argv=None, runtime=None):
     raft_precisions = None
     raft = models[0]
     submission = ("hipGraph replays of the compute segments between the halo exchanges (sharding.ShardedClipGraph)" if sgraph is not None else
-                  "eager (Python launches)" if graph is None else "hipGraph replay of the whole pass (pipeline.ClipGraph)")
+                  "eager (Python launches)" if graph is None else
+                  "hipGraph replay of the whole pass (pipeline.ClipGraph" + (", window / RAFT lanes as forked branches)" if args.graph_lanes else
+                                                                             ", one chain of launches: no forked branches)"))
+    lanes_in_effect = (1, 1) if (graph is not None or sgraph is not None) and not args.graph_lanes else (args.window_streams, args.raft_streams)
     if rank == 0 and world == 1 and not args.no_precisions and not sharded and rt.extras:
         raft_precisions = {args.raft_dtype: {"value": fps, "ms_per_step": ms_per_step, "timed": "headline (see value)"}}
         had_graph = graph is not None
@@ -731,7 +738,7 @@ def main(argv=None, runtime=None):
                     try:
                         from propainter_amd.pipeline import ClipGraph
                         torch.cuda.empty_cache()          # the eager pass's cached blocks back to the driver: the capture builds its own pool
-                        g = ClipGraph(models, L, H, W, cfg, dev, example=(frames_dev, masks_dev, masks_dev))
+                        g = ClipGraph(models, L, H, W, cfg, dev, example=(frames_dev, masks_dev, masks_dev), forked_branches=args.graph_lanes)
                         how = "mean of 2 hipGraph replays"
                     except Exception as e:
                         sys.stderr.write(f"[bench] capture at RAFT {prec} failed ({type(e).__name__}: {e}); eager\n")
@@ -794,7 +801,7 @@ def main(argv=None, runtime=None):
                 c2f, c2mk = torch.from_numpy(c2clip).to(dev), torch.from_numpy(np.repeat(c2m[None], 80, 0)).to(dev)
                 cfg2 = dataclasses.replace(cfg, subvideo_length=80, neighbor_length=10, ref_stride=10)
                 run_clip(models, c2f, c2mk, c2mk, cfg2, dev)
-                g2 = ClipGraph(models, 80, 240, 432, cfg2, dev, example=(c2f, c2mk, c2mk))
+                g2 = ClipGraph(models, 80, 240, 432, cfg2, dev, example=(c2f, c2mk, c2mk), forked_branches=args.graph_lanes)
                 g2.replay()
                 rt.sync()
                 t1 = time.perf_counter()
@@ -831,7 +838,7 @@ def main(argv=None, runtime=None):
                     rt.sync()
                 skern = {k: round(v["ms"], 1) for k, v in sorted(kps.summary().items(), key=lambda kv: -kv[1]["ms"])[:8]}
                 rt.empty_cache()
-                gs = ClipGraph(smodels, L, H, W, cfg, dev, example=(sf, smk, smk))
+                gs = ClipGraph(smodels, L, H, W, cfg, dev, example=(sf, smk, smk), forked_branches=args.graph_lanes)
                 gs.replay()
                 rt.sync()
                 t1 = time.perf_counter()
@@ -909,7 +916,8 @@ def main(argv=None, runtime=None):
             "data": "synthetic (seeded clip + rectangular mask dilated x4, seeded weights of the reference architecture)",
             "config": {"workload": work, "height": H, "width": W, "frames": L, "windows": len(sched),
                        "raft_dtype": args.raft_dtype, "stages_dtype": "f16" if fp16 else "f32", "parallelism": par,
-                       "window_streams": args.window_streams, "raft_streams": args.raft_streams},
+                       "window_streams": lanes_in_effect[0], "raft_streams": lanes_in_effect[1],
+                       "eager_window_streams": args.window_streams, "eager_raft_streams": args.raft_streams},
             "roofline": roof, "cpu_baseline": cpu, "parity_timed_output": parity_timed, "replay_consistency": replay_consistency, "parity": parity,
             "parity_windows_with_reference_frames": parity_refs,
             "fallback": fallback, "configs": configs, "stress": stress, "raft_precisions": raft_precisions,

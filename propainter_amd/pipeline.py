@@ -328,7 +328,17 @@ class ClipGraph:
         out_u8 = g(frames_u8, flow_masks_u8, masks_dilated_u8)   # uint8 [L,H,W,3] on device (static buffer)
     """
 
-    def __init__(self, models, L, H, W, cfg: InferenceConfig, device, example=None, release_eager_pool=False):
+    def __init__(self, models, L, H, W, cfg: InferenceConfig, device, example=None, release_eager_pool=False, forked_branches=False):
+        # forked_branches=False (default): the captured pass is ONE chain of launches -- no window lanes, no RAFT lanes.  Results are the
+        # same bytes either way (the lanes only reorder independent work), but on ROCm 7.2 a hipGraph with forked branches does not
+        # replay this pass reliably at every size: BASELINE config 5 (1080x1920x160, subvideo_length 20) with the 2 + 2 lanes left wrong
+        # bytes (max |d| 25) in 3 of 64 replays, the same graph without forked branches in 0 of 84; the 720x1280x80 pass with lanes
+        # 0 of ~250 (profiles/r6_c5_replays.txt).  The eager pass keeps cfg's lanes (30 eager passes with lanes: 0 deviations).
+        # forked_branches=True keeps cfg.window_streams / cfg.raft_streams inside the capture (-2 ... -3 % per pass): run self_check().
+        import dataclasses
+        if not forked_branches:
+            cfg = dataclasses.replace(cfg, window_streams=1, raft_streams=1)
+        self.cfg = cfg
         self.shape = (L, H, W)
         self.frames = torch.zeros((L, H, W, 3), dtype=torch.uint8, device=device)
         self.flow_masks = torch.zeros((L, H, W), dtype=torch.uint8, device=device)

@@ -477,6 +477,8 @@ class ShardedClipGraph:
     def __init__(self, models, L, H, W, cfg, device, rank, world, pool=None):
         """``pool`` (optional graph memory pool handle): capture into this pool instead of a private one -- for several logical ranks of
         ONE process whose graphs are replayed strictly in their capture order (StreamingClipGraph(share_pool=True))."""
+        import dataclasses
+        cfg = dataclasses.replace(cfg, window_streams=1, raft_streams=1)      # no forked branches inside a captured segment (pipeline.ClipGraph)
         self.models, self.cfg, self.device, self.rank, self.world, self.L = models, cfg, torch.device(device), rank, world, L
         self._pool = pool
         self.r0, self.r1 = ShardPlan(L, cfg, world).need_raw(rank)
@@ -813,7 +815,9 @@ class StreamingClipGraph:
         if not can_shard(L, cfg, self.world):
             raise ValueError(f"a {L}-frame clip does not split into {self.world} sub-video blocks of {cfg.subvideo_length} frames")
         self.models, self.L, self.H, self.W = models, L, H, W
-        self.cfg = dataclasses.replace(cfg, raft_streams=1)         # the ranks run next to each other: one RAFT lane each
+        # one RAFT lane per rank (the ranks run next to each other) and no window lanes: no forked branches inside a captured graph beyond
+        # the stage map's own (pipeline.ClipGraph: config 5 with lanes left wrong bytes in 3 of 64 replays, without in 0 of 84)
+        self.cfg = dataclasses.replace(cfg, raft_streams=1, window_streams=1)
         self.volume_gb = float(volume_gb)
         self.single_graph = bool(single_graph)
         self.validate = int(validate)       # single_graph: replays checked bit for bit against the eager warm-up pass at capture time (0: off)

@@ -61,7 +61,8 @@ def test_whole_pass_graph_of_a_small_clip_has_no_unordered_access():
     ref = run_clip(models, clip, masks, masks, cfg, dev).clone()
     torch.cuda.synchronize()
     with hazard.Recorder(dev) as rec:
-        g = ClipGraph(models, L, H, W, cfg, dev, example=(torch.from_numpy(clip).to(dev), torch.from_numpy(masks).to(dev), torch.from_numpy(masks).to(dev)))
+        g = ClipGraph(models, L, H, W, cfg, dev, example=(torch.from_numpy(clip).to(dev), torch.from_numpy(masks).to(dev), torch.from_numpy(masks).to(dev)),
+                      forked_branches=True)          # the multi-stream capture (window / RAFT lanes as forked branches) is the form under check
         out = g.replay()
         torch.cuda.synchronize()
     rep = rec.report()

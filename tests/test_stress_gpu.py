@@ -386,6 +386,7 @@ def test_every_replay_of_the_whole_pass_graph_leaves_the_same_bytes():
         masks = torch.from_numpy(np.repeat(m[None], L, 0)).to(dev)
         ref = run_clip(models, clip, masks, masks, cfg, dev).clone()
         g = ClipGraph(models, L, H, W, cfg, dev, example=(clip, masks, masks), release_eager_pool=True)
+        assert g.cfg.window_streams == 1 and g.cfg.raft_streams == 1      # ... and a captured pass is one chain of launches (no forked branches)
         bad = []
         for i in range(30):
             out = g.replay()

@@ -45,7 +45,7 @@ with hazard.Recorder(dev, stacks=os.environ.get("PP_HAZARD_STACKS") == "1") as r
         for _ in range(2):
             same.append(bool(torch.equal(run_clip(models, clip, masks, masks, cfg, dev), ref)))
     elif mode == "clip":
-        g = ClipGraph(models, L, H, W, cfg, dev, example=(clip, masks, masks))
+        g = ClipGraph(models, L, H, W, cfg, dev, example=(clip, masks, masks), forked_branches=True)      # the multi-stream form is what is checked
         for _ in range(2):
             same.append(bool(torch.equal(g.replay(), ref)))
     else:

@@ -1,6 +1,7 @@
 """How often does a replay of the whole-pass hipGraph (pipeline.ClipGraph) leave bytes that differ from the eager pass?  (round 6: one default bench run
 ended with `parity_timed_output.max_abs` 21 -- ~500 hole bytes off by more than one in the LAST timed replay -- where ten earlier runs had 1.)
-    python tools/diag_replay_bytes.py [replays=40] [window_streams=2] [raft_streams=2] [frames=80] [height=720] [width=1280] [eager]
+    python tools/diag_replay_bytes.py [replays=40] [window_streams=2] [raft_streams=2] [frames=80] [height=720] [width=1280] [eager] [sub=80]
+(sub=20: BASELINE config 5's --subvideo_length)
 One line per deviating replay (frames, bytes, max |d|) and a summary `REPLAY_BYTES {...}`.  PP_LIB_PATH selects another build of the library."""
 import json
 import os
@@ -21,7 +22,8 @@ argv = [a for a in sys.argv[1:] if a not in ("eager", "stress") and "=" not in a
 N, WS, RS, L, H, W = (int(v) for v in (argv[:6] + ["40", "2", "2", "80", "720", "1280"][len(argv):]))
 dev = torch.device("cuda")
 models = seeded_models(dev, raft_precision="f16x3", recipe="stress" if STRESS else "tame")
-cfg = InferenceConfig(fp16=True, window_streams=WS, raft_streams=RS)
+SUB = int(IMPLS.pop("sub", 80))
+cfg = InferenceConfig(fp16=True, window_streams=WS, raft_streams=RS, subvideo_length=SUB)
 if STRESS:
     from propainter_amd.synthetic import case_inputs
     c_, m_ = case_inputs(L, H, W, "stress")
@@ -65,7 +67,7 @@ if IMPLS:
 ref = run_clip(models, clip, masks, masks, cfg, dev).clone()
 eager_same = bool(torch.equal(run_clip(models, clip, masks, masks, cfg, dev), ref))
 torch.cuda.synchronize()
-g = None if EAGER else ClipGraph(models, L, H, W, cfg, dev, example=(clip, masks, masks))
+g = None if EAGER else ClipGraph(models, L, H, W, cfg, dev, example=(clip, masks, masks), forked_branches=True)      # the lanes under test stay inside the capture
 import time
 t0 = time.time()
 bad = []
@@ -79,7 +81,7 @@ for i in range(N):
                "bytes_off_by_more_than_1": int((d > 1).sum())}
         bad.append(rec)
         print("REPLAY_DIFF " + json.dumps(rec), flush=True)
-print("REPLAY_BYTES " + json.dumps({"replays": N, "mode": "eager passes" if EAGER else "graph replays", "ms_per_pass_incl_compare": round((time.time() - t0) / N * 1e3, 1), "deviating": len(bad), "window_streams": WS, "raft_streams": RS, "clip": f"{H}x{W}x{L}" + (" stress recipe" if STRESS else ""),
+print("REPLAY_BYTES " + json.dumps({"replays": N, "mode": "eager passes" if EAGER else "graph replays", "ms_per_pass_incl_compare": round((time.time() - t0) / N * 1e3, 1), "deviating": len(bad), "window_streams": WS, "raft_streams": RS, "clip": f"{H}x{W}x{L}" + (" stress recipe" if STRESS else ""), "subvideo_length": SUB,
                                     "second_eager_pass_identical": eager_same, "lib": os.environ.get("PP_LIB_PATH", "in-tree"),
                                     "queues": os.environ.get("DEBUG_HIP_FORCE_GRAPH_QUEUES"), "prop_layer_impls": IMPLS or None,
                                     "env": {k: v for k, v in os.environ.items() if k in ("PP_CHAIN_IN_LANES", "PP_FENCE_EVERY_LAUNCH")}}), flush=True)
