@@ -23,6 +23,8 @@ class InferenceConfig:
     ref_stride: int = 10
     fp16: bool = False
     batch_propagation: bool = True       # feature propagation of equal-length generator windows as one batch (InpaintGenerator.propagate_windows)
+    # (both lane settings act on EAGER submission; a captured pass -- ClipGraph and the sharded graphs -- is one chain of launches unless
+    #  forked_branches=True: a forked hipGraph replayed wrongly a few per cent of the time at config 5, profiles/r6_c5_replays.txt)
     window_streams: int = 2      # engine extension: generator windows in flight on separate HIP streams (bit-identical results;
                                  # measured 1167.7 -> 1102.9 ms per 720p clip with 2, 1114.6 with 3: profiles/r2_window_streams.txt)
     raft_streams: int = 2        # engine extension: RAFT's two encoders, and its pair-directions in this many groups, on separate
